@@ -1,0 +1,338 @@
+"""CPU restatement (numpy, fp32) of the reference's audio -> dgrad/offsets inference path.
+
+TEST INFRASTRUCTURE ONLY -- this is the parity oracle, not the product:
+only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import
+it, and only as the checker / the timed CPU baseline.  The product path
+(sdfa-2019_amd/) never imports anything under oracle/ and has no CPU fallback.
+
+Pinned (tests/test_oracle_golden.py, `-m "not gpu"`) against tests/golden/*.npz, which
+were produced by running the reference itself in the build container
+(oracle/gen_golden.py).  Two third-party pieces are restated from published
+librosa==0.8.0 behaviour and are *parity unpinned against the real library*
+(oracle/librosa_restate.py): the Slaney mel filterbank and the Savitzky-Golay delta.
+
+Every function cites the reference lines it follows (paths relative to /root/reference).
+"""
+import math
+import numpy as np
+
+from librosa_restate import mel_filters as _mel_filters
+
+F32 = np.float32
+EPS = np.float32(1.1920929e-07)   # torch.finfo(float32).eps, spectrogram.py:238
+
+
+# ----------------------------------------------------------------------------------------
+# a1  frame enumeration / timestamps
+# ----------------------------------------------------------------------------------------
+def frame_geometry(sr, win_s=0.064, hop_s=0.008, frames=64):
+    """speech_anime/datasets/sliding_window.py:339-343"""
+    win = int(win_s * sr)
+    hop = int(hop_s * sr)
+    return win, hop, hop * (frames - 1) + win
+
+
+def frame_index(n_samples, sr, fps=60, frames=64, win_s=0.064, hop_s=0.008, ts_delta=100):
+    """Window starts and millisecond timestamps, bit-exact.
+
+    speech_anime/datasets/sliding_window.py:345-354 with the float32 unit converters
+    of speech_anime/datasets/speech_anime.py:135-145 (`dtype(float(x))` roundings) and
+    Python's round-half-even.  Raises AssertionError exactly where the reference's
+    assert at sliding_window.py:363 fires (a window that would need padding on both sides).
+    """
+    _, _, sliding = frame_geometry(sr, win_s, hop_s, frames)
+    starts, tslist = [], []
+    idx = -1.0
+    while F32(float(idx * sr) / float(fps)) + sliding <= n_samples + sliding * 2:   # :320-322, :348
+        m = math.floor(F32(float(idx * sr) / float(fps)))                            # :349
+        e = m + sliding // 2
+        s = e - sliding
+        ts = F32(float(((s + e) / 2) * 1000.0) / float(sr))                          # speech_anime.py:135-139
+        ts = ts - ts_delta                                                           # :353 (float32 - int)
+        tslist.append(int(round(ts)))                                                # :354
+        if not (max(0, s) >= min(n_samples, e)):                                     # non-empty slice
+            assert not (s < 0 and e > n_samples), \
+                f"signal length {min(n_samples, e) - 0 + (-s)} != {sliding}."        # :363
+        starts.append(s)
+        idx += 1.0
+    return np.asarray(starts, np.int64), np.asarray(tslist, np.int64)
+
+
+def cut_windows(pcm, starts, sliding):
+    """Zero-padded windows, sliding_window.py:356-362."""
+    L = len(pcm)
+    out = np.zeros((len(starts), sliding), F32)
+    for i, s in enumerate(starts):
+        a, b = max(0, int(s)), min(L, int(s) + sliding)
+        if b > a:
+            out[i, a - int(s): b - int(s)] = pcm[a:b]
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# a2-a4  pre-emphasis, STFT, mel, dB, deltas
+# ----------------------------------------------------------------------------------------
+_SG1 = (np.arange(-4, 5) / 60.0)
+_SG2 = np.array([28, 7, -8, -17, -20, -17, -8, 7, 28], np.float64) / 462.0
+
+
+def savgol_delta(mel, order):
+    """librosa.feature.delta(order=n) == savgol_filter(width 9, polyorder n, deriv n, 'interp').
+
+    get_features.py:199-207.  Interior: 9-tap correlation; edges: the degree-n polynomial
+    fitted to the first/last 9 samples, differentiated n times -- for polyorder == deriv
+    that derivative is a constant, equal to the first/last interior value.
+    """
+    c = _SG1 if order == 1 else _SG2
+    x = mel.astype(np.float64)
+    T = x.shape[-1]
+    out = np.empty_like(x)
+    acc = np.zeros(x.shape[:-1] + (T - 8,), np.float64)
+    for j in range(9):
+        acc += c[j] * x[..., j:j + T - 8]
+    out[..., 4:T - 4] = acc
+    out[..., :4] = acc[..., :1]
+    out[..., T - 4:] = acc[..., -1:]
+    return out
+
+
+def mel_constants(sr, win):
+    hamm = np.hamming(win).astype(F32)                               # features/misc.py:94-100
+    melw = _mel_filters(sr, win, 128, 50, 3600).astype(F32)          # features/misc.py:110-117
+    return hamm, melw
+
+
+def frontend_windows(windows, sr, win, hop, preemph=0.65, ref_db=20.0, top_db=80.0):
+    """(F, sliding) -> (F, 64, 128, 3) float32."""
+    hamm, melw = mel_constants(sr, win)
+    Fn, sliding = windows.shape
+    T = (sliding - win) // hop + 1
+    # a2: features/misc.py:8-17, per WINDOW (first sample unfiltered)
+    y = np.empty_like(windows)
+    y[:, 0] = windows[:, 0]
+    y[:, 1:] = windows[:, 1:] - F32(preemph) * windows[:, :-1]
+    # a3: spectrogram.py:82-98  torch.stft(center=False, onesided) -> power -> mel matmul
+    idx = np.arange(win)[None, :] + hop * np.arange(T)[:, None]
+    fr = y[:, idx] * hamm[None, None, :]                             # (F, T, win) float32
+    spec = np.fft.rfft(fr.astype(np.float64), axis=-1)
+    re = spec.real.astype(F32)
+    im = spec.imag.astype(F32)
+    power = re * re + im * im                                        # (F, T, bins) float32
+    mel = np.matmul(power, melw.T)                                   # (F, T, 128)
+    # spectrogram.py:238,245-249
+    db = F32(10.0) * np.log10(np.maximum(mel, EPS)).astype(F32)
+    nrm = np.clip((db - F32(ref_db) + F32(top_db)) / F32(top_db), 0.0, 1.0).astype(F32)
+    m = np.transpose(nrm, (0, 2, 1))                                 # (F, 128, T)
+    d1 = savgol_delta(m, 1)
+    d2 = savgol_delta(m, 2)
+    feat = np.stack([m.astype(np.float64), d1, d2], axis=1).astype(F32)   # (F, 3, 128, T); get_features.py:210-223
+    return np.ascontiguousarray(np.transpose(feat, (0, 3, 2, 1)))    # sliding_window.py:462 -> (F, T, 128, 3)
+
+
+def fetch_audio_features(pcm, sr, chunk=64):
+    """DatasetSlidingWindow.fetch_audio_features (sliding_window.py:324-377) minus `energy`."""
+    pcm = np.asarray(pcm, F32)
+    assert -1.0 <= pcm.min() and pcm.max() <= 1.0                    # :330
+    win, hop, sliding = frame_geometry(sr)
+    starts, tslist = frame_index(len(pcm), sr)
+    feats = []
+    for i in range(0, len(starts), chunk):
+        w = cut_windows(pcm, starts[i:i + chunk], sliding)
+        feats.append(frontend_windows(w, sr, win, hop))
+    return dict(tslist=[int(t) for t in tslist], audio_feat=np.concatenate(feats, 0), starts=starts)
+
+
+# ----------------------------------------------------------------------------------------
+# weights: checkpoint layout -> folded fp32 arrays
+# ----------------------------------------------------------------------------------------
+P = "_model."
+
+
+def fold_weight_norm(sd, key):
+    """torch weight_norm(dim=0): w = g * v / ||v|| (norm over all dims but 0); device_mover.py:26-31."""
+    if key + ".weight" in sd:
+        return np.asarray(sd[key + ".weight"], F32)
+    v = np.asarray(sd[key + ".weight_v"], F32)
+    g = np.asarray(sd[key + ".weight_g"], F32)
+    n = np.sqrt((v.astype(np.float64) ** 2).reshape(v.shape[0], -1).sum(1)).astype(F32)
+    return (v * (g.reshape(-1) / n).reshape((-1,) + (1,) * (v.ndim - 1))).astype(F32)
+
+
+def _sigmoid(x):
+    return (1.0 / (1.0 + np.exp(-x.astype(np.float64)))).astype(F32)
+
+
+def _lrelu(x, a=0.2):
+    return np.where(x >= 0, x, F32(a) * x).astype(F32)
+
+
+class Oracle:
+    """Eval-mode forward of SpeechDrivenAnimation (speech_anime/model/model.py:28-45)."""
+
+    def __init__(self, state_dict, head="dgrad"):
+        sd = {k: np.asarray(v) for k, v in state_dict.items()}
+        self.head = head
+        enc = P + "_audio_encoder._layers."
+        self.conv = []
+        for idx in (1, 3, 5):
+            k = f"{enc}{idx}"
+            w = fold_weight_norm(sd, k)[..., 0]                      # (co, ci, kf)
+            b = sd[k + ".bias"].astype(F32)
+            bn = k + "._ext_post_bn"
+            scale = (sd[bn + ".weight"].astype(np.float64) /
+                     np.sqrt(sd[bn + ".running_var"].astype(np.float64) + 1e-3))
+            shift = sd[bn + ".bias"].astype(np.float64) - sd[bn + ".running_mean"].astype(np.float64) * scale
+            self.conv.append((w, b, scale.astype(F32), shift.astype(F32)))
+        k = f"{enc}6._lstm"
+        self.freq = [(sd[f"{k}.weight_ih_l0{s}"].astype(F32), sd[f"{k}.weight_hh_l0{s}"].astype(F32),
+                      (sd[f"{k}.bias_ih_l0{s}"] + sd[f"{k}.bias_hh_l0{s}"]).astype(F32)) for s in ("", "_reverse")]
+        self.freq_proj = (sd[f"{enc}6._proj.weight"].astype(F32), sd[f"{enc}6._proj.bias"].astype(F32))
+        k = f"{enc}9"
+        self.bilstm = [[(sd[f"{k}.weight_ih_l{l}{s}"].astype(F32), sd[f"{k}.weight_hh_l{l}{s}"].astype(F32), None)
+                        for s in ("", "_reverse")] for l in (0, 1)]
+        k = f"{enc}10"
+        self.attn = dict(conv=sd[k + "._conv_query.weight"].astype(F32), wk=sd[k + ".proj_key.weight"].astype(F32),
+                         wq=sd[k + ".proj_qry.weight"].astype(F32), v=sd[k + ".v.weight"].astype(F32)[0],
+                         b=sd[k + ".b"].astype(F32).reshape(-1))
+        out = P + "_output_module."
+
+        def fc(key):
+            return fold_weight_norm(sd, key), sd[key + ".bias"].astype(F32)
+        if head == "dgrad":
+            self.trunk = [fc(out + "_layers.0")]
+            self.scale = [fc(f"{out}_scale_layers.{i}") for i in range(3)]
+            self.rotat = [fc(f"{out}_rotat_layers.{i}") for i in range(3)]
+            self.pca_s = (sd[out + "_scale_pca.compT"].astype(F32), sd[out + "_scale_pca.means"].astype(F32))
+            self.pca_r = (sd[out + "_rotat_pca.compT"].astype(F32), sd[out + "_rotat_pca.means"].astype(F32))
+        else:
+            self.trunk = [fc(f"{out}_layers.{i}") for i in range(3)]
+            self.pca = (sd[out + "_pca.compT"].astype(F32), sd[out + "_pca.means"].astype(F32))
+
+    # -- a7: saber/nn/layers/conv2d.py:6-28,64-97; extend.py:94-101 (act THEN BN); functions.py:204-211
+    @staticmethod
+    def _conv_f(x, w, b, scale, shift):
+        """x (N, ci, F, T); kernel (kf, 1) along F, 'same' zero pad."""
+        co, ci, kf = w.shape
+        N, _, Fq, T = x.shape
+        if kf == 3:
+            xp = np.pad(x, ((0, 0), (0, 0), (1, 1), (0, 0)))
+        else:
+            xp = x
+        y = np.zeros((N, co, Fq, T), F32)
+        for d in range(kf):
+            y += np.einsum("oc,ncft->noft", w[:, :, d], xp[:, :, d:d + Fq, :], optimize=True).astype(F32)
+        y = y + b[None, :, None, None]
+        y = _lrelu(y)
+        return (y * scale[None, :, None, None] + shift[None, :, None, None]).astype(F32)
+
+    @staticmethod
+    def _pool_f(x):
+        return np.maximum(x[:, :, 0::2, :], x[:, :, 1::2, :])
+
+    @staticmethod
+    def _lstm_dir(x, w_ih, w_hh, b, reverse):
+        """torch.nn.LSTM one direction, gate order i,f,g,o.  x (B, S, I) -> (B, S, H)."""
+        B, S, _ = x.shape
+        H = w_hh.shape[1]
+        gx = np.matmul(x, w_ih.T)
+        if b is not None:
+            gx = gx + b
+        h = np.zeros((B, H), F32)
+        c = np.zeros((B, H), F32)
+        out = np.empty((B, S, H), F32)
+        order = range(S - 1, -1, -1) if reverse else range(S)
+        for t in order:
+            g = gx[:, t] + np.matmul(h, w_hh.T)
+            i = _sigmoid(g[:, :H]); f = _sigmoid(g[:, H:2 * H])
+            gg = np.tanh(g[:, 2 * H:3 * H]); o = _sigmoid(g[:, 3 * H:])
+            c = (f * c + i * gg).astype(F32)
+            h = (o * np.tanh(c)).astype(F32)
+            out[:, t] = h
+        return out
+
+    def _bilstm(self, x, params):
+        return np.concatenate([self._lstm_dir(x, *params[0], reverse=False),
+                               self._lstm_dir(x, *params[1], reverse=True)], -1)
+
+    def encoder(self, audio_feat, stages=None):
+        """layers/__init__.py:106-148 over config/model/dgrad.py:60-70.  (N,64,128,3) -> z (N,512), align (N,64)."""
+        x = np.transpose(np.asarray(audio_feat, F32), (0, 3, 2, 1))          # permute (0,3,2,1) -> (N,3,128,64)
+        x = self._pool_f(self._conv_f(x, *self.conv[0]))                      # (N,32,64,64)
+        if stages is not None: stages["pool1"] = x
+        x = self._pool_f(self._conv_f(x, *self.conv[1]))                      # (N,64,32,64)
+        x = self._conv_f(x, *self.conv[2])                                    # (N,64,32,64)
+        if stages is not None: stages["conv3"] = x
+        # a8: freq_lstm.py:36-55
+        N, C, Fq, T = x.shape
+        seq = np.ascontiguousarray(np.transpose(x, (0, 3, 2, 1))).reshape(N * T, Fq, C)
+        h = self._bilstm(seq, self.freq).reshape(N * T, Fq * 256)
+        z = (np.matmul(h, self.freq_proj[0].T) + self.freq_proj[1]).astype(F32).reshape(N, T, 256)
+        if stages is not None: stages["freq"] = np.transpose(z, (0, 2, 1))[:, :, None, :]
+        # a9: rnn.py:20-21 (bias=False, 2 layers, bidirectional)
+        z = self._bilstm(z, self.bilstm[0])
+        z = self._bilstm(z, self.bilstm[1])                                   # (N,64,512)
+        if stages is not None: stages["bilstm"] = z
+        # a10: layers/__init__.py:88-99; attentions.py:49-54,69-75,107-124
+        a = self.attn
+        q0 = z[:, 31:34, :]                                                   # mid=32, ahead=1, after=2
+        q = np.einsum("ock,nkc->no", a["conv"], q0, optimize=True).astype(F32)   # Conv1d k=3 s=3, no bias
+        qp = np.matmul(q, a["wq"].T)                                          # (N,128)
+        kp = np.matmul(z, a["wk"].T)                                          # (N,64,128)
+        s = np.matmul(np.tanh(qp[:, None, :] + kp + a["b"]), a["v"])         # (N,64)
+        s = s * F32(1.0)                                                      # scale_score_at_eval
+        e = np.exp(s - s.max(-1, keepdims=True))
+        align = (e / e.sum(-1, keepdims=True)).astype(F32)
+        ctx = np.einsum("nt,ntc->nc", align, z, optimize=True).astype(F32)
+        return ctx, align
+
+    @staticmethod
+    def _fc(x, wb, act):
+        y = (np.matmul(x, wb[0].T) + wb[1]).astype(F32)
+        if act == "lrelu":
+            return _lrelu(y)
+        if act == "tanh":
+            return np.tanh(y)
+        return y
+
+    def coefficients(self, z, speaker_id):
+        """modules/output_module.py:51-89 up to the PCA input; condition concat layers/__init__.py:69-83."""
+        c = np.zeros((len(z), 8), F32)
+        c[np.arange(len(z)), np.asarray(speaker_id)] = 1.0                    # modules/speaker.py:21-27
+        zc = np.concatenate([z, c], -1)
+        if self.head == "dgrad":
+            h = self._fc(zc, self.trunk[0], "lrelu")
+            hc = np.concatenate([h, c], -1)
+            cs = self._fc(self._fc(self._fc(hc, self.scale[0], "lrelu"), self.scale[1], "tanh"), self.scale[2], None)
+            cr = self._fc(self._fc(self._fc(hc, self.rotat[0], "lrelu"), self.rotat[1], "tanh"), self.rotat[2], None)
+            return h, cs, cr
+        h = self._fc(self._fc(self._fc(zc, self.trunk[0], "lrelu"), self.trunk[1], "tanh"), self.trunk[2], None)
+        return None, h, None
+
+    def expand(self, cs, cr=None):
+        """PcaInversion (output_module.py:94-116) + data_to_anime_feat interleave (model.py:246-257)."""
+        if self.head == "dgrad":
+            s = (np.matmul(cs, self.pca_s[0].T) + self.pca_s[1]).astype(F32).reshape(len(cs), -1, 6)
+            r = (np.matmul(cr, self.pca_r[0].T) + self.pca_r[1]).astype(F32).reshape(len(cr), -1, 3)
+            return np.concatenate([s, r], -1).reshape(len(cs), -1)
+        return (np.matmul(cs, self.pca[0].T) + self.pca[1]).astype(F32)
+
+    def forward(self, audio_feat, speaker_id, stages=None):
+        z, align = self.encoder(audio_feat, stages)
+        spk = np.full(len(z), speaker_id, np.int64) if np.isscalar(speaker_id) else np.asarray(speaker_id)
+        trunk, cs, cr = self.coefficients(z, spk)
+        if stages is not None:
+            stages.update(z=z, align=align, trunk=trunk, coef_scale=cs, coef_rotat=cr)
+        return self.expand(cs, cr), z, align
+
+
+def generate_animation(oracle, pcm, sr, speaker_id, batch=100):
+    """SaberSpeechDrivenAnimation.generate_animation (model.py:333-420), ensembling_ms = 0."""
+    feats = fetch_audio_features(pcm, sr)
+    x = feats["audio_feat"]
+    outs = [oracle.forward(x[i:i + batch], speaker_id)[0] for i in range(0, len(x), batch)]   # model.py:450-467
+    animes = np.concatenate(outs, 0)
+    if oracle.head == "dgrad":
+        # data_to_anime_feat (model.py:246-257) views (n,1,9976,6|3) as (n,1,9976,1,6|3), so the
+        # reference's result is (F, 9976, 9) -- same bytes as (F, 89784).
+        animes = animes.reshape(len(animes), -1, 9)
+    return feats["tslist"], animes
