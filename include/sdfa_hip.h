@@ -1,0 +1,161 @@
+/*
+ * sdfa_hip.h -- C ABI of libsdfa_hip.so: the MI355X (gfx950) implementation of the
+ * audio -> dgrad/offsets inference path of chaiyujin/sdfa-2019.
+ *
+ * Plain pointers and sizes only; no torch / C++ types cross this boundary.
+ * Every d_* pointer is DEVICE memory (hipMalloc'ed or owned by any allocator, e.g.
+ * PyTorch's caching allocator); every h_* pointer is HOST memory.  `stream` is a
+ * hipStream_t passed as void* (NULL = the default stream).  All device work is enqueued
+ * on `stream` and the calls never synchronise.  Functions return 0 (or a non-negative
+ * count) on success and a negative SDFA_E* code on failure; sdfa_last_error() returns
+ * the message of the calling thread's last failure.
+ *
+ * Each entry point names the reference interface (paths relative to the reference
+ * repository root) whose arithmetic it replaces.  The Python host that keeps the
+ * reference's own names on top of this ABI lives in sdfa-2019_amd/speech_anime/.
+ */
+#ifndef SDFA_HIP_H
+#define SDFA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDFA_ABI_VERSION 1
+
+#define SDFA_OK            0
+#define SDFA_EINVAL       -1   /* bad argument (shape, size, null pointer, unsupported rate) */
+#define SDFA_ESHORTCLIP   -2   /* a window would need zero padding on both sides: the reference asserts
+                                  (speech_anime/datasets/sliding_window.py:363) */
+#define SDFA_EHIP         -3   /* a HIP runtime call failed */
+#define SDFA_ESTATE       -4   /* model not finalised / tensor missing */
+#define SDFA_ENOSPACE     -5   /* output capacity or workspace too small */
+
+#define SDFA_HEAD_DGRAD    0   /* speech_anime/config/model/dgrad.py   : 9976 triangles x (6 scale | 3 rotat) */
+#define SDFA_HEAD_OFFSETS  1   /* speech_anime/config/model/offsets.py : 15069 vertex offsets */
+
+#define SDFA_FEAT_FRAMES   64  /* audio.feature.sliding_window_frames  (config/model/dgrad.py:11) */
+#define SDFA_FEAT_MELS    128  /* audio.mel.n_mels                     (config/data/voca-dgrad.py:13) */
+#define SDFA_FEAT_CH        3  /* mel, delta, delta-delta              (datasets/get_features.py:196-215) */
+#define SDFA_Z_DIM        512
+#define SDFA_DGRAD_DIM  89784  /* 9976 * 9  (speech_anime/model/model.py:246-257) */
+#define SDFA_OFFSETS_DIM 15069
+#define SDFA_COEF_SCALE    85
+#define SDFA_COEF_ROTAT   180
+#define SDFA_COEF_OFFSETS  59
+
+int         sdfa_abi_version(void);
+const char *sdfa_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * (a1) Frame enumeration and timestamps -- host integer / float32-rounded arithmetic.
+ * Replaces the `while` loop of DatasetSlidingWindow.fetch_audio_features
+ * (speech_anime/datasets/sliding_window.py:339-354) and the unit converters
+ * frame_to_sample / sample_to_ms (speech_anime/datasets/speech_anime.py:135-145).
+ * Bit-exact, including numpy-float32 roundings and Python round-half-to-even.
+ *
+ *   sample_rate, fps              hparams.audio.sample_rate, hparams.anime.fps (60)
+ *   win, hop                      int(0.064*sr), int(0.008*sr)
+ *   ts_delta_ms                   hparams.anime.feature.ts_delta (100)
+ *   h_starts[cap], h_tslist[cap]  window start sample (may be negative) and timestamp (ms)
+ * Returns the number of frames F (call with cap = 0 and null outputs to size), or
+ * SDFA_ESHORTCLIP where the reference's assert would fire.
+ * ---------------------------------------------------------------------------------------- */
+int64_t sdfa_frame_index(int64_t n_samples, int sample_rate, int fps, int win, int hop,
+                         int ts_delta_ms, int64_t *h_starts, int32_t *h_tslist, int64_t cap);
+
+/* ------------------------------------------------------------------------------------------
+ * (a2-a4) Spectral-gather front end: zero-padded window cut, per-window pre-emphasis,
+ * Hamming STFT (center=False), power, 128-band Slaney mel, dB, normalise+clamp, delta and
+ * delta-delta (Savitzky-Golay width 9), (T,F,C) interleave.
+ * Replaces saber.audio.features.mel_spectrogram (saber/data/audio/features/spectrogram.py:66-104,
+ * 236-249, 298-308; misc.py:8-19,94-123), windowed_features' inference branch
+ * (speech_anime/datasets/get_features.py:8-69,90,159-167,196-223) and the per-frame body of
+ * fetch_audio_features (sliding_window.py:356-371, :462).
+ *
+ *   d_pcm              concatenated clips, float32 in [-1,1]
+ *   d_clip_off/len     [n_clips] offset and length (samples) of each clip inside d_pcm
+ *   d_frame_clip       [n_frames] clip index of each frame
+ *   d_frame_start      [n_frames] window start relative to its clip (from sdfa_frame_index)
+ *   sample_rate        8000 (win 512, hop 64) or 16000 (win 1024, hop 128)
+ *   d_audio_feat       out [n_frames][64][128][3] float32
+ * ---------------------------------------------------------------------------------------- */
+int sdfa_mel_frontend(const float *d_pcm, const int64_t *d_clip_off, const int64_t *d_clip_len,
+                      int32_t n_clips, const int32_t *d_frame_clip, const int64_t *d_frame_start,
+                      int64_t n_frames, int sample_rate, float *d_audio_feat, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Model weights.  Tensors are given by the reference's state_dict names with the `_model.`
+ * prefix stripped, AFTER weight-norm has been folded
+ * (saber/trainer/manager/device_mover.py:26-31) -- i.e. `...weight`, never weight_g/weight_v --
+ * as contiguous float32 host arrays.  BatchNorm is given unfolded (weight, bias, running_mean,
+ * running_var); the library folds it (eps 1e-3, config/model/dgrad.py:1).
+ * sdfa_model_finalize packs everything into the device layouts the kernels stream from and
+ * fails with SDFA_ESTATE if a tensor of the chosen head is missing or has the wrong size.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct sdfa_model sdfa_model;
+
+sdfa_model *sdfa_model_create(int head);
+void        sdfa_model_destroy(sdfa_model *m);
+int         sdfa_model_set_tensor(sdfa_model *m, const char *name, const float *h_data, int64_t numel);
+int         sdfa_model_finalize(sdfa_model *m, void *stream);
+int         sdfa_model_head(const sdfa_model *m);
+int64_t     sdfa_model_out_dim(const sdfa_model *m);          /* 89784 or 15069 */
+int64_t     sdfa_model_coef_dim(const sdfa_model *m);         /* 265 (85 scale | 180 rotat) or 59 */
+
+/* Bytes of scratch device memory the forward calls need for up to `max_frames` frames per call. */
+int64_t sdfa_workspace_bytes(const sdfa_model *m, int64_t max_frames);
+
+/* ------------------------------------------------------------------------------------------
+ * (a6-a10) Audio encoder: permute, conv2d x3 (+LeakyReLU 0.2 then eval BatchNorm) with two
+ * max-pools along frequency, frequency BiLSTM + 8192->256 projection, 2-layer time BiLSTM,
+ * Bahdanau attention with the centre-3-frame query.
+ * Replaces modules.Configurable("audio_encoder").forward (speech_anime/modules/configurable.py:17-25)
+ * = layers.forward over config/model/dgrad.py:60-70 (speech_anime/layers/__init__.py:63-148;
+ * saber/nn/layers/conv2d.py:6-28,64-97; layers/freq_lstm.py:36-55; layers/rnn.py:20-21;
+ * layers/attentions.py:39-75,92-124).
+ *
+ *   d_audio_feat  [n_frames][64][128][3] float32, contiguous
+ *   d_z           out [n_frames][512]   attention context (z_audio)
+ *   d_align       out [n_frames][64]    attention weights (align_dict["audio_encoder10"]); may be NULL
+ * ---------------------------------------------------------------------------------------- */
+int sdfa_encoder_forward(const sdfa_model *m, const float *d_audio_feat, int64_t n_frames,
+                         float *d_z, float *d_align, void *d_workspace, int64_t workspace_bytes,
+                         void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (a5, a11, a12) Speaker one-hot condition, output MLPs, PCA expansion and the per-triangle
+ * [6 scale | 3 rotat] interleave.
+ * Replaces SpeakerEmbedding.forward (speech_anime/modules/speaker.py:21-27), OutputModule.forward and
+ * PcaInversion.forward (speech_anime/modules/output_module.py:51-89,94-116) and
+ * data_to_anime_feat (speech_anime/model/model.py:246-257).
+ *
+ *   d_z           [n_frames][512]
+ *   d_speaker_id  [n_frames] int64, each in [0, 8)
+ *   d_coef        out [n_frames][coef_dim]  PCA coefficients (scale then rotat); may be NULL
+ *   d_out         out [n_frames][out_dim]   dgrad (9976 x [s0..s5 r0 r1 r2]) or offsets; may be NULL
+ * ---------------------------------------------------------------------------------------- */
+int sdfa_regress_forward(const sdfa_model *m, const float *d_z, const int64_t *d_speaker_id,
+                         int64_t n_frames, float *d_coef, float *d_out, void *d_workspace,
+                         int64_t workspace_bytes, void *stream);
+
+/* Debug / parity taps: copy an intermediate activation of the LAST sdfa_encoder_forward call out of
+ * the workspace in the reference's layout.  what: 0 = pool1 (n,32,64,64)  1 = conv3 (n,64,32,64)
+ * 2 = freq-lstm (n,256,64)  3 = bilstm (n,64,512).  Used by tests only. */
+int sdfa_debug_keep_intermediates(sdfa_model *m, int on);   /* un-aliased workspace: call before sizing it */
+int sdfa_debug_tap(const sdfa_model *m, int what, int64_t n_frames, float *d_dst, const void *d_workspace,
+                   void *stream);
+
+/* Per-stage device timing of the last forward calls made with profiling enabled (HIP events on the
+ * caller's stream).  names: "conv1","conv23","freq_lstm","freq_proj","gx0","lstm0","gx1","lstm1",
+ * "attn_proj","attn","mlp","pca".  Returns milliseconds or a negative code. */
+int   sdfa_profile_enable(sdfa_model *m, int on);
+int   sdfa_profile_reset(sdfa_model *m);
+float sdfa_profile_ms(const sdfa_model *m, const char *stage);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDFA_HIP_H */

@@ -1,0 +1,726 @@
+// C ABI of libsdfa_hip.so (include/sdfa_hip.h): host orchestration, weight packing, workspace layout.
+#include "../../include/sdfa_hip.h"
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) return fail(SDFA_EHIP, "%s failed: %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------------------
+// front-end constants (window, twiddles, sparse mel rows), cached per sample rate
+// ------------------------------------------------------------------------------------------------
+struct FrontendCache {
+    FrontendConsts c{};
+    void *blob = nullptr;
+};
+std::mutex g_fe_mu;
+std::map<int, FrontendCache> g_fe;
+
+// Slaney mel scale / triangular filters as librosa 0.8.0 filters.mel(norm="slaney") defines them
+// (third-party, un-vendored; called at saber/data/audio/features/misc.py:110-117).
+double hz_to_mel(double f) {
+    const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+    return f >= min_log_hz ? min_log_mel + std::log(f / min_log_hz) / logstep : f / f_sp;
+}
+double mel_to_hz(double m) {
+    const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+    return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m;
+}
+
+int build_frontend(int sr, FrontendCache &fc) {
+    const int win = (int)(0.064 * sr), hop = (int)(0.008 * sr);
+    if (!((sr == 8000 && win == 512) || (sr == 16000 && win == 1024)))
+        return fail(SDFA_EINVAL, "sample_rate %d unsupported: the FFT kernels cover 8000 (win 512) and 16000 (win 1024)", sr);
+    const int nbins = win / 2 + 1, n_mels = 128;
+    const double fmin = 50.0, fmax = 3600.0;
+    std::vector<float> hamm(win);
+    std::vector<float> tw(2 * win);
+    for (int n = 0; n < win; ++n) {
+        hamm[n] = (float)(0.54 - 0.46 * std::cos(2.0 * M_PI * n / (win - 1)));   // np.hamming, misc.py:94-100
+        tw[2 * n] = (float)std::cos(-2.0 * M_PI * n / win);
+        tw[2 * n + 1] = (float)std::sin(-2.0 * M_PI * n / win);
+    }
+    std::vector<double> mel_f(n_mels + 2);
+    const double m_lo = hz_to_mel(fmin), m_hi = hz_to_mel(fmax);
+    for (int i = 0; i < n_mels + 2; ++i) mel_f[i] = mel_to_hz(m_lo + (m_hi - m_lo) * i / (n_mels + 1));
+    std::vector<int> ptr(n_mels + 1, 0), bins;
+    std::vector<float> wts;
+    int used = 0;
+    for (int i = 0; i < n_mels; ++i) {
+        const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+        for (int b = 0; b < nbins; ++b) {
+            const double fr = (double)sr / 2 * b / (nbins - 1);
+            const double lower = -(mel_f[i] - fr) / (mel_f[i + 1] - mel_f[i]);
+            const double upper = (mel_f[i + 2] - fr) / (mel_f[i + 2] - mel_f[i + 1]);
+            const float w = (float)std::fmax(0.0, std::fmin(lower, upper));
+            const float wn = (float)((double)w * enorm);   // float32 weights *= float64 enorm -> float32
+            if (wn != 0.f) {
+                bins.push_back(b);
+                wts.push_back(wn);
+                if (b + 1 > used) used = b + 1;
+            }
+        }
+        ptr[i + 1] = (int)bins.size();
+    }
+    if (bins.size() > 512 || used > 256) return fail(SDFA_EINVAL, "mel filterbank does not fit the kernel tables");
+    const size_t o_h = 0, o_t = o_h + win * 4, o_p = o_t + win * 8, o_b = o_p + 132 * 4, o_w = o_b + 512 * 4, total = o_w + 512 * 4;
+    std::vector<char> host(total, 0);
+    memcpy(&host[o_h], hamm.data(), win * 4);
+    memcpy(&host[o_t], tw.data(), win * 8);
+    memcpy(&host[o_p], ptr.data(), ptr.size() * 4);
+    memcpy(&host[o_b], bins.data(), bins.size() * 4);
+    memcpy(&host[o_w], wts.data(), wts.size() * 4);
+    HIP_TRY(hipMalloc(&fc.blob, total));
+    HIP_TRY(hipMemcpy(fc.blob, host.data(), total, hipMemcpyHostToDevice));
+    char *d = (char *)fc.blob;
+    fc.c.hamm = (const float *)(d + o_h);
+    fc.c.twiddle = (const float2 *)(d + o_t);
+    fc.c.mel_ptr = (const int *)(d + o_p);
+    fc.c.mel_bin = (const int *)(d + o_b);
+    fc.c.mel_w = (const float *)(d + o_w);
+    fc.c.win = win; fc.c.hop = hop; fc.c.sliding = hop * 63 + win;
+    fc.c.nbins_used = used; fc.c.nnz = (int)bins.size();
+    return SDFA_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// model
+// ================================================================================================
+struct sdfa_model {
+    int head = SDFA_HEAD_DGRAD;
+    bool finalized = false;
+    bool keep = false;      // debug: no workspace aliasing, so taps stay valid
+    bool profile = false;
+    std::map<std::string, std::vector<float>> host;
+    void *blob = nullptr;   // all packed weights
+    // device pointers into blob
+    const float *w1, *b1, *s1, *t1, *w2, *b2, *s2, *t2, *w3, *b3, *s3, *t3;
+    const float *fl_w, *fl_b, *fp_w, *fp_b;
+    const float *gx_w[2], *tl_w[2];
+    const float *kp_w, *qc_w, *qp_w, *at_v, *at_b;
+    struct Fc { const float *w, *b, *cw; int K, P, Ppad, Pstore; int act; };
+    Fc trunk, br[2][3], off[3];
+    const float *pca_q, *pca_bias;
+    int pca_K;           // 288 (96 | 192) or 64
+    int64_t pca_ld;      // padded output width
+    int64_t out_dim, coef_dim;
+    // profiling
+    struct Ev { std::string stage; hipEvent_t a, b; };
+    mutable std::vector<Ev> events;
+};
+
+namespace {
+
+const std::vector<float> *get(const sdfa_model *m, const std::string &name, size_t numel) {
+    auto it = m->host.find(name);
+    if (it == m->host.end()) { fail(SDFA_ESTATE, "tensor '%s' missing", name.c_str()); return nullptr; }
+    if (it->second.size() != numel) {
+        fail(SDFA_ESTATE, "tensor '%s' has %zu elements, expected %zu", name.c_str(), it->second.size(), numel);
+        return nullptr;
+    }
+    return &it->second;
+}
+
+struct Packer {
+    std::vector<float> buf;
+    size_t add(size_t n) {   // 256-byte aligned slots
+        size_t o = (buf.size() + 63) / 64 * 64;
+        buf.resize(o + n, 0.f);
+        return o;
+    }
+};
+
+// W [P][K] row-major (+ row permutation) -> K4 [K/4][Ppad][4], zero padded
+size_t pack_k4(Packer &pk, const float *W, int P, int K, int ldw, int col0, int Kpad, int Ppad, const int *perm = nullptr) {
+    size_t o = pk.add((size_t)Kpad * Ppad);
+    for (int p = 0; p < P; ++p) {
+        const float *row = W + (size_t)(perm ? perm[p] : p) * ldw + col0;
+        for (int k = 0; k < K; ++k) pk.buf[o + ((size_t)(k / 4) * Ppad + p) * 4 + (k % 4)] = row[k];
+    }
+    return o;
+}
+
+// packed gate row p = w*128 + gate*32 + jj  <->  torch row gate*H + 32*w + jj
+std::vector<int> gate_perm(int H) {
+    std::vector<int> perm(4 * H);
+    for (int w = 0; w < H / 32; ++w)
+        for (int g = 0; g < 4; ++g)
+            for (int jj = 0; jj < 32; ++jj) perm[w * 128 + g * 32 + jj] = g * H + 32 * w + jj;
+    return perm;
+}
+
+int pack_fc(sdfa_model *m, Packer &pk, const std::string &key, int P, int Kin, bool cond, int act, size_t off[3],
+            sdfa_model::Fc &fc) {
+    const int Ktot = cond ? Kin + 8 : Kin;
+    auto *w = get(m, key + ".weight", (size_t)P * Ktot);
+    auto *b = get(m, key + ".bias", P);
+    if (!w || !b) return SDFA_ESTATE;
+    fc.K = Kin; fc.P = P; fc.Ppad = (int)round_up(P, 128); fc.Pstore = (int)round_up(P, 32); fc.act = act;
+    off[0] = pack_k4(pk, w->data(), P, Kin, Ktot, 0, Kin, fc.Ppad);
+    off[1] = pk.add(fc.Ppad);
+    memcpy(&pk.buf[off[1]], b->data(), P * 4);
+    off[2] = (size_t)-1;
+    if (cond) {
+        off[2] = pk.add((size_t)fc.Ppad * 8);
+        for (int p = 0; p < P; ++p)
+            for (int s = 0; s < 8; ++s) pk.buf[off[2] + ((size_t)(p / 4) * 8 + s) * 4 + (p % 4)] = (*w)[(size_t)p * Ktot + Kin + s];
+    }
+    return SDFA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sdfa_abi_version(void) { return SDFA_ABI_VERSION; }
+const char *sdfa_last_error(void) { return g_err.c_str(); }
+
+// ------------------------------------------------------------------------------------------------
+int64_t sdfa_frame_index(int64_t n_samples, int sample_rate, int fps, int win, int hop, int ts_delta_ms,
+                         int64_t *h_starts, int32_t *h_tslist, int64_t cap) {
+    if (n_samples <= 0 || sample_rate <= 0 || fps <= 0 || win <= 0 || hop <= 0) return fail(SDFA_EINVAL, "bad frame_index arguments");
+    const int64_t sliding = (int64_t)hop * 63 + win;
+    int64_t count = 0;
+    double idx = -1.0;
+    for (;;) {
+        // frame_to_sample: np.float32(float(idx * sr) / float(fps))          speech_anime.py:141-145
+        const float fs = (float)((idx * (double)sample_rate) / (double)fps);
+        // frame_in_range: float32 + int -> float32                           sliding_window.py:320-322
+        const float lhs = fs + (float)sliding;
+        if (!((double)lhs <= (double)(n_samples + 2 * sliding))) break;
+        const int64_t mid = (int64_t)std::floor((double)fs);
+        const int64_t e = mid + sliding / 2, s = e - sliding;
+        // sample_to_ms: np.float32(float(((s+e)/2) * 1000.0) / float(sr)); then float32 - ts_delta; round half even
+        const float ms = (float)(((((double)(s + e)) / 2.0) * 1000.0) / (double)sample_rate);
+        const float shifted = ms - (float)ts_delta_ms;
+        const int32_t ts = (int32_t)std::nearbyintf(shifted);
+        const int64_t lo = s > 0 ? s : 0, hi = e < n_samples ? e : n_samples;
+        if (hi > lo && s < 0 && e > n_samples)
+            return fail(SDFA_ESHORTCLIP, "signal length %lld != %lld.", (long long)(hi - lo - s), (long long)sliding);
+        if (count < cap) {
+            if (h_starts) h_starts[count] = s;
+            if (h_tslist) h_tslist[count] = ts;
+        }
+        ++count;
+        idx += 1.0;
+    }
+    if (cap > 0 && count > cap) return fail(SDFA_ENOSPACE, "frame_index: %lld frames, capacity %lld", (long long)count, (long long)cap);
+    return count;
+}
+
+// ------------------------------------------------------------------------------------------------
+int sdfa_mel_frontend(const float *d_pcm, const int64_t *d_clip_off, const int64_t *d_clip_len, int32_t n_clips,
+                      const int32_t *d_frame_clip, const int64_t *d_frame_start, int64_t n_frames, int sample_rate,
+                      float *d_audio_feat, void *stream) {
+    if (n_frames == 0) return SDFA_OK;
+    if (!d_pcm || !d_clip_off || !d_clip_len || !d_frame_clip || !d_frame_start || !d_audio_feat || n_clips <= 0 || n_frames < 0)
+        return fail(SDFA_EINVAL, "mel_frontend: null pointer or bad count");
+    FrontendConsts c;
+    {
+        std::lock_guard<std::mutex> lk(g_fe_mu);
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        auto key = sample_rate * 64 + dev;
+        auto it = g_fe.find(key);
+        if (it == g_fe.end()) {
+            FrontendCache fc;
+            int rc = build_frontend(sample_rate, fc);
+            if (rc) return rc;
+            it = g_fe.emplace(key, fc).first;
+        }
+        c = it->second.c;
+    }
+    HIP_TRY(sdfa_launch_frontend(c, d_pcm, d_clip_off, d_clip_len, d_frame_clip, d_frame_start, n_frames, d_audio_feat,
+                                 (hipStream_t)stream));
+    return SDFA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+sdfa_model *sdfa_model_create(int head) {
+    if (head != SDFA_HEAD_DGRAD && head != SDFA_HEAD_OFFSETS) { fail(SDFA_EINVAL, "unknown head %d", head); return nullptr; }
+    auto *m = new sdfa_model();
+    m->head = head;
+    m->out_dim = head == SDFA_HEAD_DGRAD ? SDFA_DGRAD_DIM : SDFA_OFFSETS_DIM;
+    m->coef_dim = head == SDFA_HEAD_DGRAD ? SDFA_COEF_SCALE + SDFA_COEF_ROTAT : SDFA_COEF_OFFSETS;
+    return m;
+}
+
+void sdfa_model_destroy(sdfa_model *m) {
+    if (!m) return;
+    if (m->blob) (void)hipFree(m->blob);
+    for (auto &e : m->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    delete m;
+}
+
+int sdfa_model_set_tensor(sdfa_model *m, const char *name, const float *h_data, int64_t numel) {
+    if (!m || !name || !h_data || numel <= 0) return fail(SDFA_EINVAL, "set_tensor: bad argument");
+    if (m->finalized) return fail(SDFA_ESTATE, "set_tensor after finalize");
+    m->host[name].assign(h_data, h_data + numel);
+    return SDFA_OK;
+}
+
+int sdfa_model_head(const sdfa_model *m) { return m ? m->head : SDFA_EINVAL; }
+int64_t sdfa_model_out_dim(const sdfa_model *m) { return m ? m->out_dim : SDFA_EINVAL; }
+int64_t sdfa_model_coef_dim(const sdfa_model *m) { return m ? m->coef_dim : SDFA_EINVAL; }
+
+int sdfa_model_finalize(sdfa_model *m, void *stream) {
+    if (!m) return fail(SDFA_EINVAL, "null model");
+    if (m->finalized) return SDFA_OK;
+    Packer pk;
+    const std::string enc = "_audio_encoder._layers.";
+    // ---- conv stack: fold eval BatchNorm (eps 1e-3) into scale/shift applied AFTER LeakyReLU (extend.py:94-101)
+    size_t o_conv[3][4];
+    const int cshape[3][3] = {{32, 3, 3}, {64, 32, 3}, {64, 64, 1}};   // co, ci, kf
+    const int cidx[3] = {1, 3, 5};
+    for (int l = 0; l < 3; ++l) {
+        const int co = cshape[l][0], ci = cshape[l][1], kf = cshape[l][2];
+        const std::string k = enc + std::to_string(cidx[l]);
+        auto *w = get(m, k + ".weight", (size_t)co * ci * kf);
+        auto *b = get(m, k + ".bias", co);
+        auto *g = get(m, k + "._ext_post_bn.weight", co), *be = get(m, k + "._ext_post_bn.bias", co);
+        auto *mu = get(m, k + "._ext_post_bn.running_mean", co), *var = get(m, k + "._ext_post_bn.running_var", co);
+        if (!w || !b || !g || !be || !mu || !var) return SDFA_ESTATE;
+        if (l == 0) {   // A operand [5 k-steps][2 halves][32 co], k = df*3 + c, k = 9 -> 0
+            o_conv[0][0] = pk.add(5 * 2 * 32);
+            for (int s = 0; s < 5; ++s)
+                for (int hh = 0; hh < 2; ++hh)
+                    for (int o = 0; o < 32; ++o) {
+                        const int kk = 2 * s + hh;
+                        float v = 0.f;
+                        if (kk < 9) { const int df = kk / 3, c = kk % 3; v = (*w)[((size_t)o * 3 + c) * 3 + df]; }
+                        pk.buf[o_conv[0][0] + (s * 2 + hh) * 32 + o] = v;
+                    }
+        } else {        // K4 [K/4][64][4], k = df*ci + c
+            const int K = ci * kf;
+            std::vector<float> flat((size_t)co * K);
+            for (int o = 0; o < co; ++o)
+                for (int c = 0; c < ci; ++c)
+                    for (int df = 0; df < kf; ++df) flat[(size_t)o * K + df * ci + c] = (*w)[((size_t)o * ci + c) * kf + df];
+            o_conv[l][0] = pack_k4(pk, flat.data(), co, K, K, 0, K, co);
+        }
+        o_conv[l][1] = pk.add(co); o_conv[l][2] = pk.add(co); o_conv[l][3] = pk.add(co);
+        for (int o = 0; o < co; ++o) {
+            const double sc = (double)(*g)[o] / std::sqrt((double)(*var)[o] + 1e-3);
+            pk.buf[o_conv[l][1] + o] = (*b)[o];
+            pk.buf[o_conv[l][2] + o] = (float)sc;
+            pk.buf[o_conv[l][3] + o] = (float)((double)(*be)[o] - (double)(*mu)[o] * sc);
+        }
+    }
+    // ---- frequency LSTM: [W_ih | W_hh] concatenated along K, gate rows packed per wave; bias = b_ih + b_hh
+    size_t o_flw = pk.add(0), o_flb;
+    {
+        const auto perm = gate_perm(128);
+        const char *suf[2] = {"", "_reverse"};
+        std::vector<float> cat((size_t)512 * 192);
+        size_t first = 0;
+        std::vector<float> bias(1024);
+        for (int d = 0; d < 2; ++d) {
+            const std::string k = enc + "6._lstm.";
+            auto *wih = get(m, k + "weight_ih_l0" + suf[d], 512 * 64), *whh = get(m, k + "weight_hh_l0" + suf[d], 512 * 128);
+            auto *bih = get(m, k + "bias_ih_l0" + suf[d], 512), *bhh = get(m, k + "bias_hh_l0" + suf[d], 512);
+            if (!wih || !whh || !bih || !bhh) return SDFA_ESTATE;
+            for (int r = 0; r < 512; ++r) {
+                memcpy(&cat[(size_t)r * 192], &(*wih)[(size_t)r * 64], 64 * 4);
+                memcpy(&cat[(size_t)r * 192 + 64], &(*whh)[(size_t)r * 128], 128 * 4);
+            }
+            size_t o = pack_k4(pk, cat.data(), 512, 192, 192, 0, 192, 512, perm.data());
+            if (d == 0) first = o;
+            else if (o != first + (size_t)48 * 512 * 4) return fail(SDFA_ESTATE, "internal: freq-lstm weights not contiguous");
+            for (int p = 0; p < 512; ++p) bias[d * 512 + p] = (*bih)[perm[p]] + (*bhh)[perm[p]];
+        }
+        o_flw = first;
+        o_flb = pk.add(1024);
+        memcpy(&pk.buf[o_flb], bias.data(), 1024 * 4);
+    }
+    size_t o_fpw, o_fpb;
+    {
+        auto *w = get(m, enc + "6._proj.weight", (size_t)256 * 8192), *b = get(m, enc + "6._proj.bias", 256);
+        if (!w || !b) return SDFA_ESTATE;
+        o_fpw = pack_k4(pk, w->data(), 256, 8192, 8192, 0, 8192, 256);
+        o_fpb = pk.add(256);
+        memcpy(&pk.buf[o_fpb], b->data(), 256 * 4);
+    }
+    // ---- time BiLSTM (bias=False): input projections as one 2048-row GEMM per layer, recurrent weights K4
+    size_t o_gx[2], o_tl[2];
+    {
+        const auto perm = gate_perm(256);
+        const char *suf[2] = {"", "_reverse"};
+        for (int l = 0; l < 2; ++l) {
+            const int Kin = l == 0 ? 256 : 512;
+            std::vector<float> both((size_t)2048 * Kin);
+            size_t first = 0;
+            for (int d = 0; d < 2; ++d) {
+                auto *wih = get(m, enc + "9.weight_ih_l" + std::to_string(l) + suf[d], (size_t)1024 * Kin);
+                auto *whh = get(m, enc + "9.weight_hh_l" + std::to_string(l) + suf[d], (size_t)1024 * 256);
+                if (!wih || !whh) return SDFA_ESTATE;
+                for (int p = 0; p < 1024; ++p) memcpy(&both[((size_t)d * 1024 + p) * Kin], &(*wih)[(size_t)perm[p] * Kin], Kin * 4);
+                size_t o = pack_k4(pk, whh->data(), 1024, 256, 256, 0, 256, 1024, perm.data());
+                if (d == 0) first = o;
+                else if (o != first + (size_t)64 * 1024 * 4) return fail(SDFA_ESTATE, "internal: time-lstm weights not contiguous");
+            }
+            o_tl[l] = first;
+            o_gx[l] = pack_k4(pk, both.data(), 2048, Kin, Kin, 0, Kin, 2048);
+        }
+    }
+    // ---- attention
+    size_t o_kp, o_qc, o_qp, o_v, o_b;
+    {
+        const std::string k = enc + "10.";
+        auto *cq = get(m, k + "_conv_query.weight", (size_t)512 * 512 * 3), *wk = get(m, k + "proj_key.weight", 128 * 512);
+        auto *wq = get(m, k + "proj_qry.weight", 128 * 512), *v = get(m, k + "v.weight", 128), *b = get(m, k + "b", 128);
+        if (!cq || !wk || !wq || !v || !b) return SDFA_ESTATE;
+        o_kp = pack_k4(pk, wk->data(), 128, 512, 512, 0, 512, 128);
+        o_qp = pack_k4(pk, wq->data(), 128, 512, 512, 0, 512, 128);
+        std::vector<float> flat((size_t)512 * 1536);   // k = tap*512 + c
+        for (int o = 0; o < 512; ++o)
+            for (int c = 0; c < 512; ++c)
+                for (int t = 0; t < 3; ++t) flat[(size_t)o * 1536 + t * 512 + c] = (*cq)[((size_t)o * 512 + c) * 3 + t];
+        o_qc = pack_k4(pk, flat.data(), 512, 1536, 1536, 0, 1536, 512);
+        o_v = pk.add(128); memcpy(&pk.buf[o_v], v->data(), 512);
+        o_b = pk.add(128); memcpy(&pk.buf[o_b], b->data(), 512);
+    }
+    // ---- output module
+    const std::string om = "_output_module.";
+    size_t o_fc[7][3];
+    size_t o_pq, o_pb;
+    if (m->head == SDFA_HEAD_DGRAD) {
+        if (pack_fc(m, pk, om + "_layers.0", 512, 512, true, ACT_LRELU, o_fc[0], m->trunk)) return SDFA_ESTATE;
+        const char *brn[2] = {"_scale_layers.", "_rotat_layers."};
+        const int nco[2] = {SDFA_COEF_SCALE, SDFA_COEF_ROTAT};
+        for (int b = 0; b < 2; ++b) {
+            if (pack_fc(m, pk, om + brn[b] + "0", 512, 512, true, ACT_LRELU, o_fc[1 + 3 * b], m->br[b][0])) return SDFA_ESTATE;
+            if (pack_fc(m, pk, om + brn[b] + "1", 256, 512, false, ACT_TANH, o_fc[2 + 3 * b], m->br[b][1])) return SDFA_ESTATE;
+            if (pack_fc(m, pk, om + brn[b] + "2", nco[b], 256, false, ACT_NONE, o_fc[3 + 3 * b], m->br[b][2])) return SDFA_ESTATE;
+        }
+        auto *cs = get(m, om + "_scale_pca.compT", (size_t)59856 * 85), *ms = get(m, om + "_scale_pca.means", 59856);
+        auto *cr = get(m, om + "_rotat_pca.compT", (size_t)29928 * 180), *mr = get(m, om + "_rotat_pca.means", 29928);
+        if (!cs || !ms || !cr || !mr) return SDFA_ESTATE;
+        // combined basis, K = 96 (scale, zero padded) + 192 (rotat): output coordinate o = tri*9 + c
+        m->pca_K = 288; m->pca_ld = round_up(SDFA_DGRAD_DIM, 128);
+        o_pq = pk.add((size_t)m->pca_K * m->pca_ld);
+        o_pb = pk.add(m->pca_ld);
+        for (int64_t tri = 0; tri < 9976; ++tri)
+            for (int c = 0; c < 9; ++c) {
+                const int64_t o = tri * 9 + c;
+                if (c < 6) {
+                    const float *row = &(*cs)[(size_t)(tri * 6 + c) * 85];
+                    for (int k = 0; k < 85; ++k) pk.buf[o_pq + ((size_t)(k / 4) * m->pca_ld + o) * 4 + (k % 4)] = row[k];
+                    pk.buf[o_pb + o] = (*ms)[tri * 6 + c];
+                } else {
+                    const float *row = &(*cr)[(size_t)(tri * 3 + c - 6) * 180];
+                    for (int k = 0; k < 180; ++k) pk.buf[o_pq + ((size_t)((96 + k) / 4) * m->pca_ld + o) * 4 + ((96 + k) % 4)] = row[k];
+                    pk.buf[o_pb + o] = (*mr)[tri * 3 + c - 6];
+                }
+            }
+    } else {
+        if (pack_fc(m, pk, om + "_layers.0", 512, 512, true, ACT_LRELU, o_fc[0], m->off[0])) return SDFA_ESTATE;
+        if (pack_fc(m, pk, om + "_layers.1", 256, 512, false, ACT_TANH, o_fc[1], m->off[1])) return SDFA_ESTATE;
+        if (pack_fc(m, pk, om + "_layers.2", SDFA_COEF_OFFSETS, 256, false, ACT_NONE, o_fc[2], m->off[2])) return SDFA_ESTATE;
+        auto *cp = get(m, om + "_pca.compT", (size_t)SDFA_OFFSETS_DIM * 59), *mp = get(m, om + "_pca.means", SDFA_OFFSETS_DIM);
+        if (!cp || !mp) return SDFA_ESTATE;
+        m->pca_K = 64; m->pca_ld = round_up(SDFA_OFFSETS_DIM, 128);
+        o_pq = pk.add((size_t)m->pca_K * m->pca_ld);
+        o_pb = pk.add(m->pca_ld);
+        for (int64_t o = 0; o < SDFA_OFFSETS_DIM; ++o) {
+            for (int k = 0; k < 59; ++k) pk.buf[o_pq + ((size_t)(k / 4) * m->pca_ld + o) * 4 + (k % 4)] = (*cp)[(size_t)o * 59 + k];
+            pk.buf[o_pb + o] = (*mp)[o];
+        }
+    }
+    // ---- upload
+    HIP_TRY(hipMalloc(&m->blob, pk.buf.size() * 4));
+    HIP_TRY(hipMemcpyAsync(m->blob, pk.buf.data(), pk.buf.size() * 4, hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));   // host staging buffer dies with this call
+    const float *d = (const float *)m->blob;
+    m->w1 = d + o_conv[0][0]; m->b1 = d + o_conv[0][1]; m->s1 = d + o_conv[0][2]; m->t1 = d + o_conv[0][3];
+    m->w2 = d + o_conv[1][0]; m->b2 = d + o_conv[1][1]; m->s2 = d + o_conv[1][2]; m->t2 = d + o_conv[1][3];
+    m->w3 = d + o_conv[2][0]; m->b3 = d + o_conv[2][1]; m->s3 = d + o_conv[2][2]; m->t3 = d + o_conv[2][3];
+    m->fl_w = d + o_flw; m->fl_b = d + o_flb; m->fp_w = d + o_fpw; m->fp_b = d + o_fpb;
+    for (int l = 0; l < 2; ++l) { m->gx_w[l] = d + o_gx[l]; m->tl_w[l] = d + o_tl[l]; }
+    m->kp_w = d + o_kp; m->qc_w = d + o_qc; m->qp_w = d + o_qp; m->at_v = d + o_v; m->at_b = d + o_b;
+    auto bind = [&](sdfa_model::Fc &fc, size_t o[3]) {
+        fc.w = d + o[0]; fc.b = d + o[1]; fc.cw = o[2] == (size_t)-1 ? nullptr : d + o[2];
+    };
+    if (m->head == SDFA_HEAD_DGRAD) {
+        bind(m->trunk, o_fc[0]);
+        for (int b = 0; b < 2; ++b)
+            for (int i = 0; i < 3; ++i) bind(m->br[b][i], o_fc[1 + 3 * b + i]);
+    } else {
+        for (int i = 0; i < 3; ++i) bind(m->off[i], o_fc[i]);
+    }
+    m->pca_q = d + o_pq; m->pca_bias = d + o_pb;
+    m->host.clear();
+    m->finalized = true;
+    return SDFA_OK;
+}
+
+}  // extern "C"
+
+// ================================================================================================
+// workspace layout (floats), per chunk of Nc frames, Mc = 64*Nc columns
+// ================================================================================================
+namespace {
+
+struct Ws {
+    int64_t P1, X3, HF, Z, GX, H0, H1, KP, QC, QP, ZK, R, total;   // offsets in floats
+};
+
+Ws layout(int64_t Nc, bool keep) {
+    const int64_t Mc = 64 * Nc;
+    Ws w{};
+    int64_t o = 0;
+    auto take = [&](int64_t n) { int64_t r = o; o += round_up(n, 64); return r; };
+    if (keep) {   // debug: nothing aliased, taps stay valid after the forward
+        w.P1 = take(2048 * Mc); w.X3 = take(2048 * Mc); w.HF = take(8192 * Mc); w.Z = take(256 * Mc);
+        w.GX = take(2048 * Mc); w.H0 = take(512 * Mc); w.H1 = take(512 * Mc); w.KP = take(128 * Mc);
+    } else {
+        const int64_t A = take(2048 * Mc);   // P1, later GX
+        const int64_t B = take(2048 * Mc);   // X3, later Z | H0 | H1 | KP
+        w.HF = take(8192 * Mc);
+        w.P1 = A; w.GX = A;
+        w.X3 = B; w.Z = B; w.H0 = B + 256 * Mc; w.H1 = B + 768 * Mc; w.KP = B + 1280 * Mc;
+    }
+    w.QC = take(512 * Nc); w.QP = take(128 * Nc); w.ZK = take(512 * Nc);
+    w.R = take(2560 * Nc);   // regressor scratch: trunk 512 | a 512 | b 256 | coef 288 (+ second branch a/b)
+    w.total = o;
+    return w;
+}
+
+int64_t capacity(int64_t bytes, bool keep) {   // largest Nc (multiple of 128) whose layout fits
+    const int64_t per128 = layout(128, keep).total * 4;
+    int64_t nc = bytes / per128 * 128;
+    while (nc > 0 && layout(nc, keep).total * 4 > bytes) nc -= 128;
+    return nc;
+}
+
+struct Prof {
+    const sdfa_model *m;
+    hipStream_t s;
+    void begin(const char *stage) {
+        if (!m->profile) return;
+        sdfa_model::Ev e; e.stage = stage;
+        (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b);
+        (void)hipEventRecord(e.a, s);
+        m->events.push_back(e);
+    }
+    void end() {
+        if (!m->profile) return;
+        (void)hipEventRecord(m->events.back().b, s);
+    }
+};
+
+GemmArgs gemm_fc(const sdfa_model::Fc &fc, const float *Q, int64_t ldq, float *D, int64_t Nc, const int64_t *spk, int64_t nreal) {
+    GemmArgs g{};
+    g.P = fc.w; g.Q = Q; g.D = D; g.bias = fc.b; g.cond_w = fc.cw; g.cond_idx = fc.cw ? spk : nullptr;
+    g.ldp = fc.Ppad; g.ldq = ldq; g.ldd = Nc; g.Ppad = fc.Ppad; g.Qpad = Nc; g.Pstore = fc.Pstore; g.Qreal = nreal;
+    g.K = fc.K; g.seg_k = fc.K; g.seg_col = 0; g.act = fc.act; g.out_mode = OUT_K4; g.bias_on_q = 0;
+    return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t sdfa_workspace_bytes(const sdfa_model *m, int64_t max_frames) {
+    if (!m || max_frames <= 0) return fail(SDFA_EINVAL, "workspace_bytes: bad argument");
+    return layout(round_up(max_frames, 128), m->keep).total * 4;
+}
+
+int sdfa_debug_keep_intermediates(sdfa_model *m, int on) {
+    if (!m) return fail(SDFA_EINVAL, "null model");
+    m->keep = on != 0;
+    return SDFA_OK;
+}
+
+int sdfa_profile_enable(sdfa_model *m, int on) {
+    if (!m) return fail(SDFA_EINVAL, "null model");
+    m->profile = on != 0;
+    for (auto &e : m->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    m->events.clear();
+    return SDFA_OK;
+}
+
+float sdfa_profile_ms(const sdfa_model *m, const char *stage) {
+    if (!m || !stage) return (float)fail(SDFA_EINVAL, "profile_ms: bad argument");
+    float total = 0.f;
+    bool any = false;
+    for (auto &e : m->events)
+        if (e.stage == stage) {
+            float ms = 0.f;
+            if (hipEventSynchronize(e.b) != hipSuccess || hipEventElapsedTime(&ms, e.a, e.b) != hipSuccess)
+                return (float)fail(SDFA_EHIP, "profile_ms: event query failed");
+            total += ms; any = true;
+        }
+    return any ? total : (float)fail(SDFA_EINVAL, "profile_ms: no such stage '%s'", stage);
+}
+
+int sdfa_profile_reset(sdfa_model *m) { return m ? sdfa_profile_enable(m, m->profile) : fail(SDFA_EINVAL, "null model"); }
+
+// ------------------------------------------------------------------------------------------------
+int sdfa_encoder_forward(const sdfa_model *m, const float *d_audio_feat, int64_t n_frames, float *d_z, float *d_align,
+                         void *d_workspace, int64_t workspace_bytes, void *stream) {
+    if (!m || !m->finalized) return fail(SDFA_ESTATE, "encoder_forward: model not finalised");
+    if (n_frames == 0) return SDFA_OK;
+    if (!d_audio_feat || !d_z || !d_workspace || n_frames < 0) return fail(SDFA_EINVAL, "encoder_forward: bad argument");
+    if (((uintptr_t)d_workspace | (uintptr_t)d_audio_feat | (uintptr_t)d_z) & 15) return fail(SDFA_EINVAL, "encoder_forward: pointers must be 16-byte aligned");
+    const int64_t cap = capacity(workspace_bytes, m->keep);
+    if (cap < 128) return fail(SDFA_ENOSPACE, "encoder_forward: workspace of %lld bytes holds no 128-frame chunk", (long long)workspace_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    Prof pf{m, s};
+    float *ws = (float *)d_workspace;
+    for (int64_t f0 = 0; f0 < n_frames; f0 += cap) {
+        const int64_t N = std::min(cap, n_frames - f0);
+        const int64_t Nc = round_up(N, 128), Mc = 64 * Nc;
+        const Ws w = layout(Nc, m->keep);
+        ConvArgs ca{};
+        ca.audio_feat = d_audio_feat + f0 * (64 * 128 * 3); ca.N = N; ca.Nc = Nc; ca.Mc = Mc;
+        ca.w1 = m->w1; ca.b1 = m->b1; ca.s1 = m->s1; ca.t1 = m->t1; ca.P1 = ws + w.P1;
+        ca.w2 = m->w2; ca.b2 = m->b2; ca.s2 = m->s2; ca.t2 = m->t2;
+        ca.w3 = m->w3; ca.b3 = m->b3; ca.s3 = m->s3; ca.t3 = m->t3; ca.X3 = ws + w.X3;
+        pf.begin("conv1"); HIP_TRY(sdfa_launch_conv1(ca, s)); pf.end();
+        pf.begin("conv23"); HIP_TRY(sdfa_launch_conv23(ca, s)); pf.end();
+
+        FreqLstmArgs fa{ws + w.X3, m->fl_w, m->fl_b, ws + w.HF, Mc};
+        pf.begin("freq_lstm"); HIP_TRY(sdfa_launch_freq_lstm(fa, s)); pf.end();
+
+        GemmArgs g{};   // FreqLstm._proj: Linear(8192 -> 256) + bias
+        g.P = m->fp_w; g.Q = ws + w.HF; g.D = ws + w.Z; g.bias = m->fp_b;
+        g.ldp = 256; g.ldq = Mc; g.ldd = Mc; g.Ppad = 256; g.Qpad = Mc; g.Pstore = 256; g.Qreal = Mc;
+        g.K = 8192; g.seg_k = 8192; g.act = ACT_NONE; g.out_mode = OUT_K4;
+        pf.begin("freq_proj"); HIP_TRY(sdfa_launch_gemm(g, s)); pf.end();
+
+        const float *xin = ws + w.Z;
+        float *hout[2] = {ws + w.H0, ws + w.H1};
+        const char *gxn[2] = {"gx0", "gx1"}, *lsn[2] = {"lstm0", "lstm1"};
+        for (int l = 0; l < 2; ++l) {
+            GemmArgs gi{};
+            gi.P = m->gx_w[l]; gi.Q = xin; gi.D = ws + w.GX;
+            gi.ldp = 2048; gi.ldq = Mc; gi.ldd = Mc; gi.Ppad = 2048; gi.Qpad = Mc; gi.Pstore = 2048; gi.Qreal = Mc;
+            gi.K = l == 0 ? 256 : 512; gi.seg_k = gi.K; gi.act = ACT_NONE; gi.out_mode = OUT_K4;
+            pf.begin(gxn[l]); HIP_TRY(sdfa_launch_gemm(gi, s)); pf.end();
+            TimeLstmArgs ta{ws + w.GX, m->tl_w[l], hout[l], Nc, Mc};
+            pf.begin(lsn[l]); HIP_TRY(sdfa_launch_time_lstm(ta, s)); pf.end();
+            xin = hout[l];
+        }
+        // attention: proj_key over all 64 keys, Conv1d query over time steps 31..33, proj_qry
+        pf.begin("attn_proj");
+        GemmArgs gk{};
+        gk.P = m->kp_w; gk.Q = ws + w.H1; gk.D = ws + w.KP;
+        gk.ldp = 128; gk.ldq = Mc; gk.ldd = Mc; gk.Ppad = 128; gk.Qpad = Mc; gk.Pstore = 128; gk.Qreal = Mc;
+        gk.K = 512; gk.seg_k = 512; gk.act = ACT_NONE; gk.out_mode = OUT_K4;
+        HIP_TRY(sdfa_launch_gemm(gk, s));
+        GemmArgs gc{};
+        gc.P = m->qc_w; gc.Q = ws + w.H1 + 31 * Nc * 4; gc.D = ws + w.QC;
+        gc.ldp = 512; gc.ldq = Mc; gc.ldd = Nc; gc.Ppad = 512; gc.Qpad = Nc; gc.Pstore = 512; gc.Qreal = Nc;
+        gc.K = 1536; gc.seg_k = 512; gc.seg_col = Nc; gc.act = ACT_NONE; gc.out_mode = OUT_K4;
+        HIP_TRY(sdfa_launch_gemm(gc, s));
+        GemmArgs gq{};
+        gq.P = m->qp_w; gq.Q = ws + w.QC; gq.D = ws + w.QP;
+        gq.ldp = 128; gq.ldq = Nc; gq.ldd = Nc; gq.Ppad = 128; gq.Qpad = Nc; gq.Pstore = 128; gq.Qreal = Nc;
+        gq.K = 512; gq.seg_k = 512; gq.act = ACT_NONE; gq.out_mode = OUT_K4;
+        HIP_TRY(sdfa_launch_gemm(gq, s));
+        pf.end();
+
+        AttnArgs aa{};
+        aa.KP = ws + w.KP; aa.QP = ws + w.QP; aa.H = ws + w.H1; aa.v = m->at_v; aa.b = m->at_b;
+        aa.Zk4 = ws + w.ZK; aa.z_out = d_z + f0 * 512; aa.align_out = d_align ? d_align + f0 * 64 : nullptr;
+        aa.N = N; aa.Nc = Nc; aa.Mc = Mc;
+        pf.begin("attn"); HIP_TRY(sdfa_launch_attn(aa, s)); pf.end();
+    }
+    return SDFA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int sdfa_regress_forward(const sdfa_model *m, const float *d_z, const int64_t *d_speaker_id, int64_t n_frames,
+                         float *d_coef, float *d_out, void *d_workspace, int64_t workspace_bytes, void *stream) {
+    if (!m || !m->finalized) return fail(SDFA_ESTATE, "regress_forward: model not finalised");
+    if (n_frames == 0) return SDFA_OK;
+    if (!d_z || !d_speaker_id || !d_workspace || n_frames < 0) return fail(SDFA_EINVAL, "regress_forward: bad argument");
+    if (((uintptr_t)d_workspace | (uintptr_t)d_z) & 15) return fail(SDFA_EINVAL, "regress_forward: pointers must be 16-byte aligned");
+    const int64_t cap = capacity(workspace_bytes, m->keep);
+    if (cap < 128) return fail(SDFA_ENOSPACE, "regress_forward: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    Prof pf{m, s};
+    float *ws = (float *)d_workspace;
+    for (int64_t f0 = 0; f0 < n_frames; f0 += cap) {
+        const int64_t N = std::min(cap, n_frames - f0);
+        const int64_t Nc = round_up(N, 128);
+        const Ws w = layout(Nc, m->keep);
+        float *zk = ws + w.ZK, *r = ws + w.R;
+        float *trunk = r, *a0 = r + 512 * Nc, *a1 = r + 1024 * Nc, *coef = r + 1280 * Nc;   // coef: up to 288 rows
+        const int64_t *spk = d_speaker_id + f0;
+        pf.begin("mlp");
+        HIP_TRY(sdfa_launch_rows_to_k4(d_z + f0 * 512, N, 512, zk, Nc, s));
+        if (m->head == SDFA_HEAD_DGRAD) {
+            HIP_TRY(sdfa_launch_gemm(gemm_fc(m->trunk, zk, Nc, trunk, Nc, spk, N), s));
+            for (int b = 0; b < 2; ++b) {
+                HIP_TRY(sdfa_launch_gemm(gemm_fc(m->br[b][0], trunk, Nc, a0, Nc, spk, N), s));
+                HIP_TRY(sdfa_launch_gemm(gemm_fc(m->br[b][1], a0, Nc, a1, Nc, spk, N), s));
+                HIP_TRY(sdfa_launch_gemm(gemm_fc(m->br[b][2], a1, Nc, coef + (b ? 96 * Nc : 0), Nc, spk, N), s));
+            }
+            if (d_coef) {
+                HIP_TRY(sdfa_launch_k4_to_rows(coef, Nc, N, 288, 0, SDFA_COEF_SCALE, d_coef + f0 * m->coef_dim, m->coef_dim, s));
+                HIP_TRY(sdfa_launch_k4_to_rows(coef, Nc, N, 288, 96, SDFA_COEF_ROTAT, d_coef + f0 * m->coef_dim + SDFA_COEF_SCALE, m->coef_dim, s));
+            }
+        } else {
+            HIP_TRY(sdfa_launch_gemm(gemm_fc(m->off[0], zk, Nc, a0, Nc, spk, N), s));
+            HIP_TRY(sdfa_launch_gemm(gemm_fc(m->off[1], a0, Nc, a1, Nc, spk, N), s));
+            HIP_TRY(sdfa_launch_gemm(gemm_fc(m->off[2], a1, Nc, coef, Nc, spk, N), s));
+            if (d_coef) HIP_TRY(sdfa_launch_k4_to_rows(coef, Nc, N, 64, 0, SDFA_COEF_OFFSETS, d_coef + f0 * m->coef_dim, m->coef_dim, s));
+        }
+        pf.end();
+        if (d_out) {
+            // PCA expansion: out[n][o] = sum_k coef[k][n] * basis[k][o] + means[o]   (rows = frames)
+            GemmArgs g{};
+            g.P = coef; g.Q = m->pca_q; g.D = d_out + f0 * m->out_dim; g.bias = m->pca_bias; g.bias_on_q = 1;
+            g.ldp = Nc; g.ldq = m->pca_ld; g.ldd = m->out_dim; g.Ppad = Nc; g.Qpad = m->pca_ld; g.Pstore = N; g.Qreal = m->out_dim;
+            g.K = m->pca_K; g.seg_k = m->pca_K; g.act = ACT_NONE; g.out_mode = OUT_ROW;
+            pf.begin("pca"); HIP_TRY(sdfa_launch_gemm(g, s)); pf.end();
+        }
+    }
+    return SDFA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int sdfa_debug_tap(const sdfa_model *m, int what, int64_t n_frames, float *d_dst, const void *d_workspace, void *stream) {
+    if (!m || !m->keep) return fail(SDFA_ESTATE, "debug_tap needs sdfa_debug_keep_intermediates(model, 1) before the forward");
+    if (what < 0 || what > 3 || n_frames <= 0 || !d_dst || !d_workspace) return fail(SDFA_EINVAL, "debug_tap: bad argument");
+    const int64_t Nc = round_up(n_frames, 128);
+    const Ws w = layout(Nc, true);
+    const float *ws = (const float *)d_workspace;
+    const float *src = what == 0 ? ws + w.P1 : what == 1 ? ws + w.X3 : what == 2 ? ws + w.Z : ws + w.H1;
+    HIP_TRY(sdfa_launch_tap(src, what, n_frames, Nc, d_dst, (hipStream_t)stream));
+    return SDFA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,154 @@
+// Bahdanau attention tail (speech_anime/layers/attentions.py:92-124,69-75) and small layout kernels.
+//
+// The dense contractions of the attention layer (query Conv1d, proj_qry, proj_key) run on the MFMA GEMM
+// (gemm.hip); this kernel does what is left per frame n:
+//     score[t] = v . tanh(qp[:, n] + kp[:, t, n] + b)          t = 0..63
+//     align    = softmax_t(score * 1.0)                         (scale_score_at_eval = 1.0)
+//     ctx      = sum_t align[t] * x[:, t, n]                    (torch.bmm(align, value))
+// One workgroup = 64 consecutive frames (one per lane) so that every global access is a 1 KiB
+// contiguous run of the K4 [feature/4][t*Nc + n] arrays; the 64-way softmax is reduced through LDS.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+    __shared__ float sPart[4][64][64];   // [wave][t][frame] partial scores
+    __shared__ float sAlign[64][64];     // [t][frame]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t n = (int64_t)blockIdx.x * 64 + lane;
+    const float4 *__restrict__ KP = reinterpret_cast<const float4 *>(a.KP);
+    const float4 *__restrict__ QP = reinterpret_cast<const float4 *>(a.QP);
+    const float4 *__restrict__ H = reinterpret_cast<const float4 *>(a.H);
+
+    // ---- scores: wave w sums units 32w .. 32w+31
+    float4 qb[8], vv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        float4 qp = QP[(int64_t)(8 * wave + q) * a.Nc + n];
+        float4 bb = ld4(a.b + (8 * wave + q) * 4);
+        qb[q] = make_float4(qp.x + bb.x, qp.y + bb.y, qp.z + bb.z, qp.w + bb.w);
+        vv[q] = ld4(a.v + (8 * wave + q) * 4);
+    }
+    for (int t = 0; t < 64; ++t) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float4 k = KP[(int64_t)(8 * wave + q) * a.Mc + (int64_t)t * a.Nc + n];
+            s += vv[q].x * tanhf_acc(qb[q].x + k.x);
+            s += vv[q].y * tanhf_acc(qb[q].y + k.y);
+            s += vv[q].z * tanhf_acc(qb[q].z + k.z);
+            s += vv[q].w * tanhf_acc(qb[q].w + k.w);
+        }
+        sPart[wave][t][lane] = s;
+    }
+    __syncthreads();
+    // ---- softmax over t (every wave redundantly; wave w publishes t = 16w .. 16w+15)
+    float mx = -3.0e38f;
+    for (int t = 0; t < 64; ++t) {
+        float s = sPart[0][t][lane] + sPart[1][t][lane] + sPart[2][t][lane] + sPart[3][t][lane];
+        mx = fmaxf(mx, s);
+    }
+    float den = 0.f;
+    for (int t = 0; t < 64; ++t) {
+        float s = sPart[0][t][lane] + sPart[1][t][lane] + sPart[2][t][lane] + sPart[3][t][lane];
+        den += __expf(s - mx);
+    }
+    const float inv = 1.0f / den;
+    for (int t = 16 * wave; t < 16 * wave + 16; ++t) {
+        float s = sPart[0][t][lane] + sPart[1][t][lane] + sPart[2][t][lane] + sPart[3][t][lane];
+        float al = __expf(s - mx) * inv;
+        sAlign[t][lane] = al;
+        if (a.align_out && n < a.N) a.align_out[n * 64 + t] = al;
+    }
+    __syncthreads();
+    // ---- context: wave w owns feature quads 32w .. 32w+31
+    float4 acc[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < 64; ++t) {
+        const float al = sAlign[t][lane];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            float4 x = H[(int64_t)(32 * wave + q) * a.Mc + (int64_t)t * a.Nc + n];
+            acc[q].x += al * x.x; acc[q].y += al * x.y; acc[q].z += al * x.z; acc[q].w += al * x.w;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        st4(a.Zk4 + ((int64_t)(32 * wave + q) * a.Nc + n) * 4, acc[q]);
+        if (a.z_out && n < a.N) st4(a.z_out + n * 512 + (32 * wave + q) * 4, acc[q]);
+    }
+}
+
+// row-major [n][F] -> K4 [F/4][ld]; columns n >= N are zero-filled
+__global__ void rows_to_k4_kernel(const float *__restrict__ src, int64_t N, int F, float *__restrict__ dst, int64_t ld) {
+    const int64_t n = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    if (n >= ld) return;
+    for (int q = threadIdx.x >> 6; q < F / 4; q += blockDim.x >> 6) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < N) v = ld4(src + n * F + 4 * q);
+        st4(dst + ((int64_t)q * ld + n) * 4, v);
+    }
+}
+
+// K4 [.. /4][ld] features f0 .. f0+nf-1  ->  row-major dst[n*dst_ld + (f - f0)]
+__global__ void k4_to_rows_kernel(const float *__restrict__ src, int64_t ld, int64_t N, int f0, int nf,
+                                  float *__restrict__ dst, int64_t dst_ld) {
+    const int64_t n = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    if (n >= N) return;
+    for (int f = f0 + (threadIdx.x >> 6); f < f0 + nf; f += blockDim.x >> 6)
+        dst[n * dst_ld + (f - f0)] = src[((int64_t)(f >> 2) * ld + n) * 4 + (f & 3)];
+}
+
+// debug taps: K4 [F/4][Mc], m = t*Nc + n  ->  the reference's layouts
+//   what 0: pool1 (n, 32 ci, 64 f, 64 t)   K4 rows f*32+ci
+//   what 1: conv3 (n, 64 ch, 32 f, 64 t)   K4 rows f*64+ch
+//   what 2: freq  (n, 256, 64 t)           K4 rows c
+//   what 3: bilstm (n, 64 t, 512)          K4 rows c
+__global__ void tap_kernel(const float *__restrict__ src, int what, int64_t N, int64_t Nc, float *__restrict__ dst) {
+    const int64_t Mc = 64 * Nc;
+    const int64_t total = N * (what <= 1 ? 2048 * 64 : (what == 2 ? 256 * 64 : 512 * 64));
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t n, row, t;
+        if (what == 0) {
+            n = i / (2048 * 64); int64_t r = i % (2048 * 64);
+            int ci = r / (64 * 64), f = (r / 64) % 64; t = r % 64; row = f * 32 + ci;
+        } else if (what == 1) {
+            n = i / (2048 * 64); int64_t r = i % (2048 * 64);
+            int ch = r / (32 * 64), f = (r / 64) % 32; t = r % 64; row = f * 64 + ch;
+        } else if (what == 2) {
+            n = i / (256 * 64); int64_t r = i % (256 * 64);
+            row = r / 64; t = r % 64;
+        } else {
+            n = i / (512 * 64); int64_t r = i % (512 * 64);
+            t = r / 512; row = r % 512;
+        }
+        dst[i] = src[((row >> 2) * Mc + t * Nc + n) * 4 + (row & 3)];
+    }
+}
+
+}  // namespace
+
+hipError_t sdfa_launch_attn(const AttnArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(attn_kernel, dim3((unsigned)(a.Nc / 64)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t sdfa_launch_rows_to_k4(const float *src, int64_t N, int F, float *dst, int64_t ld, hipStream_t s) {
+    hipLaunchKernelGGL(rows_to_k4_kernel, dim3((unsigned)((ld + 63) / 64)), dim3(256), 0, s, src, N, F, dst, ld);
+    return hipGetLastError();
+}
+
+hipError_t sdfa_launch_k4_to_rows(const float *src, int64_t ld, int64_t N, int F, int f0, int nf, float *dst,
+                                  int64_t dst_ld, hipStream_t s) {
+    (void)F;
+    hipLaunchKernelGGL(k4_to_rows_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s, src, ld, N, f0, nf, dst, dst_ld);
+    return hipGetLastError();
+}
+
+hipError_t sdfa_launch_tap(const float *src, int what, int64_t N, int64_t Nc, float *dst, hipStream_t s) {
+    hipLaunchKernelGGL(tap_kernel, dim3(1024), dim3(256), 0, s, src, what, N, Nc, dst);
+    return hipGetLastError();
+}

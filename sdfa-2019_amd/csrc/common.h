@@ -1,0 +1,51 @@
+// Shared device helpers for the gfx950 kernels.
+//
+// Activation layout ("K4"): a [F features][M columns] matrix is stored as float4[F/4][M]:
+// element (f, m) lives at ((f/4)*M + m)*4 + (f%4).  A column is one (animation frame, STFT
+// time step) pair, m = t*Nc + n for frame n of a chunk of Nc frames.  K4 is what the 32x32
+// fp32 MFMA accumulator produces for free (each lane owns 4 consecutive rows per register
+// quad) and what its operands want (one 16-byte LDS read feeds four MFMA k-steps).
+//
+// MFMA used everywhere: v_mfma_f32_32x32x2_f32  (D[32x32] += A[32x2] * B[2x32], exact fp32).
+//   lane l:  A[i = l&31][k = l>>5]   B[k = l>>5][j = l&31]
+//   D reg r: row i = (r&3) + 8*(r>>2) + 4*(l>>5), col j = l&31
+// With operands in K4 a lane in half h = l>>5 reads the float4 of k-quad (2*kb + h); the four
+// MFMAs of k-block kb then contract k = 8kb+{0..3} (half 0) with k = 8kb+4+{0..3} (half 1) --
+// the same pairing an accumulator quad has, so a D tile can be fed back as a B operand
+// straight from registers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ void mfma4(f32x16 &acc, const float4 &a, const float4 &b) {
+    acc = MFMA(a.x, b.x, acc);
+    acc = MFMA(a.y, b.y, acc);
+    acc = MFMA(a.z, b.z, acc);
+    acc = MFMA(a.w, b.w, acc);
+}
+
+__device__ __forceinline__ float lrelu02(float x) { return x >= 0.f ? x : 0.2f * x; }
+
+__device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// tanh with ~1e-7 absolute error: odd, exp-based, no cancellation blow-up near 0
+__device__ __forceinline__ float tanhf_acc(float x) {
+    float ax = fabsf(x);
+    float r;
+    if (ax < 0.04f) {
+        float x2 = x * x;
+        r = x * (1.0f + x2 * (-0.33333334f + x2 * 0.13333334f));
+    } else {
+        float e = __expf(-2.0f * ax);
+        r = copysignf((1.0f - e) / (1.0f + e), x);
+    }
+    return r;
+}
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, const float4 &v) { *reinterpret_cast<float4 *>(p) = v; }

@@ -1,0 +1,188 @@
+// Conv stack of the audio encoder (speech_anime/config/model/dgrad.py:62-64):
+//   conv2d 3->32 (3,1) + LeakyReLU(0.2) + BN  -> maxpool (2,1)        [conv1_pool_kernel]
+//   conv2d 32->64 (3,1) + LeakyReLU + BN      -> maxpool (2,1)
+//   conv2d 64->64 (1,1) + LeakyReLU + BN                               [conv23_kernel, chained in registers]
+// Reference arithmetic: saber/nn/layers/conv2d.py:6-28,64-97 ('same' zero pad along frequency,
+// saber/nn/functions.py:204-249), extend.py:94-101 (activation THEN BatchNorm, eval statistics, eps 1e-3).
+//
+// Kernels act along frequency only, so every (frame, time-step) column is an independent
+// 128-bin signal: the stack is a set of small GEMMs  D[co][col] = W[co][k] * X[k][col]  with
+// 32 columns on the MFMA lanes.  Because the conv is along the row (k) axis of a [f][ci][col]
+// image, the im2col matrix of output row f is just 3*ci CONTIGUOUS rows of that image.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------- conv1 + pool
+constexpr int C1_ROWS = 391;   // input rows f*3+c = -3 .. 387 (zero rows either side)
+
+__global__ __launch_bounds__(256, 2) void conv1_pool_kernel(ConvArgs a) {
+    __shared__ float sIn[C1_ROWS][32];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * 32;
+    const int64_t t = m0 / a.Nc, n0 = m0 % a.Nc;
+
+    // audio_feat row (n, t) is 384 contiguous floats (f*3 + c); transpose into [k][col]
+    for (int idx = tid; idx < 32 * 96; idx += 256) {
+        int col = idx / 96, q = idx % 96;
+        int64_t n = n0 + col;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < a.N) v = ld4(a.audio_feat + ((n * 64 + t) * 384 + 4 * q));
+        sIn[3 + 4 * q + 0][col] = v.x;
+        sIn[3 + 4 * q + 1][col] = v.y;
+        sIn[3 + 4 * q + 2][col] = v.z;
+        sIn[3 + 4 * q + 3][col] = v.w;
+    }
+    if (tid < 32 * 7) {
+        int r = tid >> 5, c = tid & 31;
+        sIn[r < 3 ? r : 384 + r][c] = 0.f;   // rows 0..2 and 387..390
+    }
+    float wa[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) wa[s] = a.w1[(s * 2 + h) * 32 + l31];
+    float4 bb[4], ss[4], tt[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        bb[g] = ld4(a.b1 + 8 * g + 4 * h);
+        ss[g] = ld4(a.s1 + 8 * g + 4 * h);
+        tt[g] = ld4(a.t1 + 8 * g + 4 * h);
+    }
+    __syncthreads();
+
+    for (int pp = 0; pp < 16; ++pp) {
+        const int p = wave * 16 + pp;   // pooled row; conv rows f = 2p, 2p+1
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            float b0 = sIn[(2 * p) * 3 + 2 * s + h][l31];
+            float b1 = sIn[(2 * p + 1) * 3 + 2 * s + h][l31];
+            acc0 = MFMA(wa[s], b0, acc0);
+            acc1 = MFMA(wa[s], b1, acc1);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float bq[4] = {bb[g].x, bb[g].y, bb[g].z, bb[g].w};
+            const float sq[4] = {ss[g].x, ss[g].y, ss[g].z, ss[g].w};
+            const float tq[4] = {tt[g].x, tt[g].y, tt[g].z, tt[g].w};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v0 = lrelu02(acc0[4 * g + e] + bq[e]) * sq[e] + tq[e];
+                float v1 = lrelu02(acc1[4 * g + e] + bq[e]) * sq[e] + tq[e];
+                o[e] = fmaxf(v0, v1);
+            }
+            st4(a.P1 + (((int64_t)(p * 8 + 2 * g + h)) * a.Mc + m0 + l31) * 4, make_float4(o[0], o[1], o[2], o[3]));
+        }
+    }
+}
+
+// ------------------------------------------------------- conv2 + pool + conv3 (register-chained)
+// One workgroup: 32 columns x 4 pooled output rows (one per wave).  A wave computes conv2 rows
+// 2fo and 2fo+1 for all 64 channels (4 MFMA tiles, K = 96), applies LeakyReLU/BN, max-pools the
+// two rows in registers, and feeds the pooled 64x32 tile straight back as the B operand of the
+// 1x1 conv3 (2 tiles, K = 64).
+__global__ __launch_bounds__(256, 2) void conv23_kernel(ConvArgs a) {
+    __shared__ float4 sP1[80][32];   // 10 pool1 rows x 32 ci as 80 k-quads
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int fc = blockIdx.x & 7;                       // chunk of 4 pooled rows
+    const int64_t m0 = (int64_t)(blockIdx.x >> 3) * 32;
+    const int f1lo = 8 * fc - 1;                         // first pool1 row held in LDS
+
+    const float4 *__restrict__ P1 = reinterpret_cast<const float4 *>(a.P1);
+    for (int idx = tid; idx < 80 * 32; idx += 256) {
+        int qd = idx >> 5, col = idx & 31;
+        int f1 = f1lo + (qd >> 3);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f1 >= 0 && f1 < 64) v = P1[(int64_t)(f1 * 8 + (qd & 7)) * a.Mc + m0 + col];
+        sP1[qd][col] = v;
+    }
+    __syncthreads();
+
+    const float4 *__restrict__ W2 = reinterpret_cast<const float4 *>(a.w2);
+    const float4 *__restrict__ W3 = reinterpret_cast<const float4 *>(a.w3);
+    const int fo = fc * 4 + wave;
+
+    f32x16 acc[2][2];   // [conv row a/b][out tile]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll 2
+    for (int kb = 0; kb < 12; ++kb) {
+        float4 wa0 = W2[(2 * kb + h) * 64 + l31];
+        float4 wa1 = W2[(2 * kb + h) * 64 + 32 + l31];
+        float4 xa = sP1[16 * wave + 2 * kb + h][l31];
+        float4 xb = sP1[16 * wave + 8 + 2 * kb + h][l31];
+        mfma4(acc[0][0], wa0, xa);
+        mfma4(acc[0][1], wa1, xa);
+        mfma4(acc[1][0], wa0, xb);
+        mfma4(acc[1][1], wa1, xb);
+    }
+    // LeakyReLU -> BN -> max over the row pair: pooled tile, rows = channels
+    f32x16 p2[2];
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 b = ld4(a.b2 + ot * 32 + 8 * g + 4 * h), s = ld4(a.s2 + ot * 32 + 8 * g + 4 * h),
+                   t = ld4(a.t2 + ot * 32 + 8 * g + 4 * h);
+            const float bq[4] = {b.x, b.y, b.z, b.w}, sq[4] = {s.x, s.y, s.z, s.w}, tq[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v0 = lrelu02(acc[0][ot][4 * g + e] + bq[e]) * sq[e] + tq[e];
+                float v1 = lrelu02(acc[1][ot][4 * g + e] + bq[e]) * sq[e] + tq[e];
+                p2[ot][4 * g + e] = fmaxf(v0, v1);
+            }
+        }
+    // conv3 (1x1): contract over the pooled tile's ROW index straight from registers
+    f32x16 acc3[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc3[j][r] = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 xb = make_float4(p2[ct][4 * g], p2[ct][4 * g + 1], p2[ct][4 * g + 2], p2[ct][4 * g + 3]);
+            float4 w0 = W3[(8 * ct + 2 * g + h) * 64 + l31];
+            float4 w1 = W3[(8 * ct + 2 * g + h) * 64 + 32 + l31];
+            mfma4(acc3[0], w0, xb);
+            mfma4(acc3[1], w1, xb);
+        }
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 b = ld4(a.b3 + ot * 32 + 8 * g + 4 * h), s = ld4(a.s3 + ot * 32 + 8 * g + 4 * h),
+                   t = ld4(a.t3 + ot * 32 + 8 * g + 4 * h);
+            float4 o;
+            o.x = lrelu02(acc3[ot][4 * g + 0] + b.x) * s.x + t.x;
+            o.y = lrelu02(acc3[ot][4 * g + 1] + b.y) * s.y + t.y;
+            o.z = lrelu02(acc3[ot][4 * g + 2] + b.z) * s.z + t.z;
+            o.w = lrelu02(acc3[ot][4 * g + 3] + b.w) * s.w + t.w;
+            st4(a.X3 + ((int64_t)(fo * 16 + ot * 8 + 2 * g + h) * a.Mc + m0 + l31) * 4, o);
+        }
+}
+
+}  // namespace
+
+hipError_t sdfa_launch_conv1(const ConvArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(conv1_pool_kernel, dim3((unsigned)(a.Mc / 32)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t sdfa_launch_conv23(const ConvArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(conv23_kernel, dim3((unsigned)(a.Mc / 32 * 8)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}

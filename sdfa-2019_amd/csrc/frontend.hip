@@ -1,0 +1,186 @@
+// Spectral-gather front end: PCM window -> (64, 128, 3) mel / delta / delta-delta features.
+//
+// Reference arithmetic (paths relative to the reference repository):
+//   window cut + zero pad            speech_anime/datasets/sliding_window.py:356-362
+//   per-window pre-emphasis 0.65     saber/data/audio/features/misc.py:8-17   (y[0] = x[0])
+//   Hamming STFT, center=False       saber/data/audio/features/spectrogram.py:82-96
+//   power, 128-band Slaney mel       spectrogram.py:97-98, misc.py:110-117
+//   dB, normalise, clamp             spectrogram.py:238,245-249
+//   delta / delta-delta (SG width 9) speech_anime/datasets/get_features.py:199-207
+//   (T,F,C) interleave               get_features.py:210-215, sliding_window.py:462
+//
+// One 256-thread workgroup per animation frame.  The zero-padded, pre-emphasised window is
+// staged once in LDS (coalesced HBM read of sliding*4 bytes); each wave then transforms PAIRS
+// of STFT columns as one complex radix-4 Stockham FFT (column t in the real part, t+1 in the
+// imaginary part) with twiddles and the Hamming window resident in LDS, untangles the two
+// spectra, gathers the sparse mel rows (CSR, ~449 non-zeros, only bins below 3.6 kHz are ever
+// needed) and writes log-mel into an LDS image from which the 9-tap delta filters and the
+// interleaved (T,F,C) store run.  HBM traffic per frame: the window read + 98,304 bytes written.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+template <int WIN>
+__global__ __launch_bounds__(256) void frontend_kernel(FrontendConsts c, const float *__restrict__ pcm,
+                                                       const int64_t *__restrict__ clip_off,
+                                                       const int64_t *__restrict__ clip_len,
+                                                       const int32_t *__restrict__ frame_clip,
+                                                       const int64_t *__restrict__ frame_start, float *__restrict__ out) {
+    constexpr int HOP = WIN / 8, SLIDING = HOP * 63 + WIN, NB = 256, NR4 = WIN / 256;   // radix-4 butterflies per lane
+    constexpr bool HAS_R2 = (WIN == 512);
+    __shared__ float sY[SLIDING];
+    __shared__ float2 sFft[4][WIN];
+    __shared__ float2 sTw[WIN];
+    __shared__ float sHamm[WIN];
+    __shared__ float sPow[4][2][NB];
+    __shared__ float sMel[64][129];
+    __shared__ int sPtr[132];
+    __shared__ int sBin[512];
+    __shared__ float sW[512];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t frame = blockIdx.x;
+    const int clip = frame_clip[frame];
+    const int64_t off = clip_off[clip], len = clip_len[clip], s0 = frame_start[frame];
+
+    for (int i = tid; i < WIN; i += 256) { sTw[i] = c.twiddle[i]; sHamm[i] = c.hamm[i]; }
+    for (int i = tid; i < 129; i += 256) sPtr[i] = c.mel_ptr[i];
+    for (int i = tid; i < c.nnz; i += 256) { sBin[i] = c.mel_bin[i]; sW[i] = c.mel_w[i]; }
+    // window cut, zero pad, pre-emphasis (fp32, one rounding per op as numpy does)
+    for (int i = tid; i < SLIDING; i += 256) {
+        const int64_t g = s0 + i;
+        float x = (g >= 0 && g < len) ? pcm[off + g] : 0.f;
+        float xm = (i > 0 && g - 1 >= 0 && g - 1 < len) ? pcm[off + g - 1] : 0.f;
+        sY[i] = (i == 0) ? x : __fsub_rn(x, __fmul_rn(0.65f, xm));
+    }
+    __syncthreads();
+
+    float2 *buf = sFft[wave];
+    for (int pi = wave; pi < 32; pi += 4) {      // all four waves run 8 iterations: block barriers are uniform
+        const int t0 = 2 * pi;
+        const float *ya = sY + t0 * HOP, *yb = sY + (t0 + 1) * HOP;
+        float2 v[NR4][4];
+        // ---- stage 0 (Ns = 1) straight from the windowed signal
+#pragma unroll
+        for (int b = 0; b < NR4; ++b) {
+            const int j = lane + 64 * b;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nidx = j + r * (WIN / 4);
+                const float w = sHamm[nidx];
+                v[b][r] = make_float2(w * ya[nidx], w * yb[nidx]);
+            }
+        }
+        int Ns = 1;
+#pragma unroll
+        for (int stage = 0; stage < (HAS_R2 ? 4 : 5); ++stage) {
+            if (stage > 0) {
+#pragma unroll
+                for (int b = 0; b < NR4; ++b) {
+                    const int j = lane + 64 * b, k = j & (Ns - 1);
+                    const int tstep = k * (WIN / (4 * Ns));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float2 x = buf[j + r * (WIN / 4)];
+                        v[b][r] = (r == 0) ? x : cmul(x, sTw[(tstep * r) & (WIN - 1)]);
+                    }
+                }
+                __syncthreads();   // every read of this stage done before any write
+            }
+#pragma unroll
+            for (int b = 0; b < NR4; ++b) {
+                const int j = lane + 64 * b, k = j & (Ns - 1);
+                const int j0 = (j - k) * 4 + k;
+                float2 a0 = cadd(v[b][0], v[b][2]), a1 = csub(v[b][0], v[b][2]);
+                float2 a2 = cadd(v[b][1], v[b][3]), d = csub(v[b][1], v[b][3]);
+                float2 a3 = make_float2(d.y, -d.x);   // (-i) * d
+                buf[j0] = cadd(a0, a2);
+                buf[j0 + Ns] = cadd(a1, a3);
+                buf[j0 + 2 * Ns] = csub(a0, a2);
+                buf[j0 + 3 * Ns] = csub(a1, a3);
+            }
+            __syncthreads();
+            Ns *= 4;
+        }
+        if (HAS_R2) {   // WIN = 512 = 4^4 * 2: final radix-2 stage, Ns = 256
+            float2 u[4][2];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int j = lane + 64 * b;
+                u[b][0] = buf[j];
+                u[b][1] = cmul(buf[j + WIN / 2], sTw[j]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int j = lane + 64 * b;
+                buf[j] = cadd(u[b][0], u[b][1]);
+                buf[j + WIN / 2] = csub(u[b][0], u[b][1]);
+            }
+            __syncthreads();
+        }
+        // ---- untangle the two real spectra, power
+        for (int k = lane; k < c.nbins_used; k += 64) {
+            float2 zk = buf[k], zn = buf[(WIN - k) & (WIN - 1)];
+            float ar = 0.5f * (zk.x + zn.x), ai = 0.5f * (zk.y - zn.y);     // A = (Z[k] + conj Z[N-k]) / 2
+            float br = 0.5f * (zk.y + zn.y), bi = -0.5f * (zk.x - zn.x);    // B = (Z[k] - conj Z[N-k]) / (2i)
+            sPow[wave][0][k] = __fadd_rn(__fmul_rn(ar, ar), __fmul_rn(ai, ai));
+            sPow[wave][1][k] = __fadd_rn(__fmul_rn(br, br), __fmul_rn(bi, bi));
+        }
+        __syncthreads();
+        // ---- sparse mel gather, dB, normalise, clamp
+#pragma unroll
+        for (int col = 0; col < 2; ++col)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const int band = lane + 64 * bb;
+                float m = 0.f;
+                for (int e = sPtr[band]; e < sPtr[band + 1]; ++e) m += sW[e] * sPow[wave][col][sBin[e]];
+                float db = __fmul_rn(10.0f, log10f(fmaxf(m, 1.1920929e-07f)));
+                float nv = __fdiv_rn(__fadd_rn(__fsub_rn(db, 20.0f), 80.0f), 80.0f);
+                sMel[t0 + col][band] = fminf(fmaxf(nv, 0.f), 1.f);
+            }
+        __syncthreads();
+    }
+    // ---- Savitzky-Golay deltas (edges replicate the first / last interior value) + (T,F,C) store
+    const float c2[9] = {28.f / 462.f, 7.f / 462.f, -8.f / 462.f, -17.f / 462.f, -20.f / 462.f,
+                         -17.f / 462.f, -8.f / 462.f, 7.f / 462.f, 28.f / 462.f};
+    float *dst = out + frame * (64 * 128 * 3);
+    for (int idx = tid; idx < 64 * 128; idx += 256) {
+        const int t = idx >> 7, f = idx & 127;
+        const int tc = t < 4 ? 4 : (t > 59 ? 59 : t);
+        float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+        for (int j = -4; j <= 4; ++j) {
+            const float mv = sMel[tc + j][f];
+            d1 += (float)j * (1.0f / 60.0f) * mv;
+            d2 += c2[j + 4] * mv;
+        }
+        dst[idx * 3 + 0] = sMel[t][f];
+        dst[idx * 3 + 1] = d1;
+        dst[idx * 3 + 2] = d2;
+    }
+}
+
+}  // namespace
+
+hipError_t sdfa_launch_frontend(const FrontendConsts &c, const float *pcm, const int64_t *clip_off,
+                                const int64_t *clip_len, const int32_t *frame_clip, const int64_t *frame_start,
+                                int64_t n_frames, float *audio_feat, hipStream_t s) {
+    if (n_frames <= 0) return hipSuccess;
+    if (c.nnz > 512 || c.nbins_used > 256) return hipErrorInvalidValue;
+    if (c.win == 1024)
+        hipLaunchKernelGGL(frontend_kernel<1024>, dim3((unsigned)n_frames), dim3(256), 0, s, c, pcm, clip_off, clip_len,
+                           frame_clip, frame_start, audio_feat);
+    else if (c.win == 512)
+        hipLaunchKernelGGL(frontend_kernel<512>, dim3((unsigned)n_frames), dim3(256), 0, s, c, pcm, clip_off, clip_len,
+                           frame_clip, frame_start, audio_feat);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}

@@ -1,0 +1,93 @@
+// Internal launcher interface between api.cpp (host orchestration) and the .hip kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_TANH = 2 };
+enum { OUT_K4 = 0, OUT_ROW = 1 };
+
+struct GemmArgs {
+    const float *P;      // K4 [K/4][ldp]
+    const float *Q;      // K4 [K/4][ldq] (per segment)
+    float *D;
+    const float *bias;   // over p (K4 features) or over q (OUT_ROW)
+    const float *cond_w; // K4-ish [Ppad/4][8][4]: column of the FC weight that the one-hot speaker selects
+    const int64_t *cond_idx;  // [Qreal] speaker ids
+    int64_t ldp, ldq, ldd;
+    int64_t Ppad, Qpad;  // multiples of 128: tiles launched
+    int64_t Pstore;      // rows actually stored (multiple of 4)
+    int64_t Qreal;       // columns that exist (OUT_ROW store mask / bias_q / cond bounds)
+    int K;               // total contraction length, multiple of 32
+    int seg_k;           // contraction length per segment (= K when one segment)
+    int64_t seg_col;     // Q column offset between segments
+    int act, out_mode, bias_on_q;
+};
+hipError_t sdfa_launch_gemm(const GemmArgs &a, hipStream_t s);
+
+// ---- front end -----------------------------------------------------------------------------
+struct FrontendConsts {      // device pointers, built once per sample rate
+    const float *hamm;       // [win]
+    const float2 *twiddle;   // [win]  exp(-2*pi*i*m/win)
+    const int *mel_ptr;      // [129]  CSR over mel bands
+    const int *mel_bin;      // [nnz]
+    const float *mel_w;      // [nnz]
+    int win, hop, sliding, nbins_used, nnz;
+};
+hipError_t sdfa_launch_frontend(const FrontendConsts &c, const float *pcm, const int64_t *clip_off,
+                                const int64_t *clip_len, const int32_t *frame_clip, const int64_t *frame_start,
+                                int64_t n_frames, float *audio_feat, hipStream_t s);
+
+// ---- conv stack ----------------------------------------------------------------------------
+struct ConvArgs {
+    const float *audio_feat;  // [N][64][128][3]
+    int64_t N, Nc, Mc;        // real frames, padded frames per chunk, columns = 64*Nc
+    // conv1: packed A operand [5 k-steps][2 halves][32 co] (k = df*3 + c, k = 9 -> 0), epilogue constants
+    const float *w1, *b1, *s1, *t1;   // bias, BN scale, BN shift per co
+    float *P1;                // K4 [2048/4][Mc]   rows f1*32 + co
+    // conv2 / conv3: K4 weights [K/4][64][4]
+    const float *w2, *b2, *s2, *t2;   // K = 96  (k = df*32 + ci)
+    const float *w3, *b3, *s3, *t3;   // K = 64
+    float *X3;                // K4 [2048/4][Mc]   rows f*64 + ch
+};
+hipError_t sdfa_launch_conv1(const ConvArgs &a, hipStream_t s);
+hipError_t sdfa_launch_conv23(const ConvArgs &a, hipStream_t s);
+
+// ---- LSTM recurrences ----------------------------------------------------------------------
+struct FreqLstmArgs {
+    const float *X3;     // K4 [2048/4][Mc]
+    const float *W;      // per direction: K4 [(64+128)/4][512][4], gate rows packed per wave
+    const float *bias;   // per direction: [512] packed (b_ih + b_hh)
+    float *HF;           // K4 [8192/4][Mc]  rows f*256 + dir*128 + j
+    int64_t Mc;
+};
+hipError_t sdfa_launch_freq_lstm(const FreqLstmArgs &a, hipStream_t s);
+
+struct TimeLstmArgs {
+    const float *GX;     // K4 [2048/4][Mc]  rows dir*1024 + packed gate row  (input projections)
+    const float *W;      // per direction: K4 [256/4][1024][4]
+    float *H;            // K4 [512/4][Mc]   rows dir*256 + j
+    int64_t Nc, Mc;
+};
+hipError_t sdfa_launch_time_lstm(const TimeLstmArgs &a, hipStream_t s);
+
+// ---- attention scores / softmax / context ---------------------------------------------------
+struct AttnArgs {
+    const float *KP;     // K4 [128/4][Mc]  key projections
+    const float *QP;     // K4 [128/4][Nc]  query projection
+    const float *H;      // K4 [512/4][Mc]  values (BiLSTM output)
+    const float *v;      // [128]
+    const float *b;      // [128]
+    float *Zk4;          // K4 [512/4][Nc]  context (feeds the output MLPs)
+    float *z_out;        // [N][512] row-major (may be null)
+    float *align_out;    // [N][64]  row-major (may be null)
+    int64_t N, Nc, Mc;
+};
+hipError_t sdfa_launch_attn(const AttnArgs &a, hipStream_t s);
+
+// ---- layout helpers --------------------------------------------------------------------------
+// row-major [n][F] (n < N) -> K4 [F/4][ld]  (zero for n >= N), and back
+hipError_t sdfa_launch_rows_to_k4(const float *src, int64_t N, int F, float *dst, int64_t ld, hipStream_t s);
+hipError_t sdfa_launch_k4_to_rows(const float *src, int64_t ld, int64_t N, int F, int f0, int nf, float *dst,
+                                  int64_t dst_ld, hipStream_t s);
+// debug taps (tests): K4 [F/4][Mc] with m = t*Nc+n  ->  reference layouts
+hipError_t sdfa_launch_tap(const float *src, int what, int64_t N, int64_t Nc, float *dst, hipStream_t s);

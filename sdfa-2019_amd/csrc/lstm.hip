@@ -1,0 +1,214 @@
+// LSTM recurrences of the audio encoder on fp32 MFMA.
+//
+//   freq_lstm_kernel : FreqLstm (speech_anime/layers/freq_lstm.py:36-55) -- bidirectional LSTM(64 -> 128,
+//                      biases) over the 32 frequency rows of every (frame, time-step) column.  The input
+//                      projection is fused: each step contracts [x_f | h] (K = 64 + 128) against the
+//                      concatenated weights, so no gate pre-activations ever go to HBM.
+//   time_lstm_kernel : one layer/direction of torch.nn.LSTM(256 -> 256, bias=False, bidirectional)
+//                      (speech_anime/layers/rnn.py:20-21) over the 64 time steps of every frame; the input
+//                      projection x_t * W_ih^T comes precomputed from the GEMM (GX) and seeds the accumulators.
+//
+// Both: one workgroup owns 64 sequences (columns) for all steps, gate rows on the MFMA row axis and
+// sequences on the lanes.  Gate rows are packed per wave as [i | f | g | o] x 32 hidden units, so the four
+// gate tiles of one wave share a register layout and the cell update is purely elementwise in registers;
+// only h crosses waves, through LDS in K4 layout (which is exactly what an accumulator quad stores).
+// Weights stream from L2 every step (0.4-1 MB per direction; fp32 MFMA needs < 20 GB/s per CU of them).
+// PyTorch gate order i, f, g, o;  c' = sig(f)*c + sig(i)*tanh(g);  h' = sig(o)*tanh(c').
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ void lstm_cell_quad(const f32x16 &ai, const f32x16 &af, const f32x16 &ag, const f32x16 &ao,
+                                               f32x16 &c, int g, float4 &hq) {
+    float hv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        float ig = sigmoidf_acc(ai[r]);
+        float fg = sigmoidf_acc(af[r]);
+        float gg = tanhf_acc(ag[r]);
+        float og = sigmoidf_acc(ao[r]);
+        float cn = fg * c[r] + ig * gg;
+        c[r] = cn;
+        hv[e] = og * tanhf_acc(cn);
+    }
+    hq = make_float4(hv[0], hv[1], hv[2], hv[3]);
+}
+
+// ------------------------------------------------------------------------------------ frequency LSTM
+__global__ __launch_bounds__(256, 2) void freq_lstm_kernel(FreqLstmArgs a) {
+    __shared__ float4 sH[32][64];       // h_{s-1}: 128 hidden as 32 k-quads x 64 sequences
+    __shared__ float4 sX[2][16][64];    // x_f tile, double buffered
+    __shared__ float sBias[512];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int dir = blockIdx.x & 1;
+    const int64_t m0 = (int64_t)(blockIdx.x >> 1) * 64;
+
+    const float4 *__restrict__ X3 = reinterpret_cast<const float4 *>(a.X3);
+    const float4 *__restrict__ W = reinterpret_cast<const float4 *>(a.W) + (size_t)dir * 48 * 512;
+    float4 *__restrict__ HF = reinterpret_cast<float4 *>(a.HF);
+
+    sBias[tid] = a.bias[dir * 512 + tid];
+    sBias[256 + tid] = a.bias[dir * 512 + 256 + tid];
+
+    float4 xr0, xr1, xr2, xr3;
+#define XLOAD1(f, i, R) { const int idx = (i)*256 + tid; R = X3[(int64_t)((f)*16 + (idx >> 6)) * a.Mc + m0 + (idx & 63)]; }
+#define XLOAD(f) XLOAD1(f, 0, xr0) XLOAD1(f, 1, xr1) XLOAD1(f, 2, xr2) XLOAD1(f, 3, xr3)
+#define XSTORE1(buf, i, R) { const int idx = (i)*256 + tid; sX[buf][idx >> 6][idx & 63] = R; }
+#define XSTORE(buf) XSTORE1(buf, 0, xr0) XSTORE1(buf, 1, xr1) XSTORE1(buf, 2, xr2) XSTORE1(buf, 3, xr3)
+    XLOAD(dir ? 31 : 0)
+    XSTORE(0)
+    __syncthreads();
+
+    f32x16 c[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[j][r] = 0.f;
+
+    const float4 *__restrict__ Ww = W + wave * 128 + l31;   // + quad*512 + gate*32
+
+    for (int s = 0; s < 32; ++s) {
+        const int f = dir ? 31 - s : s;
+        const int cur = s & 1;
+        if (s + 1 < 32) { XLOAD(dir ? 30 - s : s + 1) }
+
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 b = *reinterpret_cast<const float4 *>(&sBias[wave * 128 + gt * 32 + 8 * g + 4 * h]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[gt][j][4 * g + 0] = b.x; acc[gt][j][4 * g + 1] = b.y;
+                    acc[gt][j][4 * g + 2] = b.z; acc[gt][j][4 * g + 3] = b.w;
+                }
+            }
+        // x part: k-quads 0..15
+#pragma unroll 2
+        for (int kb = 0; kb < 8; ++kb) {
+            const int kq = 2 * kb + h;
+            float4 b0 = sX[cur][kq][l31], b1 = sX[cur][kq][32 + l31];
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt) {
+                float4 w = Ww[kq * 512 + gt * 32];
+                mfma4(acc[gt][0], w, b0);
+                mfma4(acc[gt][1], w, b1);
+            }
+        }
+        // h part: k-quads 16..47 (h_{-1} = 0: skipped on the first step)
+        if (s > 0) {
+#pragma unroll 2
+            for (int kb = 0; kb < 16; ++kb) {
+                const int kq = 2 * kb + h;
+                float4 b0 = sH[kq][l31], b1 = sH[kq][32 + l31];
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt) {
+                    float4 w = Ww[(16 + kq) * 512 + gt * 32];
+                    mfma4(acc[gt][0], w, b0);
+                    mfma4(acc[gt][1], w, b1);
+                }
+            }
+        }
+        __syncthreads();   // every wave has finished reading sH / sX[cur]
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 hq;
+                lstm_cell_quad(acc[0][j], acc[1][j], acc[2][j], acc[3][j], c[j], g, hq);
+                const int hq_idx = 8 * wave + 2 * g + h;
+                sH[hq_idx][j * 32 + l31] = hq;
+                HF[(int64_t)(f * 64 + dir * 32 + hq_idx) * a.Mc + m0 + j * 32 + l31] = hq;
+            }
+        if (s + 1 < 32) { XSTORE(cur ^ 1) }
+        __syncthreads();
+    }
+}
+
+// ----------------------------------------------------------------------------------------- time LSTM
+__global__ __launch_bounds__(512, 2) void time_lstm_kernel(TimeLstmArgs a) {
+    extern __shared__ float4 sHt[];   // [2][64 k-quads][64 sequences]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // 8 waves: hidden block of 32
+    const int l31 = lane & 31, h = lane >> 5;
+    const int dir = blockIdx.x & 1;
+    const int64_t n0 = (int64_t)(blockIdx.x >> 1) * 64;
+
+    const float4 *__restrict__ GX = reinterpret_cast<const float4 *>(a.GX);
+    const float4 *__restrict__ Ww = reinterpret_cast<const float4 *>(a.W) + (size_t)dir * 64 * 1024 + wave * 128 + l31;
+    float4 *__restrict__ H = reinterpret_cast<float4 *>(a.H);
+
+    f32x16 c[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[j][r] = 0.f;
+
+    for (int s = 0; s < 64; ++s) {
+        const int t = dir ? 63 - s : s;
+        const int64_t mcol = (int64_t)t * a.Nc + n0 + l31;
+        const float4 *sHc = sHt + (size_t)(s & 1) * 64 * 64;
+        float4 *sHn = sHt + (size_t)((s & 1) ^ 1) * 64 * 64;
+
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float4 v = GX[(int64_t)(dir * 256 + wave * 32 + gt * 8 + 2 * g + h) * a.Mc + mcol + j * 32];
+                    acc[gt][j][4 * g + 0] = v.x; acc[gt][j][4 * g + 1] = v.y;
+                    acc[gt][j][4 * g + 2] = v.z; acc[gt][j][4 * g + 3] = v.w;
+                }
+        if (s > 0) {
+#pragma unroll 2
+            for (int kb = 0; kb < 32; ++kb) {
+                const int kq = 2 * kb + h;
+                float4 b0 = sHc[kq * 64 + l31], b1 = sHc[kq * 64 + 32 + l31];
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt) {
+                    float4 w = Ww[kq * 1024 + gt * 32];
+                    mfma4(acc[gt][0], w, b0);
+                    mfma4(acc[gt][1], w, b1);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 hq;
+                lstm_cell_quad(acc[0][j], acc[1][j], acc[2][j], acc[3][j], c[j], g, hq);
+                const int hq_idx = 8 * wave + 2 * g + h;
+                sHn[hq_idx * 64 + j * 32 + l31] = hq;
+                H[(int64_t)(dir * 64 + hq_idx) * a.Mc + mcol + j * 32] = hq;
+            }
+        __syncthreads();   // h_s complete in sHn before anyone reads it; sHc free for step s+1's writes
+    }
+}
+
+}  // namespace
+
+hipError_t sdfa_launch_freq_lstm(const FreqLstmArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(freq_lstm_kernel, dim3((unsigned)(a.Mc / 64 * 2)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t sdfa_launch_time_lstm(const TimeLstmArgs &a, hipStream_t s) {
+    static bool attr_set = false;
+    const size_t lds = 2 * 64 * 64 * sizeof(float4);   // 128 KiB
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(time_lstm_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(time_lstm_kernel, dim3((unsigned)(a.Nc / 64 * 2)), dim3(512), lds, s, a);
+    return hipGetLastError();
+}

@@ -1,0 +1,69 @@
+"""ctypes binding of libsdfa_hip.so -- the C ABI declared in include/sdfa_hip.h.
+
+There is NO fallback: if the HIP library is missing or a symbol is absent, importing this
+module raises.  The product path never routes through a CPU implementation.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("SDFA_HIP_LIB", os.path.join(_HERE, "libsdfa_hip.so"))
+
+OK, EINVAL, ESHORTCLIP, EHIP, ESTATE, ENOSPACE = 0, -1, -2, -3, -4, -5
+HEAD_DGRAD, HEAD_OFFSETS = 0, 1
+
+# name -> (restype, argtypes); kept in one table so tests can check every declared symbol is exported
+_p, _i64, _i32, _f = C.c_void_p, C.c_int64, C.c_int32, C.c_float
+SYMBOLS = {
+    "sdfa_abi_version": (C.c_int, []),
+    "sdfa_last_error": (C.c_char_p, []),
+    "sdfa_frame_index": (_i64, [_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _i64]),
+    "sdfa_mel_frontend": (C.c_int, [_p, _p, _p, _i32, _p, _p, _i64, C.c_int, _p, _p]),
+    "sdfa_model_create": (_p, [C.c_int]),
+    "sdfa_model_destroy": (None, [_p]),
+    "sdfa_model_set_tensor": (C.c_int, [_p, C.c_char_p, _p, _i64]),
+    "sdfa_model_finalize": (C.c_int, [_p, _p]),
+    "sdfa_model_head": (C.c_int, [_p]),
+    "sdfa_model_out_dim": (_i64, [_p]),
+    "sdfa_model_coef_dim": (_i64, [_p]),
+    "sdfa_workspace_bytes": (_i64, [_p, _i64]),
+    "sdfa_encoder_forward": (C.c_int, [_p, _p, _i64, _p, _p, _p, _i64, _p]),
+    "sdfa_regress_forward": (C.c_int, [_p, _p, _p, _i64, _p, _p, _p, _i64, _p]),
+    "sdfa_debug_keep_intermediates": (C.c_int, [_p, C.c_int]),
+    "sdfa_debug_tap": (C.c_int, [_p, C.c_int, _i64, _p, _p, _p]),
+    "sdfa_profile_enable": (C.c_int, [_p, C.c_int]),
+    "sdfa_profile_reset": (C.c_int, [_p]),
+    "sdfa_profile_ms": (_f, [_p, C.c_char_p]),
+}
+
+
+class SdfaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libsdfa_hip: {msg} (code {code})")
+        self.code = code
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C sdfa-2019_amd/csrc` "
+            "(or __graft_entry__.build()).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)      # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc):
+    if rc is not None and rc < 0:
+        code = int(rc)
+        msg = lib.sdfa_last_error().decode("utf-8", "replace")
+        if code == ESHORTCLIP:
+            raise AssertionError(msg)      # the reference raises AssertionError here (sliding_window.py:363)
+        raise SdfaError(code, msg)
+    return rc

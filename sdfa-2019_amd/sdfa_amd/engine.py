@@ -1,0 +1,151 @@
+"""Host-side engine over the C ABI: device buffers and streams come from PyTorch-ROCm (plumbing only);
+every arithmetic step of the hot path runs in libsdfa_hip.so."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check
+from .weights import fold_state_dict, head_of
+
+FPS = 60
+TS_DELTA_MS = 100
+FEAT_SHAPE = (64, 128, 3)
+
+
+def frame_geometry(sr):
+    """speech_anime/datasets/sliding_window.py:339-343 (window / hop given in seconds)."""
+    win, hop = int(0.064 * sr), int(0.008 * sr)
+    return win, hop, hop * 63 + win
+
+
+def frame_index(n_samples, sr, fps=FPS, ts_delta=TS_DELTA_MS):
+    """(starts int64[F], tslist int32[F]) -- bit-exact frame enumeration (C ABI sdfa_frame_index)."""
+    win, hop, _ = frame_geometry(sr)
+    n = check(lib.sdfa_frame_index(int(n_samples), int(sr), int(fps), win, hop, int(ts_delta), None, None, 0))
+    starts = np.empty(n, np.int64)
+    ts = np.empty(n, np.int32)
+    check(lib.sdfa_frame_index(int(n_samples), int(sr), int(fps), win, hop, int(ts_delta),
+                               starts.ctypes.data_as(C.c_void_p), ts.ctypes.data_as(C.c_void_p), n))
+    return starts, ts
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class Engine:
+    """One model replica on one GPU."""
+
+    def __init__(self, state_dict, device="cuda:0", max_frames=8192, debug_keep=False):
+        if not torch.cuda.is_available():
+            raise RuntimeError("sdfa_amd.Engine needs a ROCm GPU: the hot path has no CPU implementation")
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        folded = fold_state_dict(state_dict)
+        self.head = head_of(state_dict)
+        self._m = lib.sdfa_model_create(_lib.HEAD_DGRAD if self.head == "dgrad" else _lib.HEAD_OFFSETS)
+        if not self._m:
+            raise _lib.SdfaError(-1, lib.sdfa_last_error().decode())
+        for name, arr in folded.items():
+            check(lib.sdfa_model_set_tensor(self._m, name.encode(), arr.ctypes.data_as(C.c_void_p), arr.size))
+        if debug_keep:
+            check(lib.sdfa_debug_keep_intermediates(self._m, 1))
+        check(lib.sdfa_model_finalize(self._m, _stream()))
+        self.out_dim = int(lib.sdfa_model_out_dim(self._m))
+        self.coef_dim = int(lib.sdfa_model_coef_dim(self._m))
+        self.max_frames = int(max_frames)
+        self._ws = None
+
+    def __del__(self):
+        m, self._m = getattr(self, "_m", None), None
+        if m:
+            lib.sdfa_model_destroy(m)
+
+    # ------------------------------------------------------------------ workspace
+    def workspace(self, n_frames):
+        need = check(lib.sdfa_workspace_bytes(self._m, min(int(n_frames), self.max_frames)))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    # ------------------------------------------------------------------ front end
+    def mel_frontend(self, clips, sr):
+        """clips: list of 1-D float32 arrays/tensors in [-1,1].  Returns (audio_feat (F_total,64,128,3) cuda,
+        per-clip tslists, per-clip frame counts)."""
+        _, _, sliding = frame_geometry(sr)
+        offs, lens, fclip, fstart, tslists, counts = [], [], [], [], [], []
+        pos = 0
+        for ci, c in enumerate(clips):
+            n = int(c.shape[0])
+            starts, ts = frame_index(n, sr)
+            offs.append(pos); lens.append(n); pos += n
+            fclip.append(np.full(len(starts), ci, np.int32)); fstart.append(starts)
+            tslists.append([int(t) for t in ts]); counts.append(len(starts))
+        dev = self.device
+        pcm = torch.cat([torch.as_tensor(c, dtype=torch.float32).reshape(-1) for c in clips]).to(dev, non_blocking=True)
+        d_off = torch.tensor(offs, dtype=torch.int64, device=dev)
+        d_len = torch.tensor(lens, dtype=torch.int64, device=dev)
+        d_fc = torch.from_numpy(np.concatenate(fclip)).to(dev)
+        d_fs = torch.from_numpy(np.concatenate(fstart)).to(dev)
+        feat = self.mel_frontend_device(pcm, d_off, d_len, d_fc, d_fs, sr)
+        return feat, tslists, counts
+
+    def mel_frontend_device(self, pcm, clip_off, clip_len, frame_clip, frame_start, sr, out=None):
+        F = int(frame_clip.numel())
+        if out is None:
+            out = torch.empty((F,) + FEAT_SHAPE, dtype=torch.float32, device=self.device)
+        check(lib.sdfa_mel_frontend(_ptr(pcm), _ptr(clip_off), _ptr(clip_len), int(clip_off.numel()), _ptr(frame_clip),
+                                    _ptr(frame_start), F, int(sr), _ptr(out), _stream()))
+        return out
+
+    # ------------------------------------------------------------------ model
+    def encoder(self, audio_feat, want_align=True):
+        assert audio_feat.is_cuda and audio_feat.dtype == torch.float32 and tuple(audio_feat.shape[1:]) == FEAT_SHAPE
+        audio_feat = audio_feat.contiguous()
+        n = audio_feat.shape[0]
+        z = torch.empty((n, 512), dtype=torch.float32, device=self.device)
+        align = torch.empty((n, 64), dtype=torch.float32, device=self.device) if want_align else None
+        ws = self.workspace(n)
+        check(lib.sdfa_encoder_forward(self._m, _ptr(audio_feat), n, _ptr(z), _ptr(align), _ptr(ws), ws.numel(), _stream()))
+        return z, align
+
+    def regress(self, z, speaker_id, want_coef=False, want_out=True, out=None):
+        n = z.shape[0]
+        z = z.contiguous()
+        spk = speaker_id.to(device=self.device, dtype=torch.int64).contiguous()
+        assert spk.numel() == n
+        coef = torch.empty((n, self.coef_dim), dtype=torch.float32, device=self.device) if want_coef else None
+        if want_out and out is None:
+            out = torch.empty((n, self.out_dim), dtype=torch.float32, device=self.device)
+        ws = self.workspace(n)
+        check(lib.sdfa_regress_forward(self._m, _ptr(z), _ptr(spk), n, _ptr(coef), _ptr(out) if want_out else None,
+                                       _ptr(ws), ws.numel(), _stream()))
+        return coef, out
+
+    def forward(self, audio_feat, speaker_id, want_coef=False):
+        z, align = self.encoder(audio_feat)
+        coef, out = self.regress(z, speaker_id, want_coef=want_coef)
+        return out, z, align, coef
+
+    def tap(self, what, n_frames):
+        shapes = {0: (32, 64, 64), 1: (64, 32, 64), 2: (256, 64), 3: (64, 512)}
+        dst = torch.empty((n_frames,) + shapes[what], dtype=torch.float32, device=self.device)
+        check(lib.sdfa_debug_tap(self._m, what, n_frames, _ptr(dst), _ptr(self._ws), _stream()))
+        return dst
+
+    # ------------------------------------------------------------------ profiling
+    def profile(self, on=True):
+        check(lib.sdfa_profile_enable(self._m, 1 if on else 0))
+
+    def profile_ms(self, stage):
+        v = lib.sdfa_profile_ms(self._m, stage.encode())
+        if v < 0:
+            check(int(v))
+        return float(v)

@@ -1,0 +1,153 @@
+"""GPU parity: the HIP path (through the C ABI) against the reference-generated golden fixtures and
+against the CPU oracle on the same seeded inputs.  Tolerances: 1e-4 abs on fp32 dgrad (BASELINE.json
+north_star), bit-exact on frame indexing."""
+import numpy as np
+import pytest
+import torch
+
+import sdfa_oracle as O
+from sdfa_amd import synth
+from sdfa_amd.engine import Engine
+
+pytestmark = pytest.mark.gpu
+
+TOL_FEAT = 5e-5     # audio_feat in [0,1]
+TOL_ACT = 1e-4
+TOL_DGRAD = 1e-4    # north_star
+
+
+@pytest.fixture(scope="module")
+def eng(synth_sd):
+    return Engine(synth_sd["dgrad"], debug_keep=True)
+
+
+@pytest.fixture(scope="module")
+def eng_off(synth_sd):
+    return Engine(synth_sd["offsets"])
+
+
+def _t(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+@pytest.mark.parametrize("sr", [8000, 16000])
+@pytest.mark.parametrize("kind,clip", [("uniform", 0), ("zeros", 1), ("sweep", 2), ("speechlike", 3)])
+def test_frontend_vs_reference_fixture(eng, golden, sr, kind, clip):
+    g = golden["frontend"]
+    pre = f"sr{sr}_{kind}_"
+    pcm = synth.make_pcm(clip, 2 * sr, kind)
+    feat, tslists, counts = eng.mel_frontend([pcm], sr)
+    feat = feat.cpu().numpy()
+    assert np.array_equal(np.asarray(tslists[0]), g[pre + "tslist"])          # bit-exact indexing
+    assert list(feat.shape) == list(g[pre + "shape"])
+    keep = g[pre + "frames"]
+    err = np.abs(feat[keep] - g[pre + "audio_feat"]).max()
+    assert err <= TOL_FEAT, err
+    s = feat.astype(np.float64).sum(axis=(1, 2, 3))
+    assert np.abs(s - g[pre + "frame_sum"]).max() <= 64 * 128 * 3 * 5e-6
+    if kind == "zeros":
+        assert not feat.any()
+
+
+def test_frontend_multi_clip_ragged_vs_oracle(eng):
+    sr = 16000
+    clips = [synth.make_pcm(10, 9088), synth.make_pcm(11, 20011, "speechlike"), synth.make_pcm(12, 16000, "sweep")]
+    feat, tslists, counts = eng.mel_frontend(clips, sr)
+    feat = feat.cpu().numpy()
+    pos = 0
+    for c, ts, n in zip(clips, tslists, counts):
+        ref = O.fetch_audio_features(c, sr)
+        assert ts == ref["tslist"] and n == len(ref["tslist"])
+        assert np.abs(feat[pos:pos + n] - ref["audio_feat"]).max() <= TOL_FEAT
+        pos += n
+    assert pos == feat.shape[0]
+
+
+def test_model_stages_vs_reference_fixture(eng, golden):
+    g = golden["model_dgrad"]
+    x = _t(g["audio_feat"])
+    n = x.shape[0]
+    spk = torch.full((n,), int(g["speaker"]), dtype=torch.int64)
+    out, z, align, coef = eng.forward(x, spk, want_coef=True)
+    pool1 = eng.tap(0, n).cpu().numpy(); conv3 = eng.tap(1, n).cpu().numpy()
+    freq = eng.tap(2, n).cpu().numpy(); bil = eng.tap(3, n).cpu().numpy()
+    assert np.abs(pool1[:2] - g["pool1_f01"]).max() <= TOL_ACT
+    assert np.abs(conv3[:2] - g["conv3_f01"]).max() <= TOL_ACT
+    assert np.abs(freq - g["freq"][:, :, 0, :]).max() <= TOL_ACT
+    assert np.abs(bil - g["bilstm"]).max() <= TOL_ACT
+    align = align.cpu().numpy(); z = z.cpu().numpy(); coef = coef.cpu().numpy(); out = out.cpu().numpy()
+    assert np.abs(align - g["align"][:, 0]).max() <= 1e-5
+    assert np.abs(align.sum(1) - 1).max() <= 1e-5
+    assert np.abs(z - g["z"][:, 0]).max() <= TOL_ACT
+    assert np.abs(coef[:, :85] - g["coef_scale"][:, 0]).max() <= TOL_ACT
+    assert np.abs(coef[:, 85:] - g["coef_rotat"][:, 0]).max() <= TOL_ACT
+    assert out.shape == (n, 89784)
+    assert np.abs(out[:2] - g["dgrad_f01"]).max() <= TOL_DGRAD
+    assert np.abs(out[:, ::97] - g["dgrad_stride97"]).max() <= TOL_DGRAD
+    assert np.abs(out.astype(np.float64).sum(1) - g["dgrad_sum"]).max() <= 89784 * 2e-6
+
+
+def test_second_speaker(eng, golden):
+    g = golden["model_dgrad"]; g5 = golden["model_dgrad_spk5"]
+    x = _t(g["audio_feat"][:3])
+    out, z, align, coef = eng.forward(x, torch.full((3,), 5, dtype=torch.int64), want_coef=True)
+    assert np.abs(coef.cpu().numpy()[:, :85] - g5["coef_scale"][:, 0]).max() <= TOL_ACT
+    assert np.abs(out.cpu().numpy()[:, ::97] - g5["dgrad_stride97"]).max() <= TOL_DGRAD
+
+
+def test_mixed_speakers_in_one_batch(eng, golden):
+    g = golden["model_dgrad"]; g5 = golden["model_dgrad_spk5"]
+    x = _t(g["audio_feat"][:3])
+    out, *_ = eng.forward(x, torch.tensor([2, 5, 2], dtype=torch.int64))
+    out = out.cpu().numpy()
+    assert np.abs(out[0, ::97] - g["dgrad_stride97"][0]).max() <= TOL_DGRAD
+    assert np.abs(out[1, ::97] - g5["dgrad_stride97"][1]).max() <= TOL_DGRAD
+
+
+def test_offsets_head(eng_off, golden):
+    g = golden["model_offsets"]; gm = golden["model_dgrad"]
+    x = _t(gm["audio_feat"][:4])
+    out, z, align, coef = eng_off.forward(x, torch.full((4,), 2, dtype=torch.int64), want_coef=True)
+    out = out.cpu().numpy()
+    assert out.shape == (4, 15069)
+    assert np.abs(coef.cpu().numpy() - g["coef"][:, 0]).max() <= TOL_ACT
+    assert np.abs(out[0] - g["offsets_f0"]).max() <= TOL_DGRAD
+    assert np.abs(out[:, ::7] - g["offsets_stride7"]).max() <= TOL_DGRAD
+
+
+@pytest.mark.parametrize("sr", [8000, 16000])
+def test_end_to_end_vs_reference_fixture(eng, golden, sr):
+    g = golden["e2e_dgrad"]
+    feat, tslists, counts = eng.mel_frontend([synth.make_pcm(0, 2 * sr)], sr)
+    out, *_ = eng.forward(feat, torch.full((feat.shape[0],), 2, dtype=torch.int64))
+    out = out.cpu().numpy().reshape(feat.shape[0], 9976, 9)
+    assert np.array_equal(np.asarray(tslists[0]), g[f"sr{sr}_tslist"])
+    assert list(out.shape) == list(g[f"sr{sr}_shape"])
+    assert np.abs(out[:, ::97] - g[f"sr{sr}_stride97"]).max() <= TOL_DGRAD
+    assert np.abs(out[10] - g[f"sr{sr}_frame10"]).max() <= TOL_DGRAD
+
+
+def test_batch_vs_oracle_ragged_sizes(eng, synth_sd):
+    """Sizes that are not multiples of any tile (1, 129, 300 frames) against the CPU oracle."""
+    orc = O.Oracle(synth_sd["dgrad"], "dgrad")
+    rs = np.random.RandomState(3)
+    for n in (1, 129, 300):
+        x = rs.uniform(0, 1, (n, 64, 128, 3)).astype(np.float32)
+        x[:, :, :, 1:] = (x[:, :, :, 1:] - 0.5) * 0.1
+        spk = rs.randint(0, 8, n)
+        ref, zr, ar = orc.forward(x, spk)
+        out, z, align, _ = eng.forward(_t(x), torch.from_numpy(spk))
+        assert np.abs(out.cpu().numpy() - ref).max() <= TOL_DGRAD, n
+        assert np.abs(align.cpu().numpy() - ar).max() <= 1e-5
+
+
+def test_chunked_equals_unchunked(synth_sd, golden):
+    """A workspace that forces 128-frame chunks gives the same bits as one big chunk."""
+    rs = np.random.RandomState(4)
+    x = _t(rs.uniform(0, 1, (300, 64, 128, 3)).astype(np.float32))
+    spk = torch.full((300,), 3, dtype=torch.int64)
+    a = Engine(synth_sd["dgrad"], max_frames=128)
+    b = Engine(synth_sd["dgrad"], max_frames=4096)
+    oa, *_ = a.forward(x, spk)
+    ob, *_ = b.forward(x, spk)
+    assert torch.equal(oa, ob)
