@@ -6,6 +6,11 @@ module raises.  The product path never routes through a CPU implementation.
 import ctypes as C
 import os
 
+# PyTorch-ROCm bundles its own libamdhip64.so.7.  Streams and device pointers handed across the C ABI
+# come from that runtime, so it must be the one libsdfa_hip.so binds to: load torch first (same SONAME,
+# the dynamic loader then reuses the copy already in the process).
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SDFA_HIP_LIB", os.path.join(_HERE, "libsdfa_hip.so"))
 
