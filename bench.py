@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Headline benchmark: animation frames/s for batches of 10 s @ 16 kHz clips (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+One "step" = one pass of the whole hot path over one batch of synthetic PCM that is already resident
+in HBM: frame windows -> mel/delta front end -> conv + freq-LSTM + BiLSTM + attention encoder -> MLPs + PCA
+expansion -> interleaved dgrad rows (F, 89784) in HBM.  Per GPU the batch is 32 clips x 10 s @ 16 kHz
+(20,352 animation frames); with N GPUs every rank takes its own 32 clips (weak scaling) and the per-frame
+dgrad rows of all ranks are reassembled on every rank with an RCCL all-gather issued chunk by chunk so that
+it overlaps the next chunk's compute (inside the timed region).
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fused frequency-LSTM recurrence,
+fp32 MFMA), measured live with HIP events on the launch stream; `cpu_baseline` times the CPU oracle
+(oracle/sdfa_oracle.py, a numpy port of the reference path) on a bounded sample on rank 0 at N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "sdfa-2019_amd"))
+
+FLOP_FREQ_LSTM_PER_FRAME = 64 * 32 * 2 * 512 * (64 + 128) * 2      # 268.4 + 536.9 MFLOP
+FLOP_MODEL_PER_FRAME = 1.514e9
+FRONTEND_BYTES_PER_FRAME = 4 * 16000 / 60 + 64 * 128 * 3 * 4         # new PCM + feature write = 99.4 KB
+PEAK_FP32_MFMA_TFLOPS = 157.3                                        # MI355X_MICROARCH.md chip table
+PEAK_HBM_GBPS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--clips-per-gpu", type=int, default=32)
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--sample-rate", type=int, default=16000)
+    ap.add_argument("--chunk", type=int, default=8192, help="frames per encoder launch group")
+    ap.add_argument("--gather", choices=["dgrad", "coef", "none"], default="dgrad")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-seconds", type=float, default=2.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(sr, seconds, eng, state_dict):
+    """Oracle (numpy port of the reference path) timed on one short clip; also the dgrad parity number."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import sdfa_oracle as O
+    from sdfa_amd import synth
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    pcm = synth.make_pcm(0, int(seconds * sr))
+    orc = O.Oracle(state_dict, "dgrad")
+    t0 = time.perf_counter()
+    ts, ref = O.generate_animation(orc, pcm, sr, 2)
+    dt = time.perf_counter() - t0
+    feat, tslists, counts = eng.mel_frontend([pcm], sr)
+    out, *_ = eng.forward(feat, torch.full((feat.shape[0],), 2, dtype=torch.int64))
+    err = float(np.abs(out.cpu().numpy() - ref.reshape(len(ref), -1)).max())
+    ts_equal = bool(tslists[0] == list(ts))
+    return dict(value=round(len(ref) / dt, 2), unit="frames/s", cores=int(cores), kind="port",
+                sample=f"1 clip x {seconds:g} s @ {sr} Hz = {len(ref)} frames, oracle/sdfa_oracle.py (numpy fp32), {dt:.1f} s"), err, ts_equal
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from sdfa_amd import synth, dist as sdist
+    from sdfa_amd.engine import Engine, frame_index
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    sr, L = a.sample_rate, int(a.seconds * a.sample_rate)
+    sd = synth.make_state_dict("dgrad", 1234)
+    eng = Engine(sd, device=dev, max_frames=a.chunk)
+
+    # ---- this rank's clips: global clip ids [rank*C, (rank+1)*C), PCM resident in HBM before timing
+    C = a.clips_per_gpu
+    starts, ts = frame_index(L, sr)
+    F_clip = len(starts)
+    F = C * F_clip
+    pcm = torch.from_numpy(np.concatenate([synth.make_pcm(rank * C + c, L) for c in range(C)])).to(dev)
+    clip_off = torch.arange(C, dtype=torch.int64, device=dev) * L
+    clip_len = torch.full((C,), L, dtype=torch.int64, device=dev)
+    frame_clip = torch.arange(C, dtype=torch.int32, device=dev).repeat_interleave(F_clip)
+    frame_start = torch.from_numpy(np.tile(starts, C)).to(dev)
+    spk = torch.full((F,), 2, dtype=torch.int64, device=dev)          # speaker "m1"
+    feat = torch.empty((F, 64, 128, 3), dtype=torch.float32, device=dev)
+    width = eng.out_dim if a.gather != "coef" else eng.coef_dim
+    gatherer = None
+    if world > 1 and a.gather != "none":
+        gatherer = sdist.FrameGatherer([F] * world, width, torch.float32, dev)
+    out = torch.empty((F, eng.out_dim), dtype=torch.float32, device=dev)
+
+    def step():
+        eng.mel_frontend_device(pcm, clip_off, clip_len, frame_clip, frame_start, sr, out=feat)
+        for f0 in range(0, F, a.chunk):
+            f1 = min(F, f0 + a.chunk)
+            z, _ = eng.encoder(feat[f0:f1], want_align=False)
+            coef, o = eng.regress(z, spk[f0:f1], want_coef=(a.gather == "coef"), out=out[f0:f1])
+            if gatherer is not None:
+                gatherer.gather_chunk(o if a.gather == "dgrad" else coef, f0, a.chunk)
+        if gatherer is not None:
+            gatherer.finish()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    eng.profile(True)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fe_ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # ---- per-kernel device times (HIP events recorded on the launch stream inside the timed region)
+    n_chunks = (F + a.chunk - 1) // a.chunk
+    stages = {}
+    for st in ("conv1", "conv23", "freq_lstm", "freq_proj", "gx0", "lstm0", "gx1", "lstm1", "attn_proj", "attn", "mlp", "pca"):
+        stages[st] = eng.profile_ms(st) / a.steps
+    eng.profile(False)
+    # front end: timed separately (same stream, HIP events), outside the headline region
+    ev0.record(); eng.mel_frontend_device(pcm, clip_off, clip_len, frame_clip, frame_start, sr, out=feat); ev1.record()
+    torch.cuda.synchronize()
+    fe_ms = ev0.elapsed_time(ev1)
+    stages["frontend"] = fe_ms
+
+    if rank == 0:
+        frames_total = F * world * a.steps
+        value = frames_total / dt
+        lstm_ms_per_launch = stages["freq_lstm"] / n_chunks
+        flop_per_launch = FLOP_FREQ_LSTM_PER_FRAME * (F / n_chunks)
+        achieved = flop_per_launch / (lstm_ms_per_launch * 1e-3) / 1e12
+        res = {
+            "metric": "animation frames/s/node (10 s@16 kHz clips); max|Δdgrad| vs CPU ref",
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"batch={C} x {a.seconds:g} s@{sr} Hz synthetic PCM per GPU -> dgrad (BASELINE configs[1])",
+                       "clips_per_gpu": C, "frames_per_gpu": F, "head": "dgrad", "chunk_frames": a.chunk,
+                       "gather": a.gather if world > 1 else "none (1 GPU)", "weights": "synthetic seed 1234"},
+            "roofline": {"kernel": "freq_lstm_kernel", "bound": "mfma", "achieved": round(achieved, 2),
+                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "traffic": None, "launch_ms": round(lstm_ms_per_launch, 3),
+                         "flop_per_launch": flop_per_launch},
+            "model_tflops": round(value / world * FLOP_MODEL_PER_FRAME / 1e12, 2),
+            "model_frac_of_fp32_mfma_peak": round(value / world * FLOP_MODEL_PER_FRAME / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+            "frontend": {"ms": round(fe_ms, 3), "frames_per_s": round(F / (fe_ms * 1e-3), 1),
+                         "hbm_gbps_algorithmic": round(F * FRONTEND_BYTES_PER_FRAME / (fe_ms * 1e-3) / 1e9, 1),
+                         "frac_of_hbm_peak": round(F * FRONTEND_BYTES_PER_FRAME / (fe_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)},
+            "stage_ms_per_step": {k: round(v, 3) for k, v in stages.items()},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            cb, err, ts_ok = cpu_baseline(sr, a.cpu_sample_seconds, eng, sd)
+            res["cpu_baseline"] = cb
+            res["max_abs_dgrad_err_vs_cpu_ref"] = err
+            res["tslist_bit_exact"] = ts_ok
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,67 @@
+"""world_size-2 gloo test of the N>1 path's sharding and chunked all-gather bookkeeping (CPU tensors)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n_clips, frames_per_clip, width, chunk, q):
+    import sys
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(here, "sdfa-2019_amd"))
+    from sdfa_amd import dist as sd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = sd.shard_range(n_clips, rank, world)
+    # stand-in for the per-frame output: row value encodes (global clip, frame-in-clip, column)
+    rows = []
+    for c in range(lo, hi):
+        for f in range(frames_per_clip[c]):
+            rows.append(c * 1000.0 + f + np.arange(width) * 1e-3)
+    local = torch.tensor(np.asarray(rows, np.float32).reshape(-1, width))
+    counts = sd.frame_counts_all(local.shape[0])
+    g = sd.FrameGatherer(counts, width, torch.float32, "cpu")
+    for i in range(g.n_chunks(chunk)):
+        f0 = i * chunk
+        g.gather_chunk(local[f0:f0 + chunk], f0, chunk)
+    out = g.finish()
+    q.put((rank, counts, out.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("frames_per_clip", [[5, 5, 5, 5], [3, 9, 4, 1, 7]])
+def test_sharded_gather_reassembles_clip_order(frames_per_clip):
+    world, width, chunk = 2, 6, 4
+    n_clips = len(frames_per_clip)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_clips, frames_per_clip, width, chunk, q)) for r in range(world)]
+    for p in procs: p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs: p.join(timeout=60)
+    expect = np.asarray([c * 1000.0 + f + np.arange(width) * 1e-3 for c in range(n_clips) for f in range(frames_per_clip[c])], np.float32)
+    for rank, counts, out in res:
+        assert sum(counts) == len(expect)
+        assert np.array_equal(out, expect), rank
+
+
+def test_shard_range_partitions():
+    import sys
+    from sdfa_amd.dist import shard_range
+    for n in (0, 1, 7, 32, 256, 257):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
