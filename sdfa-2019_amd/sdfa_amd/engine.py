@@ -39,14 +39,50 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-class Engine:
+class FrontendOnly:
+    """The spectral-gather front end alone (needs no weights)."""
+
+    def __init__(self, device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("sdfa_amd needs a ROCm GPU: the hot path has no CPU implementation")
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+
+    # ------------------------------------------------------------------ front end
+    def mel_frontend(self, clips, sr):
+        """clips: list of 1-D float32 arrays/tensors in [-1,1].  Returns (audio_feat (F_total,64,128,3) cuda,
+        per-clip tslists, per-clip frame counts)."""
+        offs, lens, fclip, fstart, tslists, counts = [], [], [], [], [], []
+        pos = 0
+        for ci, c in enumerate(clips):
+            n = int(c.shape[0])
+            starts, ts = frame_index(n, sr)
+            offs.append(pos); lens.append(n); pos += n
+            fclip.append(np.full(len(starts), ci, np.int32)); fstart.append(starts)
+            tslists.append([int(t) for t in ts]); counts.append(len(starts))
+        dev = self.device
+        pcm = torch.cat([torch.as_tensor(c, dtype=torch.float32).reshape(-1) for c in clips]).to(dev, non_blocking=True)
+        d_off = torch.tensor(offs, dtype=torch.int64, device=dev)
+        d_len = torch.tensor(lens, dtype=torch.int64, device=dev)
+        d_fc = torch.from_numpy(np.concatenate(fclip)).to(dev)
+        d_fs = torch.from_numpy(np.concatenate(fstart)).to(dev)
+        feat = self.mel_frontend_device(pcm, d_off, d_len, d_fc, d_fs, sr)
+        return feat, tslists, counts
+
+    def mel_frontend_device(self, pcm, clip_off, clip_len, frame_clip, frame_start, sr, out=None):
+        F = int(frame_clip.numel())
+        if out is None:
+            out = torch.empty((F,) + FEAT_SHAPE, dtype=torch.float32, device=self.device)
+        check(lib.sdfa_mel_frontend(_ptr(pcm), _ptr(clip_off), _ptr(clip_len), int(clip_off.numel()), _ptr(frame_clip),
+                                    _ptr(frame_start), F, int(sr), _ptr(out), _stream()))
+        return out
+
+
+class Engine(FrontendOnly):
     """One model replica on one GPU."""
 
     def __init__(self, state_dict, device="cuda:0", max_frames=8192, debug_keep=False):
-        if not torch.cuda.is_available():
-            raise RuntimeError("sdfa_amd.Engine needs a ROCm GPU: the hot path has no CPU implementation")
-        self.device = torch.device(device)
-        torch.cuda.set_device(self.device)
+        super().__init__(device)
         folded = fold_state_dict(state_dict)
         self.head = head_of(state_dict)
         self._m = lib.sdfa_model_create(_lib.HEAD_DGRAD if self.head == "dgrad" else _lib.HEAD_OFFSETS)
@@ -74,36 +110,6 @@ class Engine:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
-
-    # ------------------------------------------------------------------ front end
-    def mel_frontend(self, clips, sr):
-        """clips: list of 1-D float32 arrays/tensors in [-1,1].  Returns (audio_feat (F_total,64,128,3) cuda,
-        per-clip tslists, per-clip frame counts)."""
-        _, _, sliding = frame_geometry(sr)
-        offs, lens, fclip, fstart, tslists, counts = [], [], [], [], [], []
-        pos = 0
-        for ci, c in enumerate(clips):
-            n = int(c.shape[0])
-            starts, ts = frame_index(n, sr)
-            offs.append(pos); lens.append(n); pos += n
-            fclip.append(np.full(len(starts), ci, np.int32)); fstart.append(starts)
-            tslists.append([int(t) for t in ts]); counts.append(len(starts))
-        dev = self.device
-        pcm = torch.cat([torch.as_tensor(c, dtype=torch.float32).reshape(-1) for c in clips]).to(dev, non_blocking=True)
-        d_off = torch.tensor(offs, dtype=torch.int64, device=dev)
-        d_len = torch.tensor(lens, dtype=torch.int64, device=dev)
-        d_fc = torch.from_numpy(np.concatenate(fclip)).to(dev)
-        d_fs = torch.from_numpy(np.concatenate(fstart)).to(dev)
-        feat = self.mel_frontend_device(pcm, d_off, d_len, d_fc, d_fs, sr)
-        return feat, tslists, counts
-
-    def mel_frontend_device(self, pcm, clip_off, clip_len, frame_clip, frame_start, sr, out=None):
-        F = int(frame_clip.numel())
-        if out is None:
-            out = torch.empty((F,) + FEAT_SHAPE, dtype=torch.float32, device=self.device)
-        check(lib.sdfa_mel_frontend(_ptr(pcm), _ptr(clip_off), _ptr(clip_len), int(clip_off.numel()), _ptr(frame_clip),
-                                    _ptr(frame_start), F, int(sr), _ptr(out), _stream()))
-        return out
 
     # ------------------------------------------------------------------ model
     def encoder(self, audio_feat, want_align=True):

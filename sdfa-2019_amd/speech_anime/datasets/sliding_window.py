@@ -1,0 +1,76 @@
+"""DatasetSlidingWindow -- the inference half of speech_anime/datasets/sliding_window.py (fetch_audio_features and
+the unit converters of speech_anime/datasets/speech_anime.py:128-164).  The training data loader is out of scope."""
+import numpy as np
+import torch
+
+from sdfa_amd import engine as _engine
+
+
+class DatasetSlidingWindow:
+    hparams = None
+    _engine = None          # set by SaberSpeechDrivenAnimation; a bare front-end engine is created on demand
+
+    # ---- units: same float32 roundings as the reference (speech_anime.py:128-164)
+    @classmethod
+    def ms_to_sample(cls, ms, sr=None, dtype=np.float32):
+        sr = sr or cls.hparams.audio.sample_rate
+        return dtype(float(ms * sr) / 1000.0)
+
+    @classmethod
+    def sample_to_ms(cls, sample, sr=None, dtype=np.float32):
+        sr = sr or cls.hparams.audio.sample_rate
+        return dtype(float(sample * 1000.0) / float(sr))
+
+    @classmethod
+    def frame_to_sample(cls, idx, sr=None, fps=None, dtype=np.float32):
+        sr = sr or cls.hparams.audio.sample_rate
+        fps = fps or cls.hparams.anime.fps
+        return dtype(float(idx * sr) / float(fps))
+
+    @classmethod
+    def sample_to_frame(cls, sample, sr=None, fps=None, dtype=np.float32):
+        sr = sr or cls.hparams.audio.sample_rate
+        fps = fps or cls.hparams.anime.fps
+        return dtype(float(sample * fps) / float(sr))
+
+    @classmethod
+    def frame_in_range(cls, frame_idx, sliding_size, start, end):
+        return start + cls.frame_to_sample(frame_idx) + sliding_size <= end
+
+    # ---- hot path
+    @classmethod
+    def fetch_audio_features(cls, signal, hparams=None, as_numpy=True):
+        """sliding_window.py:324-377: dict(tslist, energy (F,1,64), audio_feat (F,64,128,3)).
+
+        `as_numpy=False` keeps audio_feat on the GPU (the reference always returns numpy)."""
+        if hparams is not None and cls.hparams is None:
+            cls.hparams = hparams
+        hp = cls.hparams
+        if torch.is_tensor(signal):
+            signal = signal.detach().cpu().numpy()
+        signal = np.asarray(signal, np.float32).reshape(-1)
+        assert -1.0 <= signal.min() and signal.max() <= 1.0                      # :330
+        sr = hp.audio.sample_rate
+        fe = cls._frontend_engine()
+        feat, tslists, _ = fe.mel_frontend([signal], sr)
+        energy = cls._energy(signal, sr)
+        return dict(tslist=tslists[0], energy=energy,
+                    audio_feat=feat.cpu().numpy() if as_numpy else feat)
+
+    @classmethod
+    def _frontend_engine(cls):
+        if cls._engine is None:
+            cls._engine = _engine.FrontendOnly()
+        return cls._engine
+
+    @staticmethod
+    def _energy(signal, sr):
+        """librosa.feature.rms(frame_length=win, hop_length=hop, center=False) per window (sliding_window.py:365).
+        Carried in the result for interface parity; no model consumes it (model.py:443,487)."""
+        win, hop, sliding = _engine.frame_geometry(sr)
+        starts, _ = _engine.frame_index(len(signal), sr)
+        L = len(signal)
+        csum = np.concatenate([[0.0], np.cumsum(signal.astype(np.float64) ** 2)])
+        a = starts[:, None] + hop * np.arange(64)[None, :]
+        lo, hi = np.clip(a, 0, L), np.clip(a + win, 0, L)
+        return np.sqrt((csum[hi] - csum[lo]) / win).astype(np.float32)[:, None, :]

@@ -1,0 +1,192 @@
+"""SpeechDrivenAnimation / SaberSpeechDrivenAnimation -- inference surface of speech_anime/model/model.py.
+
+Same method names, arguments and result layouts as the reference; the arithmetic is libsdfa_hip.so.
+Not mirrored (out of scope): training (train_step/get_loss), TensorBoard hooks, video rendering and
+the dgrad -> mesh solve (evaluate() writes the dgrad track instead of .obj files / a video).
+"""
+import os
+from copy import deepcopy
+
+import numpy as np
+import torch
+
+from sdfa_amd.engine import Engine
+from sdfa_amd import weights as _weights
+from ..datasets import DatasetSlidingWindow
+from .. import audio as _audio
+from .. import stream as _stream
+
+
+class SpeechDrivenAnimation:
+    """audio_feat -> anime_feat model (model.py:18-45)."""
+
+    def __init__(self, hparams, load_pca=False):
+        self.hp = hparams
+        self._face_type = hparams.model.face_data_type
+        self._engine = None
+
+    def load_state_dict(self, state_dict, strict=True):
+        head = _weights.head_of(state_dict)
+        want = "dgrad" if self._face_type == "dgrad_3d" else "offsets"
+        if head != want:
+            raise RuntimeError(f"checkpoint holds a '{head}' output module but hparams.model.face_data_type = {self._face_type}")
+        self._engine = Engine(state_dict, device=self.hp.get("device", "cuda:0") or "cuda:0")
+        return self
+
+    def eval(self):
+        return self
+
+    def __call__(self, *a, **k):
+        return self.forward(*a, **k)
+
+    @torch.no_grad()
+    def forward(self, audio_feat, speaker_id, align_dict=None, latent_dict=None):
+        """(N,64,128,3) f32, (N,) int64 -> ((scale (N,1,9976,6), rotat (N,1,9976,3)), z_audio (N,1,512)); offsets head:
+        (pred (N,1,15069), z_audio).  A dict `align_dict` receives {"audio_encoder10": (N,1,64)} (layers/__init__.py:98-99)."""
+        if self._engine is None:
+            raise RuntimeError("no weights loaded: call load_state_dict first")
+        eng = self._engine
+        x = audio_feat.to(device=eng.device, dtype=torch.float32)
+        n = x.shape[0]
+        z, align = eng.encoder(x, want_align=isinstance(align_dict, dict))
+        if isinstance(align_dict, dict):
+            align_dict["audio_encoder10"] = align.view(n, 1, 64)
+        _, out = eng.regress(z, speaker_id)
+        z_audio = z.view(n, 1, 512)
+        if self._face_type == "dgrad_3d":
+            tri = out.view(n, 1, -1, 9)
+            return (tri[..., :6], tri[..., 6:]), z_audio      # views into the interleaved [6 | 3] rows
+        return out.view(n, 1, -1), z_audio
+
+
+class SaberSpeechDrivenAnimation:
+    """Handles evaluation (model.py:48-489, inference half)."""
+
+    def __init__(self, hparams, trainset=None, validset=None, load_pca=True):
+        self.hp = hparams
+        self.trainset, self.validset = trainset, validset
+        self._model = SpeechDrivenAnimation(hparams, load_pca)
+        self._face_type = hparams.model.face_data_type
+        self._pred_type = hparams.model.prediction_type
+        self._speakers_dict = deepcopy(dict(hparams.dataset_anime.speakers))
+        self._emotions_dict = deepcopy(dict(hparams.dataset_anime.emotions))
+        self.current_epoch = 0
+        self.on_gpu = True
+
+    # ---- weights ------------------------------------------------------------------------------
+    def load_state_dict(self, state_dict, strict=True):
+        self._model.load_state_dict(state_dict, strict)
+        DatasetSlidingWindow._engine = self._model._engine
+        return self
+
+    def eval(self):
+        return self
+
+    def __call__(self, batch):
+        return self.forward(batch)
+
+    # ---- model.py:79-107 ----------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, batch):
+        align_dict, latent_dict = dict(), dict()
+        preds, condition = self._model(batch["audio_feat"], batch["speaker_id"], align_dict=align_dict, latent_dict=latent_dict)
+        pred_dict = dict()
+        if self._face_type == "dgrad_3d":
+            assert len(preds) == 2
+            pred_dict["dgrad_3d_scale"], pred_dict["dgrad_3d_rotat"] = preds
+        else:
+            # the reference asserts len(preds) == 1 on a bare tensor here (only true for batch 1)
+            pred_dict[self._face_type] = preds
+        return dict(prediction=pred_dict, condition=condition, align_dict=align_dict, latent_dict=latent_dict)
+
+    # ---- model.py:225-259 ---------------------------------------------------------------------
+    def data_to_anime_feat(self, tensor_dict, is_prediction):
+        if self._face_type == "dgrad_3d":
+            scale, rotat = tensor_dict["dgrad_3d_scale"], tensor_dict["dgrad_3d_rotat"]
+            data = torch.cat((scale.reshape(*scale.shape[:-1], -1, 6), rotat.reshape(*rotat.shape[:-1], -1, 3)), dim=-1)
+            return data.reshape(*data.shape[:-2], -1)
+        return tensor_dict[self._face_type]
+
+    # ---- model.py:333-420 ---------------------------------------------------------------------
+    @torch.no_grad()
+    def generate_animation(self, signal, speaker, emotion, frame_id, ensembling_ms=None, dataset_class=None, **kwargs):
+        if torch.is_tensor(signal):
+            if signal.dim() > 1:
+                assert signal.dim() == 2
+                assert signal.size(0) == 1
+                signal = signal[0]
+            signal = signal.detach().cpu().numpy()
+        assert isinstance(signal, np.ndarray)
+        assert np.prod(signal.shape) == np.max(signal.shape)
+        assert signal.min() >= -1
+        assert signal.max() <= 1
+        signal = signal.flatten()
+        if dataset_class is None:
+            dataset_class = DatasetSlidingWindow
+        if isinstance(speaker, str):
+            speaker = self._speakers_dict[speaker]
+        if isinstance(emotion, str):
+            emotion = self._emotions_dict[emotion]
+        if ensembling_ms is None:
+            ensembling_ms = self.hp.ensembling_ms
+
+        passes = [signal]
+        if ensembling_ms is not None and ensembling_ms > 0:            # model.py:373-384: second pass on a delayed copy
+            pad = ensembling_ms * self.hp.audio.sample_rate // 1000
+            passes.append(np.pad(signal[:-pad], [[pad, 0]], "constant"))
+        feats = [dataset_class.fetch_audio_features(p, self.hp, as_numpy=False) for p in passes]
+        anime_sum, others = self._feature_to_anime(feats[0]["audio_feat"], feats[0]["energy"], speaker, emotion, frame_id,
+                                                   want_inputs=kwargs.get("want_inputs", True))
+        for f in feats[1:]:
+            anime_sum += self._feature_to_anime(f["audio_feat"], f["energy"], speaker, emotion, frame_id, want_inputs=False)[0]
+        return feats[0]["tslist"], anime_sum / float(len(feats)), others
+
+    # ---- model.py:428-489 ---------------------------------------------------------------------
+    @torch.no_grad()
+    def _feature_to_anime(self, feat_list, energy_list, speaker_id, emotion_id, frame_id, bs=100, want_inputs=True):
+        """`bs` is accepted for signature parity; frames are independent, so the engine batches by its own chunk size."""
+        assert isinstance(speaker_id, (int, np.integer)), f"given index is {speaker_id}, {type(speaker_id)}"
+        eng = self._model._engine
+        feat = feat_list if torch.is_tensor(feat_list) else torch.from_numpy(np.asarray(feat_list, np.float32))
+        feat = feat.to(eng.device)
+        n = feat.shape[0]
+        spk = torch.full((n,), int(speaker_id), dtype=torch.int64, device=eng.device)
+        res = self.forward({"audio_feat": feat, "speaker_id": spk})
+        animes = self.data_to_anime_feat(res["prediction"], is_prediction=True).squeeze(1)   # (n, 9976, 9) / (n, 15069)
+        animes = np.asarray(animes.cpu().numpy(), dtype=np.float32)
+        others = {"inputs": feat.permute(0, 3, 2, 1).cpu().numpy() if want_inputs else None,
+                  "phones": None, "latent": None, "latent_align": None, "formants": None}
+        return animes, others
+
+    # ---- model.py:121-223 (host loop; rendering / mesh export replaced by a dgrad track dump) ----
+    def evaluate(self, sources, experiment=None, in_trainer=False, **kwargs):
+        sr, fps = self.hp.audio.sample_rate, self.hp.anime.fps
+        output_dir = kwargs.get("output_dir") or "evaluate_results"
+        target_db = kwargs.get("audio_target_db", self.hp.dataset_anime.audio_target_db)
+        export_frames = kwargs.get("export_mesh_frames", not in_trainer)
+        results = []
+        for _, records in dict(sources).items():
+            for rec in records:
+                path = rec[0]
+                spk = "m1"
+                for extra in rec[1:]:
+                    if isinstance(extra, str) and extra.startswith("speaker="):
+                        spk = extra.split("=", 1)[1]
+                name = os.path.splitext(os.path.basename(path))[0]
+                signal = _audio.load_source(path, sr)
+                signal = _audio.rms_normalize(signal, target_db).astype(np.float32)            # model.py:165
+                tslist, animes, _ = self.generate_animation(signal=signal, speaker=spk, emotion=0, frame_id=0,
+                                                            dataset_class=DatasetSlidingWindow, want_inputs=False)
+                out_dir = os.path.join(output_dir, name)
+                os.makedirs(out_dir, exist_ok=True)
+                np.save(os.path.join(out_dir, "tslist.npy"), np.asarray(tslist, np.int64))
+                np.save(os.path.join(out_dir, f"{self._face_type}.npy"), animes)
+                if export_frames:                                                              # model.py:201-212
+                    max_frame = int(tslist[-1] * fps / 1000.0)
+                    for i_frame in range(max_frame + 1):
+                        data_frame = _stream.seek(i_frame * 1000.0 / fps, tslist, animes)
+                        np.save(os.path.join(out_dir, f"{i_frame:06d}_dgrad.npy"), data_frame)
+                print(f"[speech_anime] {name}: {len(tslist)} animation frames -> {out_dir} "
+                      "(mesh solve and video rendering are outside this path)")
+                results.append((path, tslist, animes))
+        return results

@@ -1,0 +1,65 @@
+"""Host logic of the speech_anime drop-in surface that needs no GPU."""
+import json
+
+import numpy as np
+import pytest
+
+import librosa_restate as LR
+from speech_anime.hparams import configure
+from speech_anime import audio, stream
+from speech_anime.datasets import DatasetSlidingWindow
+from sdfa_amd import synth, engine
+
+
+def test_configure_defaults_and_json_overwrite(tmp_path):
+    hp = configure(dict(mode="evaluate", custom_hparams="dgrad"))
+    assert hp.audio.sample_rate == 8000 and hp.anime.fps == 60 and hp.anime.feature.ts_delta == 100
+    assert hp.dataset_anime.speakers["m1"] == 2 and hp.model.face_data_type == "dgrad_3d"
+    p = tmp_path / "hparams.json"
+    p.write_text(json.dumps({"audio": {"sample_rate": 16000}, "trainer": {"evaluate": {"test": [["x.wav"]]}},
+                             "ensembling_ms": 30}))
+    hp = configure(dict(mode="evaluate", custom_hparams=str(p), eval_spk_cond="f1"))
+    assert hp.audio.sample_rate == 16000 and hp.audio.mel.n_mels == 128       # nested overwrite keeps siblings
+    assert hp.trainer.evaluate.test == [] and hp.ensembling_ms == 30 and hp.eval_spk_cond == "f1"
+    with pytest.raises(ValueError):
+        p.write_text(json.dumps({"audio": {"sample_rate": 44100}}))
+        configure(dict(mode="evaluate", custom_hparams=str(p)))
+
+
+def test_unit_converters_are_float32():
+    hp = configure(dict(mode="evaluate", custom_hparams="dgrad"))
+    DatasetSlidingWindow.hparams = hp
+    v = DatasetSlidingWindow.frame_to_sample(7.0)
+    assert isinstance(v, np.float32) and v == np.float32(7 * 8000 / 60)
+    assert DatasetSlidingWindow.sample_to_ms(4544 / 2) == np.float32(284.0)
+    DatasetSlidingWindow.hparams = None
+
+
+def test_energy_matches_rms_of_padded_windows():
+    sr = 8000
+    pcm = synth.make_pcm(4, 6000)
+    e = DatasetSlidingWindow._energy(pcm, sr)
+    win, hop, sliding = engine.frame_geometry(sr)
+    starts, _ = engine.frame_index(len(pcm), sr)
+    assert e.shape == (len(starts), 1, 64)
+    for i in (0, 5, len(starts) // 2, len(starts) - 1):
+        s = int(starts[i])
+        w = np.zeros(sliding, np.float32)
+        a, b = max(0, s), min(len(pcm), s + sliding)
+        if b > a:
+            w[a - s:b - s] = pcm[a:b]
+        assert np.abs(e[i] - LR.rms(w, win, hop)).max() < 1e-6
+
+
+def test_rms_normalize_hits_target_db():
+    x = synth.make_pcm(1, 8000) * 0.1
+    y = audio.rms_normalize(x, -24.5)
+    assert abs(20 * np.log10(np.sqrt(np.mean(y ** 2))) + 24.5) < 1e-3 and np.abs(y).max() <= 0.999
+
+
+def test_stream_seek_interpolates():
+    ts = [-117, -100, -83, -67]
+    seq = np.arange(4, dtype=np.float64)[:, None] * np.ones((1, 3))
+    assert np.allclose(stream.seek(-100, ts, seq), 1.0)
+    assert np.allclose(stream.seek(-91.5, ts, seq), 1.5)
+    assert np.allclose(stream.seek(-500, ts, seq), 0.0) and np.allclose(stream.seek(500, ts, seq), 3.0)

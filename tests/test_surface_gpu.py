@@ -1,0 +1,94 @@
+"""The speech_anime drop-in surface on the GPU: same calls the reference's evaluate path makes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from speech_anime.hparams import configure
+from speech_anime.api import build_model, evaluate_model
+from speech_anime.datasets import DatasetSlidingWindow
+from sdfa_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(sd, sr, head="dgrad"):
+    hp = configure(dict(mode="evaluate", custom_hparams=head))
+    hp.audio.set_key("sample_rate", sr)
+    DatasetSlidingWindow.hparams = None
+    return hp, build_model(hp, sd)
+
+
+@pytest.mark.parametrize("sr", [8000, 16000])
+def test_generate_animation_matches_reference_fixture(golden, synth_sd, sr):
+    g = golden["e2e_dgrad"]
+    hp, model = _model(synth_sd["dgrad"], sr)
+    ts, animes, others = model.generate_animation(synth.make_pcm(0, 2 * sr), "m1", 0, 0, dataset_class=DatasetSlidingWindow)
+    assert list(ts) == list(g[f"sr{sr}_tslist"]) and all(isinstance(t, int) for t in ts)
+    assert animes.dtype == np.float32 and list(animes.shape) == list(g[f"sr{sr}_shape"])
+    assert np.abs(animes[:, ::97] - g[f"sr{sr}_stride97"]).max() <= 1e-4
+    assert others["inputs"].shape == (len(ts), 3, 128, 64)
+
+
+def test_fetch_audio_features_contract(golden, synth_sd):
+    sr = 8000
+    hp, model = _model(synth_sd["dgrad"], sr)
+    g = golden["frontend"]
+    out = DatasetSlidingWindow.fetch_audio_features(synth.make_pcm(0, 2 * sr), hp)
+    assert set(out) == {"tslist", "energy", "audio_feat"}
+    assert isinstance(out["audio_feat"], np.ndarray) and out["audio_feat"].shape == (156, 64, 128, 3)
+    assert out["energy"].shape == (156, 1, 64) and out["energy"].dtype == np.float32
+    keep = g["sr8000_uniform_frames"]
+    assert np.abs(out["audio_feat"][keep] - g["sr8000_uniform_audio_feat"]).max() <= 5e-5
+    with pytest.raises(AssertionError):
+        DatasetSlidingWindow.fetch_audio_features(np.full(8000, 1.5, np.float32), hp)      # sliding_window.py:330
+
+
+def test_inner_forward_trace_contract(synth_sd):
+    """api.py:108-116: audio_feat = rand(1,64,128,3), speaker_id = zeros(1, long)."""
+    hp, model = _model(synth_sd["dgrad"], 8000)
+    align = {}
+    (scale, rotat), z = model._model(torch.rand(1, 64, 128, 3), torch.zeros(1, dtype=torch.long), align_dict=align)
+    assert scale.shape == (1, 1, 9976, 6) and rotat.shape == (1, 1, 9976, 3) and z.shape == (1, 1, 512)
+    assert align["audio_encoder10"].shape == (1, 1, 64)
+    res = model.forward({"audio_feat": torch.rand(3, 64, 128, 3), "speaker_id": torch.zeros(3, dtype=torch.long)})
+    assert set(res["prediction"]) == {"dgrad_3d_scale", "dgrad_3d_rotat"}
+
+
+def test_offsets_head_through_surface(golden, synth_sd):
+    hp, model = _model(synth_sd["offsets"], 16000, "offsets")
+    gm = golden["model_dgrad"]; g = golden["model_offsets"]
+    pred, z = model._model(torch.from_numpy(gm["audio_feat"][:4]), torch.full((4,), 2, dtype=torch.long))
+    assert pred.shape == (4, 1, 15069)
+    assert np.abs(pred.cpu().numpy()[:, 0, ::7] - g["offsets_stride7"]).max() <= 1e-4
+
+
+def test_ensembling_averages_two_passes(synth_sd):
+    sr = 16000
+    hp, model = _model(synth_sd["dgrad"], sr)
+    pcm = synth.make_pcm(5, sr)
+    ts0, a0, _ = model.generate_animation(pcm, 2, 0, 0, ensembling_ms=0)
+    ts1, a1, _ = model.generate_animation(pcm, 2, 0, 0, ensembling_ms=20)
+    pad = 20 * sr // 1000
+    _, a_shift, _ = model.generate_animation(np.pad(pcm[:-pad], [[pad, 0]]), 2, 0, 0, ensembling_ms=0)
+    assert ts0 == ts1 and np.abs(a1 - (a0 + a_shift) / 2).max() <= 1e-6
+
+
+def test_evaluate_cli_path_writes_dgrad_track(tmp_path, synth_sd):
+    from scipy.io import wavfile
+    sr = 16000
+    pcm = synth.make_pcm(6, sr)
+    wav = tmp_path / "speech@clip0.wav"
+    wavfile.write(str(wav), sr, (pcm * 32767).astype(np.int16))
+    ck = tmp_path / "epoch0050.ckpt"
+    torch.save({"epoch": 50, "global_step": 1, "state": {k: torch.from_numpy(np.array(v)) for k, v in synth_sd["dgrad"].items()}}, str(ck))
+    hpj = tmp_path / "hparams.json"
+    hpj.write_text('{"audio": {"sample_rate": 16000}}')
+    DatasetSlidingWindow.hparams = None
+    res = evaluate_model(dict(mode="evaluate", load_from=str(ck), custom_hparams=str(hpj), output_dir=str(tmp_path / "out"),
+                              eval_input=str(wav), eval_spk_cond="m1", overwrite_video=True, export_mesh_frames=True))
+    path, ts, animes = res[0]
+    d = tmp_path / "out" / "speech@clip0"
+    assert (d / "dgrad_3d.npy").exists() and (d / "000000_dgrad.npy").exists()
+    assert np.load(d / "dgrad_3d.npy").shape == (len(ts), 9976, 9)
