@@ -31,20 +31,15 @@ __device__ __forceinline__ void mfma4(f32x16 &acc, const float4 &a, const float4
 
 __device__ __forceinline__ float lrelu02(float x) { return x >= 0.f ? x : 0.2f * x; }
 
-__device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp_f32 / v_rcp_f32 based, branch-free (1-2 ulp each; absolute error ~1e-7, which is what the
+// 1e-4 dgrad tolerance needs -- gate values feed products, so absolute error is the one that matters)
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
-// tanh with ~1e-7 absolute error: odd, exp-based, no cancellation blow-up near 0
+__device__ __forceinline__ float sigmoidf_acc(float x) { return fast_rcp(1.0f + __expf(-x)); }
+
 __device__ __forceinline__ float tanhf_acc(float x) {
-    float ax = fabsf(x);
-    float r;
-    if (ax < 0.04f) {
-        float x2 = x * x;
-        r = x * (1.0f + x2 * (-0.33333334f + x2 * 0.13333334f));
-    } else {
-        float e = __expf(-2.0f * ax);
-        r = copysignf((1.0f - e) / (1.0f + e), x);
-    }
-    return r;
+    const float e = __expf(-2.0f * fabsf(x));
+    return copysignf((1.0f - e) * fast_rcp(1.0f + e), x);
 }
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }

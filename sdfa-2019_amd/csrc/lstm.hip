@@ -88,31 +88,25 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_kernel(FreqLstmArgs a) {
                     acc[gt][j][4 * g + 2] = b.z; acc[gt][j][4 * g + 3] = b.w;
                 }
             }
-        // x part: k-quads 0..15
+        // one loop over the concatenated K: k-quads 0..15 = x_f (from sX), 16..47 = h_{s-1} (from sH; h_{-1} = 0 is
+        // skipped on the first step).  Weights for k-block kb+1 are requested before the 32 MFMAs of kb are issued,
+        // so the L2 round trip hides behind 2048 cycles of matrix work.
+        const int nkb = s > 0 ? 24 : 8;
+        const float4 *__restrict__ wp = Ww + h * 512;
+        float4 wn0 = wp[0], wn1 = wp[32], wn2 = wp[64], wn3 = wp[96];
 #pragma unroll 2
-        for (int kb = 0; kb < 8; ++kb) {
-            const int kq = 2 * kb + h;
-            float4 b0 = sX[cur][kq][l31], b1 = sX[cur][kq][32 + l31];
-#pragma unroll
-            for (int gt = 0; gt < 4; ++gt) {
-                float4 w = Ww[kq * 512 + gt * 32];
-                mfma4(acc[gt][0], w, b0);
-                mfma4(acc[gt][1], w, b1);
+        for (int kb = 0; kb < nkb; ++kb) {
+            const float4 w0 = wn0, w1 = wn1, w2 = wn2, w3 = wn3;
+            if (kb + 1 < nkb) {
+                const float4 *__restrict__ wq = wp + (kb + 1) * 1024;
+                wn0 = wq[0]; wn1 = wq[32]; wn2 = wq[64]; wn3 = wq[96];
             }
-        }
-        // h part: k-quads 16..47 (h_{-1} = 0: skipped on the first step)
-        if (s > 0) {
-#pragma unroll 2
-            for (int kb = 0; kb < 16; ++kb) {
-                const int kq = 2 * kb + h;
-                float4 b0 = sH[kq][l31], b1 = sH[kq][32 + l31];
-#pragma unroll
-                for (int gt = 0; gt < 4; ++gt) {
-                    float4 w = Ww[(16 + kq) * 512 + gt * 32];
-                    mfma4(acc[gt][0], w, b0);
-                    mfma4(acc[gt][1], w, b1);
-                }
-            }
+            const float4 *bsrc = kb < 8 ? &sX[cur][2 * kb + h][0] : &sH[2 * (kb - 8) + h][0];
+            const float4 b0 = bsrc[l31], b1 = bsrc[32 + l31];
+            mfma4(acc[0][0], w0, b0); mfma4(acc[0][1], w0, b1);
+            mfma4(acc[1][0], w1, b0); mfma4(acc[1][1], w1, b1);
+            mfma4(acc[2][0], w2, b0); mfma4(acc[2][1], w2, b1);
+            mfma4(acc[3][0], w3, b0); mfma4(acc[3][1], w3, b1);
         }
         __syncthreads();   // every wave has finished reading sH / sX[cur]
 #pragma unroll
@@ -167,16 +161,21 @@ __global__ __launch_bounds__(512, 2) void time_lstm_kernel(TimeLstmArgs a) {
                     acc[gt][j][4 * g + 2] = v.z; acc[gt][j][4 * g + 3] = v.w;
                 }
         if (s > 0) {
+            const float4 *__restrict__ wp = Ww + h * 1024;
+            float4 wn0 = wp[0], wn1 = wp[32], wn2 = wp[64], wn3 = wp[96];
 #pragma unroll 2
             for (int kb = 0; kb < 32; ++kb) {
-                const int kq = 2 * kb + h;
-                float4 b0 = sHc[kq * 64 + l31], b1 = sHc[kq * 64 + 32 + l31];
-#pragma unroll
-                for (int gt = 0; gt < 4; ++gt) {
-                    float4 w = Ww[kq * 1024 + gt * 32];
-                    mfma4(acc[gt][0], w, b0);
-                    mfma4(acc[gt][1], w, b1);
+                const float4 w0 = wn0, w1 = wn1, w2 = wn2, w3 = wn3;
+                if (kb + 1 < 32) {
+                    const float4 *__restrict__ wq = wp + (kb + 1) * 2048;
+                    wn0 = wq[0]; wn1 = wq[32]; wn2 = wq[64]; wn3 = wq[96];
                 }
+                const int kq = 2 * kb + h;
+                const float4 b0 = sHc[kq * 64 + l31], b1 = sHc[kq * 64 + 32 + l31];
+                mfma4(acc[0][0], w0, b0); mfma4(acc[0][1], w0, b1);
+                mfma4(acc[1][0], w1, b0); mfma4(acc[1][1], w1, b1);
+                mfma4(acc[2][0], w2, b0); mfma4(acc[2][1], w2, b1);
+                mfma4(acc[3][0], w3, b0); mfma4(acc[3][1], w3, b1);
             }
         }
 #pragma unroll
