@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--chunk", type=int, default=8192, help="frames per encoder launch group")
     ap.add_argument("--gather", choices=["dgrad", "coef", "none"], default="dgrad")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="library tuning switch name=value (A/B runs)")
     ap.add_argument("--cpu-sample-seconds", type=float, default=2.0)
     return ap.parse_args()
 
@@ -90,6 +91,10 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
+    from sdfa_amd import _lib
+    for kv in a.opt:
+        k, v = kv.split("=")
+        _lib.check(_lib.lib.sdfa_debug_set_option(k.encode(), int(v)))
     sr, L = a.sample_rate, int(a.seconds * a.sample_rate)
     sd = synth.make_state_dict("dgrad", 1234)
     eng = Engine(sd, device=dev, max_frames=a.chunk)

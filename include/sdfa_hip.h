@@ -144,6 +144,7 @@ int sdfa_regress_forward(const sdfa_model *m, const float *d_z, const int64_t *d
 /* Debug / parity taps: copy an intermediate activation of the LAST sdfa_encoder_forward call out of
  * the workspace in the reference's layout.  what: 0 = pool1 (n,32,64,64)  1 = conv3 (n,64,32,64)
  * 2 = freq-lstm (n,256,64)  3 = bilstm (n,64,512).  Used by tests only. */
+int sdfa_debug_set_option(const char *name, int value);     /* tuning switches for A/B runs, e.g. "gemm_variant" */
 int sdfa_debug_keep_intermediates(sdfa_model *m, int on);   /* un-aliased workspace: call before sizing it */
 int sdfa_debug_tap(const sdfa_model *m, int what, int64_t n_frames, float *d_dst, const void *d_workspace,
                    void *stream);

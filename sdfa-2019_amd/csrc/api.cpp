@@ -556,6 +556,12 @@ int64_t sdfa_workspace_bytes(const sdfa_model *m, int64_t max_frames) {
     return layout(round_up(max_frames, 128), m->keep).total * 4;
 }
 
+extern int g_sdfa_gemm_variant;
+int sdfa_debug_set_option(const char *name, int value) {
+    if (name && !strcmp(name, "gemm_variant")) { g_sdfa_gemm_variant = value; return SDFA_OK; }
+    return fail(SDFA_EINVAL, "unknown option '%s'", name ? name : "(null)");
+}
+
 int sdfa_debug_keep_intermediates(sdfa_model *m, int on) {
     if (!m) return fail(SDFA_EINVAL, "null model");
     m->keep = on != 0;

@@ -94,15 +94,16 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_kernel(FreqLstmArgs a) {
         const int nkb = s > 0 ? 24 : 8;
         const float4 *__restrict__ wp = Ww + h * 512;
         float4 wn0 = wp[0], wn1 = wp[32], wn2 = wp[64], wn3 = wp[96];
+        float4 bn0 = sX[cur][h][l31], bn1 = sX[cur][h][32 + l31];
 #pragma unroll 2
         for (int kb = 0; kb < nkb; ++kb) {
-            const float4 w0 = wn0, w1 = wn1, w2 = wn2, w3 = wn3;
+            const float4 w0 = wn0, w1 = wn1, w2 = wn2, w3 = wn3, b0 = bn0, b1 = bn1;
             if (kb + 1 < nkb) {
                 const float4 *__restrict__ wq = wp + (kb + 1) * 1024;
                 wn0 = wq[0]; wn1 = wq[32]; wn2 = wq[64]; wn3 = wq[96];
+                const float4 *bsrc = kb + 1 < 8 ? &sX[cur][2 * kb + 2 + h][0] : &sH[2 * (kb - 7) + h][0];
+                bn0 = bsrc[l31]; bn1 = bsrc[32 + l31];
             }
-            const float4 *bsrc = kb < 8 ? &sX[cur][2 * kb + h][0] : &sH[2 * (kb - 8) + h][0];
-            const float4 b0 = bsrc[l31], b1 = bsrc[32 + l31];
             mfma4(acc[0][0], w0, b0); mfma4(acc[0][1], w0, b1);
             mfma4(acc[1][0], w1, b0); mfma4(acc[1][1], w1, b1);
             mfma4(acc[2][0], w2, b0); mfma4(acc[2][1], w2, b1);

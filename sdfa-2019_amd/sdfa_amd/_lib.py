@@ -34,6 +34,7 @@ SYMBOLS = {
     "sdfa_workspace_bytes": (_i64, [_p, _i64]),
     "sdfa_encoder_forward": (C.c_int, [_p, _p, _i64, _p, _p, _p, _i64, _p]),
     "sdfa_regress_forward": (C.c_int, [_p, _p, _p, _i64, _p, _p, _p, _i64, _p]),
+    "sdfa_debug_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "sdfa_debug_keep_intermediates": (C.c_int, [_p, C.c_int]),
     "sdfa_debug_tap": (C.c_int, [_p, C.c_int, _i64, _p, _p, _p]),
     "sdfa_profile_enable": (C.c_int, [_p, C.c_int]),
@@ -64,6 +65,11 @@ def _load():
 lib = _load()
 
 
+def set_option(name, value):
+    """Library tuning switch (A/B runs); also settable as SDFA_OPTS="name=value,name=value" in the environment."""
+    check(lib.sdfa_debug_set_option(name.encode(), int(value)))
+
+
 def check(rc):
     if rc is not None and rc < 0:
         code = int(rc)
@@ -72,3 +78,7 @@ def check(rc):
             raise AssertionError(msg)      # the reference raises AssertionError here (sliding_window.py:363)
         raise SdfaError(code, msg)
     return rc
+
+
+for _kv in filter(None, os.environ.get("SDFA_OPTS", "").split(",")):
+    set_option(*_kv.split("="))
