@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--sample-rate", type=int, default=16000)
     ap.add_argument("--chunk", type=int, default=8192, help="frames per encoder launch group")
     ap.add_argument("--gather", choices=["dgrad", "coef", "none"], default="dgrad")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="library tuning switch name=value (A/B runs)")
     ap.add_argument("--cpu-sample-seconds", type=float, default=2.0)
@@ -85,11 +86,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    local_dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
 
     from sdfa_amd import _lib
     for kv in a.opt:
@@ -114,17 +119,17 @@ def main():
     width = eng.out_dim if a.gather != "coef" else eng.coef_dim
     gatherer = None
     if world > 1 and a.gather != "none":
-        gatherer = sdist.FrameGatherer([F] * world, width, torch.float32, dev)
+        gatherer = sdist.FrameGatherer([F] * world, width, torch.float32, dev, a.chunk)
     out = torch.empty((F, eng.out_dim), dtype=torch.float32, device=dev)
 
     def step():
         eng.mel_frontend_device(pcm, clip_off, clip_len, frame_clip, frame_start, sr, out=feat)
-        for f0 in range(0, F, a.chunk):
+        for ci, f0 in enumerate(range(0, F, a.chunk)):
             f1 = min(F, f0 + a.chunk)
             z, _ = eng.encoder(feat[f0:f1], want_align=False)
             coef, o = eng.regress(z, spk[f0:f1], want_coef=(a.gather == "coef"), out=out[f0:f1])
             if gatherer is not None:
-                gatherer.gather_chunk(o if a.gather == "dgrad" else coef, f0, a.chunk)
+                gatherer.gather_chunk(o if a.gather == "dgrad" else coef, ci)
         if gatherer is not None:
             gatherer.finish()
 

@@ -35,45 +35,54 @@ class FrameGatherer:
     """All-gather of per-frame rows, issued chunk by chunk so that the transfer of chunk i overlaps the
     compute of chunk i+1 (the collective is asynchronous on the process group's own stream).
 
-    Rank r's rows land in out[offset[r] : offset[r] + counts[r]] on every rank, i.e. the gathered buffer is
-    the concatenation of the shards in rank order = the original clip order.  Ragged shards are handled by
-    padding a chunk to the longest shard's chunk and copying the valid rows into place afterwards.
+    Even shards (every rank holds the same number of frames, the bench case) use ONE contiguous
+    all_gather_into_tensor per chunk straight into the final buffer, which is laid out chunk-major:
+    buffer[chunk][rank][row] -- no staging copy, no extra memory.  `rows(rank)` returns that rank's frames in
+    order as a list of per-chunk views; `gathered()` materialises the rank-major (= original clip order)
+    matrix when a caller wants one tensor.  Ragged shards fall back to padded staging buffers.
     """
 
-    def __init__(self, counts, row_width, dtype, device, group=None):
+    def __init__(self, counts, row_width, dtype, device, chunk_len, group=None):
         self.group = group
         self.world = dist.get_world_size(group)
         self.counts = [int(c) for c in counts]
         assert len(self.counts) == self.world
-        self.offsets = [0]
-        for c in self.counts:
-            self.offsets.append(self.offsets[-1] + c)
-        self.width = int(row_width)
-        self.out = torch.empty((self.offsets[-1], self.width), dtype=dtype, device=device)
+        self.width, self.chunk = int(row_width), int(chunk_len)
+        self.even = len(set(self.counts)) == 1
+        self.n_chunks = (max(self.counts) + self.chunk - 1) // self.chunk
+        self.dtype, self.device = dtype, device
         self._pending = []
+        if self.even:
+            n = self.counts[0]
+            self._lens = [min(self.chunk, n - c * self.chunk) for c in range(self.n_chunks)]
+            self._base = [0]
+            for l in self._lens:
+                self._base.append(self._base[-1] + l * self.world)
+            self.buf = torch.empty((self._base[-1], self.width), dtype=dtype, device=device)
+        else:
+            self.offsets = [0]
+            for c in self.counts:
+                self.offsets.append(self.offsets[-1] + c)
+            self.buf = torch.empty((self.offsets[-1], self.width), dtype=dtype, device=device)
 
-    def n_chunks(self, chunk_len):
-        return (max(self.counts) + chunk_len - 1) // chunk_len
-
-    def gather_chunk(self, rows, f0, chunk_len):
-        """`rows`: this rank's output rows for its frames [f0, f0 + chunk_len) (fewer, possibly zero, at the end
-        of a short shard).  Every rank calls this for f0 = 0, chunk_len, 2*chunk_len, ... (n_chunks times)."""
-        lens = [max(0, min(c - f0, chunk_len)) for c in self.counts]
+    def gather_chunk(self, rows, chunk_index):
+        """`rows`: this rank's output rows for its frames [chunk_index*chunk, (chunk_index+1)*chunk) (fewer, or
+        None, at the end of a short shard).  Every rank calls this for chunk_index = 0 .. n_chunks-1."""
+        f0 = chunk_index * self.chunk
+        if self.even:
+            dst = self.buf[self._base[chunk_index]: self._base[chunk_index + 1]]
+            self._pending.append((dist.all_gather_into_tensor(dst, rows.contiguous(), group=self.group, async_op=True), None, f0, None))
+            return
+        lens = [max(0, min(c - f0, self.chunk)) for c in self.counts]
         pad = max(lens)
         if pad == 0:
             return
-        n = 0 if rows is None else int(rows.shape[0])
-        if all(l == pad for l in lens):
-            outs = [self.out[self.offsets[r] + f0: self.offsets[r] + f0 + pad] for r in range(self.world)]
-            work = dist.all_gather(outs, rows.contiguous(), group=self.group, async_op=True)
-            self._pending.append((work, None, f0, lens))
-            return
-        send = torch.zeros((pad, self.width), dtype=self.out.dtype, device=self.out.device)
-        if n:
-            send[:n] = rows
-        stage = [torch.empty((pad, self.width), dtype=self.out.dtype, device=self.out.device) for _ in range(self.world)]
-        work = dist.all_gather(stage, send, group=self.group, async_op=True)
-        self._pending.append((work, stage, f0, lens))
+        send = torch.zeros((pad, self.width), dtype=self.dtype, device=self.device)
+        if rows is not None and rows.shape[0]:
+            send[:rows.shape[0]] = rows
+        stage = torch.empty((self.world * pad, self.width), dtype=self.dtype, device=self.device)
+        work = dist.all_gather_into_tensor(stage, send, group=self.group, async_op=True)
+        self._pending.append((work, stage.view(self.world, pad, self.width), f0, lens))
 
     def finish(self):
         for work, stage, f0, lens in self._pending:
@@ -81,6 +90,17 @@ class FrameGatherer:
             if stage is not None:
                 for r in range(self.world):
                     if lens[r]:
-                        self.out[self.offsets[r] + f0: self.offsets[r] + f0 + lens[r]] = stage[r][:lens[r]]
+                        self.buf[self.offsets[r] + f0: self.offsets[r] + f0 + lens[r]] = stage[r, :lens[r]]
         self._pending = []
-        return self.out
+
+    def rows(self, rank):
+        """Rank `rank`'s frames, in order, as a list of views (one per chunk)."""
+        if not self.even:
+            return [self.buf[self.offsets[rank]: self.offsets[rank + 1]]]
+        return [self.buf[self._base[c] + rank * l: self._base[c] + (rank + 1) * l] for c, l in enumerate(self._lens)]
+
+    def gathered(self):
+        """(sum(counts), width) matrix in rank order = original clip order (copies in the even case)."""
+        if not self.even:
+            return self.buf
+        return torch.cat([v for r in range(self.world) for v in self.rows(r)], 0)

@@ -28,11 +28,13 @@ def _worker(rank, world, port, n_clips, frames_per_clip, width, chunk, q):
             rows.append(c * 1000.0 + f + np.arange(width) * 1e-3)
     local = torch.tensor(np.asarray(rows, np.float32).reshape(-1, width))
     counts = sd.frame_counts_all(local.shape[0])
-    g = sd.FrameGatherer(counts, width, torch.float32, "cpu")
-    for i in range(g.n_chunks(chunk)):
-        f0 = i * chunk
-        g.gather_chunk(local[f0:f0 + chunk], f0, chunk)
-    out = g.finish()
+    g = sd.FrameGatherer(counts, width, torch.float32, "cpu", chunk)
+    for i in range(g.n_chunks):
+        g.gather_chunk(local[i * chunk:(i + 1) * chunk], i)
+    g.finish()
+    out = g.gathered()
+    per_rank = torch.cat(g.rows(1), 0)
+    assert per_rank.shape[0] == counts[1]
     q.put((rank, counts, out.numpy()))
     dist.barrier()
     dist.destroy_process_group()
