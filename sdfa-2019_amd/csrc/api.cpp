@@ -131,9 +131,12 @@ struct sdfa_model {
     const float *kp_w, *qc_w, *qp_w, *at_v, *at_b;
     struct Fc { const float *w, *b, *cw; int K, P, Ppad, Pstore; int act; };
     Fc trunk, br[2][3], off[3];
-    const float *pca_q, *pca_bias;
-    int pca_K;           // 288 (96 | 192) or 64
-    int64_t pca_ld;      // padded output width
+    // PCA expansion: dgrad = two bases (scale K 96 -> 6 of every 9 output columns, rotat K 192 -> the other 3);
+    // offsets = one basis (K 64)
+    int pca_n = 0;
+    const float *pca_q[2], *pca_bias[2];
+    int pca_K[2], pca_k0[2], pca_group[2], pca_off[2];
+    int64_t pca_ld[2], pca_cols[2];
     int64_t out_dim, coef_dim;
     // profiling
     struct Ev { std::string stage; hipEvent_t a, b; };
@@ -413,7 +416,7 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
     // ---- output module
     const std::string om = "_output_module.";
     size_t o_fc[7][3];
-    size_t o_pq, o_pb;
+    size_t o_pq[2] = {0, 0}, o_pb[2] = {0, 0};
     if (m->head == SDFA_HEAD_DGRAD) {
         if (pack_fc(m, pk, om + "_layers.0", 512, 512, true, ACT_LRELU, o_fc[0], m->trunk)) return SDFA_ESTATE;
         const char *brn[2] = {"_scale_layers.", "_rotat_layers."};
@@ -426,35 +429,36 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
         auto *cs = get(m, om + "_scale_pca.compT", (size_t)59856 * 85), *ms = get(m, om + "_scale_pca.means", 59856);
         auto *cr = get(m, om + "_rotat_pca.compT", (size_t)29928 * 180), *mr = get(m, om + "_rotat_pca.means", 29928);
         if (!cs || !ms || !cr || !mr) return SDFA_ESTATE;
-        // combined basis, K = 96 (scale, zero padded) + 192 (rotat): output coordinate o = tri*9 + c
-        m->pca_K = 288; m->pca_ld = round_up(SDFA_DGRAD_DIM, 128);
-        o_pq = pk.add((size_t)m->pca_K * m->pca_ld);
-        o_pb = pk.add(m->pca_ld);
-        for (int64_t tri = 0; tri < 9976; ++tri)
-            for (int c = 0; c < 9; ++c) {
-                const int64_t o = tri * 9 + c;
-                if (c < 6) {
-                    const float *row = &(*cs)[(size_t)(tri * 6 + c) * 85];
-                    for (int k = 0; k < 85; ++k) pk.buf[o_pq + ((size_t)(k / 4) * m->pca_ld + o) * 4 + (k % 4)] = row[k];
-                    pk.buf[o_pb + o] = (*ms)[tri * 6 + c];
-                } else {
-                    const float *row = &(*cr)[(size_t)(tri * 3 + c - 6) * 180];
-                    for (int k = 0; k < 180; ++k) pk.buf[o_pq + ((size_t)((96 + k) / 4) * m->pca_ld + o) * 4 + ((96 + k) % 4)] = row[k];
-                    pk.buf[o_pb + o] = (*mr)[tri * 3 + c - 6];
-                }
+        // two bases; the GEMM epilogue scatters column q of basis b to output coordinate (q / g) * 9 + off + q % g,
+        // which IS the [s0..s5 r0 r1 r2] interleave of data_to_anime_feat (model.py:246-257)
+        m->pca_n = 2;
+        const std::vector<float> *comp[2] = {cs, cr}, *mean[2] = {ms, mr};
+        const int kreal[2] = {85, 180};
+        for (int b = 0; b < 2; ++b) {
+            m->pca_K[b] = b ? 192 : 96; m->pca_k0[b] = b ? 96 : 0; m->pca_group[b] = b ? 3 : 6; m->pca_off[b] = b ? 6 : 0;
+            m->pca_cols[b] = b ? 29928 : 59856; m->pca_ld[b] = round_up(m->pca_cols[b], 128);
+            o_pq[b] = pk.add((size_t)m->pca_K[b] * m->pca_ld[b]);
+            o_pb[b] = pk.add(m->pca_ld[b]);
+            for (int64_t o = 0; o < m->pca_cols[b]; ++o) {
+                const float *row = &(*comp[b])[(size_t)o * kreal[b]];
+                for (int k = 0; k < kreal[b]; ++k) pk.buf[o_pq[b] + ((size_t)(k / 4) * m->pca_ld[b] + o) * 4 + (k % 4)] = row[k];
+                pk.buf[o_pb[b] + o] = (*mean[b])[o];
             }
+        }
     } else {
         if (pack_fc(m, pk, om + "_layers.0", 512, 512, true, ACT_LRELU, o_fc[0], m->off[0])) return SDFA_ESTATE;
         if (pack_fc(m, pk, om + "_layers.1", 256, 512, false, ACT_TANH, o_fc[1], m->off[1])) return SDFA_ESTATE;
         if (pack_fc(m, pk, om + "_layers.2", SDFA_COEF_OFFSETS, 256, false, ACT_NONE, o_fc[2], m->off[2])) return SDFA_ESTATE;
         auto *cp = get(m, om + "_pca.compT", (size_t)SDFA_OFFSETS_DIM * 59), *mp = get(m, om + "_pca.means", SDFA_OFFSETS_DIM);
         if (!cp || !mp) return SDFA_ESTATE;
-        m->pca_K = 64; m->pca_ld = round_up(SDFA_OFFSETS_DIM, 128);
-        o_pq = pk.add((size_t)m->pca_K * m->pca_ld);
-        o_pb = pk.add(m->pca_ld);
+        m->pca_n = 1;
+        m->pca_K[0] = 64; m->pca_k0[0] = 0; m->pca_group[0] = 0; m->pca_off[0] = 0;
+        m->pca_cols[0] = SDFA_OFFSETS_DIM; m->pca_ld[0] = round_up(SDFA_OFFSETS_DIM, 128);
+        o_pq[0] = pk.add((size_t)m->pca_K[0] * m->pca_ld[0]);
+        o_pb[0] = pk.add(m->pca_ld[0]);
         for (int64_t o = 0; o < SDFA_OFFSETS_DIM; ++o) {
-            for (int k = 0; k < 59; ++k) pk.buf[o_pq + ((size_t)(k / 4) * m->pca_ld + o) * 4 + (k % 4)] = (*cp)[(size_t)o * 59 + k];
-            pk.buf[o_pb + o] = (*mp)[o];
+            for (int k = 0; k < 59; ++k) pk.buf[o_pq[0] + ((size_t)(k / 4) * m->pca_ld[0] + o) * 4 + (k % 4)] = (*cp)[(size_t)o * 59 + k];
+            pk.buf[o_pb[0] + o] = (*mp)[o];
         }
     }
     // ---- upload
@@ -478,7 +482,7 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
     } else {
         for (int i = 0; i < 3; ++i) bind(m->off[i], o_fc[i]);
     }
-    m->pca_q = d + o_pq; m->pca_bias = d + o_pb;
+    for (int b = 0; b < m->pca_n; ++b) { m->pca_q[b] = d + o_pq[b]; m->pca_bias[b] = d + o_pb[b]; }
     m->host.clear();
     m->finalized = true;
     return SDFA_OK;
@@ -707,11 +711,17 @@ int sdfa_regress_forward(const sdfa_model *m, const float *d_z, const int64_t *d
         pf.end();
         if (d_out) {
             // PCA expansion: out[n][o] = sum_k coef[k][n] * basis[k][o] + means[o]   (rows = frames)
-            GemmArgs g{};
-            g.P = coef; g.Q = m->pca_q; g.D = d_out + f0 * m->out_dim; g.bias = m->pca_bias; g.bias_on_q = 1;
-            g.ldp = Nc; g.ldq = m->pca_ld; g.ldd = m->out_dim; g.Ppad = Nc; g.Qpad = m->pca_ld; g.Pstore = N; g.Qreal = m->out_dim;
-            g.K = m->pca_K; g.seg_k = m->pca_K; g.act = ACT_NONE; g.out_mode = OUT_ROW;
-            pf.begin("pca"); HIP_TRY(sdfa_launch_gemm(g, s)); pf.end();
+            pf.begin("pca");
+            for (int b = 0; b < m->pca_n; ++b) {
+                GemmArgs g{};
+                g.P = coef + (int64_t)m->pca_k0[b] * Nc; g.Q = m->pca_q[b]; g.D = d_out + f0 * m->out_dim;
+                g.bias = m->pca_bias[b]; g.bias_on_q = 1;
+                g.ldp = Nc; g.ldq = m->pca_ld[b]; g.ldd = m->out_dim; g.Ppad = Nc; g.Qpad = m->pca_ld[b]; g.Pstore = N;
+                g.Qreal = m->pca_cols[b]; g.K = m->pca_K[b]; g.seg_k = g.K; g.act = ACT_NONE; g.out_mode = OUT_ROW;
+                g.col_group = m->pca_group[b]; g.col_stride = 9; g.col_off = m->pca_off[b];
+                HIP_TRY(sdfa_launch_gemm(g, s));
+            }
+            pf.end();
         }
     }
     return SDFA_OK;

@@ -136,9 +136,10 @@ __global__ __launch_bounds__(256, 2) void gemm_k4_kernel(GemmArgs a) {
                     if (p < a.Pstore) st4(a.D + ((p / 4) * a.ldd + q) * 4, make_float4(v[0], v[1], v[2], v[3]));
                 } else {
                     if (q < a.Qreal) {
+                        const int64_t o = a.col_group ? (q / a.col_group) * a.col_stride + a.col_off + q % a.col_group : q;
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (p + e < a.Pstore) a.D[(p + e) * a.ldd + q] = v[e];
+                            if (p + e < a.Pstore) a.D[(p + e) * a.ldd + o] = v[e];
                     }
                 }
             }
@@ -236,9 +237,10 @@ __global__ __launch_bounds__(256, 2) void gemm_direct_kernel(GemmArgs a) {
                     if (p < a.Pstore) st4(a.D + ((p / 4) * a.ldd + q) * 4, make_float4(v[0], v[1], v[2], v[3]));
                 } else {
                     if (q < a.Qreal) {
+                        const int64_t o = a.col_group ? (q / a.col_group) * a.col_stride + a.col_off + q % a.col_group : q;
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (p + e < a.Pstore) a.D[(p + e) * a.ldd + q] = v[e];
+                            if (p + e < a.Pstore) a.D[(p + e) * a.ldd + o] = v[e];
                     }
                 }
             }

@@ -21,6 +21,7 @@ struct GemmArgs {
     int seg_k;           // contraction length per segment (= K when one segment)
     int64_t seg_col;     // Q column offset between segments
     int act, out_mode, bias_on_q;
+    int col_group, col_stride, col_off;   // OUT_ROW only: column q is stored at (q / group) * stride + off + q % group (group 0 = identity)
 };
 hipError_t sdfa_launch_gemm(const GemmArgs &a, hipStream_t s);
 

@@ -126,37 +126,41 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_kernel(FreqLstmArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------- time LSTM
+// NT = 32-frame column tiles per workgroup: 2 (64 frames, the throughput shape) or 1 (32 frames: twice the
+// workgroups, used when a chunk would otherwise leave CUs idle).
+template <int NT>
 __global__ __launch_bounds__(512, 2) void time_lstm_kernel(TimeLstmArgs a) {
-    extern __shared__ float4 sHt[];   // [2][64 k-quads][64 sequences]
+    extern __shared__ float4 sHt[];   // [2][64 k-quads][32*NT sequences]
+    constexpr int BT = 32 * NT;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // 8 waves: hidden block of 32
     const int l31 = lane & 31, h = lane >> 5;
     const int dir = blockIdx.x & 1;
-    const int64_t n0 = (int64_t)(blockIdx.x >> 1) * 64;
+    const int64_t n0 = (int64_t)(blockIdx.x >> 1) * BT;
 
     const float4 *__restrict__ GX = reinterpret_cast<const float4 *>(a.GX);
     const float4 *__restrict__ Ww = reinterpret_cast<const float4 *>(a.W) + (size_t)dir * 64 * 1024 + wave * 128 + l31;
     float4 *__restrict__ H = reinterpret_cast<float4 *>(a.H);
 
-    f32x16 c[2];
+    f32x16 c[NT];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) c[j][r] = 0.f;
 
     for (int s = 0; s < 64; ++s) {
         const int t = dir ? 63 - s : s;
         const int64_t mcol = (int64_t)t * a.Nc + n0 + l31;
-        const float4 *sHc = sHt + (size_t)(s & 1) * 64 * 64;
-        float4 *sHn = sHt + (size_t)((s & 1) ^ 1) * 64 * 64;
+        const float4 *sHc = sHt + (size_t)(s & 1) * 64 * BT;
+        float4 *sHn = sHt + (size_t)((s & 1) ^ 1) * 64 * BT;
 
-        f32x16 acc[4][2];
+        f32x16 acc[4][NT];
 #pragma unroll
         for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NT; ++j) {
                     float4 v = GX[(int64_t)(dir * 256 + wave * 32 + gt * 8 + 2 * g + h) * a.Mc + mcol + j * 32];
                     acc[gt][j][4 * g + 0] = v.x; acc[gt][j][4 * g + 1] = v.y;
                     acc[gt][j][4 * g + 2] = v.z; acc[gt][j][4 * g + 3] = v.w;
@@ -172,21 +176,22 @@ __global__ __launch_bounds__(512, 2) void time_lstm_kernel(TimeLstmArgs a) {
                     wn0 = wq[0]; wn1 = wq[32]; wn2 = wq[64]; wn3 = wq[96];
                 }
                 const int kq = 2 * kb + h;
-                const float4 b0 = sHc[kq * 64 + l31], b1 = sHc[kq * 64 + 32 + l31];
-                mfma4(acc[0][0], w0, b0); mfma4(acc[0][1], w0, b1);
-                mfma4(acc[1][0], w1, b0); mfma4(acc[1][1], w1, b1);
-                mfma4(acc[2][0], w2, b0); mfma4(acc[2][1], w2, b1);
-                mfma4(acc[3][0], w3, b0); mfma4(acc[3][1], w3, b1);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const float4 bj = sHc[kq * BT + j * 32 + l31];
+                    mfma4(acc[0][j], w0, bj); mfma4(acc[1][j], w1, bj);
+                    mfma4(acc[2][j], w2, bj); mfma4(acc[3][j], w3, bj);
+                }
             }
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float4 hq;
                 lstm_cell_quad(acc[0][j], acc[1][j], acc[2][j], acc[3][j], c[j], g, hq);
                 const int hq_idx = 8 * wave + 2 * g + h;
-                sHn[hq_idx * 64 + j * 32 + l31] = hq;
+                sHn[hq_idx * BT + j * 32 + l31] = hq;
                 H[(int64_t)(dir * 64 + hq_idx) * a.Mc + mcol + j * 32] = hq;
             }
         __syncthreads();   // h_s complete in sHn before anyone reads it; sHc free for step s+1's writes
@@ -200,15 +205,21 @@ hipError_t sdfa_launch_freq_lstm(const FreqLstmArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t sdfa_launch_time_lstm(const TimeLstmArgs &a, hipStream_t s) {
+template <int NT>
+static hipError_t launch_time(const TimeLstmArgs &a, hipStream_t s) {
     static bool attr_set = false;
-    const size_t lds = 2 * 64 * 64 * sizeof(float4);   // 128 KiB
+    const size_t lds = 2 * 64 * 32 * NT * sizeof(float4);   // 128 KiB (NT 2) / 64 KiB (NT 1)
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(time_lstm_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(time_lstm_kernel<NT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(time_lstm_kernel, dim3((unsigned)(a.Nc / 64 * 2)), dim3(512), lds, s, a);
+    hipLaunchKernelGGL(time_lstm_kernel<NT>, dim3((unsigned)(a.Nc / (32 * NT) * 2)), dim3(512), lds, s, a);
     return hipGetLastError();
+}
+
+hipError_t sdfa_launch_time_lstm(const TimeLstmArgs &a, hipStream_t s) {
+    // 64-frame tiles while they fill the 256 CUs (one 8-wave workgroup per CU); otherwise 32-frame tiles
+    return (a.Nc / 64) * 2 >= 256 ? launch_time<2>(a, s) : launch_time<1>(a, s);
 }
