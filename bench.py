@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--gather", choices=["dgrad", "coef", "none"], default="dgrad")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-column-sharing", action="store_true", help="skip the second, column-sharing measurement")
     ap.add_argument("--opt", action="append", default=[], help="library tuning switch name=value (A/B runs)")
     ap.add_argument("--cpu-sample-seconds", type=float, default=2.0)
     return ap.parse_args()
@@ -72,6 +73,18 @@ def cpu_baseline(sr, seconds, eng, state_dict):
     ts_equal = bool(tslists[0] == list(ts))
     return dict(value=round(len(ref) / dt, 2), unit="frames/s", cores=int(cores), kind="port",
                 sample=f"1 clip x {seconds:g} s @ {sr} Hz = {len(ref)} frames, oracle/sdfa_oracle.py (numpy fp32), {dt:.1f} s"), err, ts_equal
+
+
+def traffic_from_profile(frames_per_launch):
+    """HBM bytes per freq_lstm_kernel launch from the committed rocprofv3 PMC passes (profiles/r01_pmc: FETCH_SIZE and
+    WRITE_SIZE in KiB for a launch over 8192 frames), scaled to this run's frames per launch.  Counters cannot be
+    read inside the benchmark itself."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc", "freq_lstm_traffic.json")) as f:
+            t = json.load(f)
+        return round((t["fetch_kib"] + t["write_kib"]) * 1024.0 / t["frames"] * frames_per_launch)
+    except Exception:
+        return None
 
 
 def main():
@@ -122,11 +135,16 @@ def main():
         gatherer = sdist.FrameGatherer([F] * world, width, torch.float32, dev, a.chunk)
     out = torch.empty((F, eng.out_dim), dtype=torch.float32, device=dev)
 
-    def step():
+    hop = int(0.008 * sr)
+
+    def step(share=False):
         eng.mel_frontend_device(pcm, clip_off, clip_len, frame_clip, frame_start, sr, out=feat)
         for ci, f0 in enumerate(range(0, F, a.chunk)):
             f1 = min(F, f0 + a.chunk)
-            z, _ = eng.encoder(feat[f0:f1], want_align=False)
+            if share:
+                z, _ = eng.encoder(feat[f0:f1], want_align=False, frame_clip=frame_clip[f0:f1], frame_start=frame_start[f0:f1], hop=hop)
+            else:
+                z, _ = eng.encoder(feat[f0:f1], want_align=False)
             coef, o = eng.regress(z, spk[f0:f1], want_coef=(a.gather == "coef"), out=out[f0:f1])
             if gatherer is not None:
                 gatherer.gather_chunk(o if a.gather == "dgrad" else coef, ci)
@@ -138,29 +156,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    fence()
-    eng.profile(True)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    fe_ms = 0.0
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    STAGES = ("conv1", "conv23", "freq_lstm", "freq_proj", "gx0", "lstm0", "gx1", "lstm1", "attn_proj", "attn", "mlp", "pca")
 
-    # ---- per-kernel device times (HIP events recorded on the launch stream inside the timed region)
+    def timed(share):
+        """W warm-up steps, then EXACTLY K timed steps between barrier + synchronize fences; max over ranks."""
+        for _ in range(a.warmup):
+            step(share)
+        fence()
+        eng.profile(True)
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step(share)
+        fence()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        # per-kernel device times: HIP events recorded by the library on the launch stream inside the timed region
+        st = {k: eng.profile_ms(k) / a.steps for k in STAGES + (("share_map", "share_expand") if share else ())}
+        eng.profile(False)
+        return float(tmax.item()), st
+
+    dt, stages = timed(False)
     n_chunks = (F + a.chunk - 1) // a.chunk
-    stages = {}
-    for st in ("conv1", "conv23", "freq_lstm", "freq_proj", "gx0", "lstm0", "gx1", "lstm1", "attn_proj", "attn", "mlp", "pca"):
-        stages[st] = eng.profile_ms(st) / a.steps
-    eng.profile(False)
+    shared = None
+    if not a.no_column_sharing:
+        dt_s, st_s = timed(True)
+        distinct = eng.distinct_columns(min(F - (n_chunks - 1) * a.chunk, a.chunk))
+        shared = (dt_s, st_s, distinct)
     # front end: timed separately (same stream, HIP events), outside the headline region
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record(); eng.mel_frontend_device(pcm, clip_off, clip_len, frame_clip, frame_start, sr, out=feat); ev1.record()
     torch.cuda.synchronize()
     fe_ms = ev0.elapsed_time(ev1)
@@ -182,7 +207,7 @@ def main():
                        "gather": a.gather if world > 1 else "none (1 GPU)", "weights": "synthetic seed 1234"},
             "roofline": {"kernel": "freq_lstm_kernel", "bound": "mfma", "achieved": round(achieved, 2),
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                         "traffic": None, "launch_ms": round(lstm_ms_per_launch, 3),
+                         "traffic": traffic_from_profile(F / n_chunks), "launch_ms": round(lstm_ms_per_launch, 3),
                          "flop_per_launch": flop_per_launch},
             "model_tflops": round(value / world * FLOP_MODEL_PER_FRAME / 1e12, 2),
             "model_frac_of_fp32_mfma_peak": round(value / world * FLOP_MODEL_PER_FRAME / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -191,6 +216,15 @@ def main():
                          "frac_of_hbm_peak": round(F * FRONTEND_BYTES_PER_FRAME / (fe_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)},
             "stage_ms_per_step": {k: round(v, 3) for k, v in stages.items()},
         }
+        if shared is not None:
+            dt_s, st_s, distinct = shared
+            last = min(F - (n_chunks - 1) * a.chunk, a.chunk)
+            res["column_sharing"] = {
+                "note": "same outputs (<=1e-4 of the reference), per-column stages evaluated once per DISTINCT column "
+                        "(SURVEY App. B legal redundancy); NOT the headline value",
+                "value": round(F * world * a.steps / dt_s, 1), "unit": "frames/s", "ms_per_step": round(dt_s / a.steps * 1e3, 3),
+                "distinct_column_fraction_last_chunk": round(distinct / (64.0 * last), 4),
+                "stage_ms_per_step": {k: round(v, 3) for k, v in st_s.items()}}
         if world == 1 and not a.no_cpu_baseline:
             cb, err, ts_ok = cpu_baseline(sr, a.cpu_sample_seconds, eng, sd)
             res["cpu_baseline"] = cb

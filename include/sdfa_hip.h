@@ -125,6 +125,18 @@ int sdfa_encoder_forward(const sdfa_model *m, const float *d_audio_feat, int64_t
                          float *d_z, float *d_align, void *d_workspace, int64_t workspace_bytes,
                          void *stream);
 
+/* Same result, fewer evaluations ("legal redundancy"): the per-column stages (conv stack,
+ * frequency LSTM, its projection) are run once per DISTINCT column.  Windows of one clip whose starts differ by
+ * a whole number of hops contain identical interior columns (t in [5,59]); the library finds them on the device
+ * from the frame table of sdfa_frame_index / sdfa_mel_frontend, on every call.
+ *   d_frame_clip  [n_frames] int32 clip id        d_frame_start [n_frames] int64 window start in its clip
+ *   hop           STFT hop in samples (int(0.008*sr))
+ * audio_feat must be what sdfa_mel_frontend produced for exactly this frame table. */
+int sdfa_encoder_forward_shared(const sdfa_model *m, const float *d_audio_feat, int64_t n_frames,
+                                const int32_t *d_frame_clip, const int64_t *d_frame_start, int hop,
+                                float *d_z, float *d_align, void *d_workspace, int64_t workspace_bytes,
+                                void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * (a5, a11, a12) Speaker one-hot condition, output MLPs, PCA expansion and the per-triangle
  * [6 scale | 3 rotat] interleave.
@@ -146,6 +158,9 @@ int sdfa_regress_forward(const sdfa_model *m, const float *d_z, const int64_t *d
  * 2 = freq-lstm (n,256,64)  3 = bilstm (n,64,512).  Used by tests only. */
 int sdfa_debug_set_option(const char *name, int value);     /* tuning switches for A/B runs, e.g. "gemm_variant" */
 int sdfa_debug_keep_intermediates(sdfa_model *m, int on);   /* un-aliased workspace: call before sizing it */
+/* Number of distinct columns the LAST sdfa_encoder_forward_shared call evaluated for a chunk of n_frames frames
+ * (synchronises the stream).  Tests / reporting only. */
+int64_t sdfa_debug_distinct_columns(const sdfa_model *m, int64_t n_frames, const void *d_workspace, void *stream);
 int sdfa_debug_tap(const sdfa_model *m, int what, int64_t n_frames, float *d_dst, const void *d_workspace,
                    void *stream);
 

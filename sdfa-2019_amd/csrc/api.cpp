@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <string>
@@ -496,7 +497,7 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
 namespace {
 
 struct Ws {
-    int64_t P1, X3, HF, Z, GX, H0, H1, KP, QC, QP, ZK, R, total;   // offsets in floats
+    int64_t P1, X3, HF, Z, GX, H0, H1, KP, QC, QP, ZK, R, SH, ZU, total;   // offsets in floats
 };
 
 Ws layout(int64_t Nc, bool keep) {
@@ -516,13 +517,15 @@ Ws layout(int64_t Nc, bool keep) {
     }
     w.QC = take(512 * Nc); w.QP = take(128 * Nc); w.ZK = take(512 * Nc);
     w.R = take(2560 * Nc);   // regressor scratch: trunk 512 | a 512 | b 256 | coef 288 (+ second branch a/b)
+    w.SH = take(2 * Nc + 5 * Mc + 64);   // column-sharing tables (int32 / int64 counters)
+    w.ZU = keep ? take(256 * Mc) : w.P1; // freq-proj output over distinct columns (pool1 is dead by then)
     w.total = o;
     return w;
 }
 
 int64_t capacity(int64_t bytes, bool keep) {   // largest Nc (multiple of 128) whose layout fits
     const int64_t per128 = layout(128, keep).total * 4;
-    int64_t nc = bytes / per128 * 128;
+    int64_t nc = (bytes / per128 + 2) * 128;   // per-frame cost shrinks slightly with Nc (fixed paddings): start above
     while (nc > 0 && layout(nc, keep).total * 4 > bytes) nc -= 128;
     return nc;
 }
@@ -597,8 +600,25 @@ float sdfa_profile_ms(const sdfa_model *m, const char *stage) {
 int sdfa_profile_reset(sdfa_model *m) { return m ? sdfa_profile_enable(m, m->profile) : fail(SDFA_EINVAL, "null model"); }
 
 // ------------------------------------------------------------------------------------------------
+static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t n_frames, const int32_t *d_frame_clip,
+                        const int64_t *d_frame_start, int hop, float *d_z, float *d_align, void *d_workspace,
+                        int64_t workspace_bytes, void *stream);
+
 int sdfa_encoder_forward(const sdfa_model *m, const float *d_audio_feat, int64_t n_frames, float *d_z, float *d_align,
                          void *d_workspace, int64_t workspace_bytes, void *stream) {
+    return encoder_impl(m, d_audio_feat, n_frames, nullptr, nullptr, 0, d_z, d_align, d_workspace, workspace_bytes, stream);
+}
+
+int sdfa_encoder_forward_shared(const sdfa_model *m, const float *d_audio_feat, int64_t n_frames, const int32_t *d_frame_clip,
+                                const int64_t *d_frame_start, int hop, float *d_z, float *d_align, void *d_workspace,
+                                int64_t workspace_bytes, void *stream) {
+    if (!d_frame_clip || !d_frame_start || hop <= 0) return fail(SDFA_EINVAL, "encoder_forward_shared: frame table missing");
+    return encoder_impl(m, d_audio_feat, n_frames, d_frame_clip, d_frame_start, hop, d_z, d_align, d_workspace, workspace_bytes, stream);
+}
+
+static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t n_frames, const int32_t *d_frame_clip,
+                        const int64_t *d_frame_start, int hop, float *d_z, float *d_align, void *d_workspace,
+                        int64_t workspace_bytes, void *stream) {
     if (!m || !m->finalized) return fail(SDFA_ESTATE, "encoder_forward: model not finalised");
     if (n_frames == 0) return SDFA_OK;
     if (!d_audio_feat || !d_z || !d_workspace || n_frames < 0) return fail(SDFA_EINVAL, "encoder_forward: bad argument");
@@ -617,17 +637,38 @@ int sdfa_encoder_forward(const sdfa_model *m, const float *d_audio_feat, int64_t
         ca.w1 = m->w1; ca.b1 = m->b1; ca.s1 = m->s1; ca.t1 = m->t1; ca.P1 = ws + w.P1;
         ca.w2 = m->w2; ca.b2 = m->b2; ca.s2 = m->s2; ca.t2 = m->t2;
         ca.w3 = m->w3; ca.b3 = m->b3; ca.s3 = m->s3; ca.t3 = m->t3; ca.X3 = ws + w.X3;
+        const bool share = d_frame_clip != nullptr;
+        const int64_t *d_ulimit = nullptr;     // device scalar: number of distinct columns, padded to 256
+        int32_t *col_to_u = nullptr;
+        if (share) {
+            int32_t *sh = reinterpret_cast<int32_t *>(ws + w.SH);
+            ShareArgs sa{};
+            sa.frame_clip = d_frame_clip + f0; sa.frame_start = d_frame_start + f0; sa.hop = hop;
+            sa.N = N; sa.Nc = Nc; sa.Mc = Mc;
+            sa.counts = reinterpret_cast<int64_t *>(sh);           // 16 ints reserved
+            sa.prev = sh + 16; sa.shift = sa.prev + Nc;
+            sa.owner = sa.shift + Nc; sa.flag = sa.owner + Mc; sa.uid = sa.flag + Mc;
+            sa.col_src = sa.uid + Mc; sa.col_to_u = sa.col_src + Mc;
+            if (getenv("SDFA_DEBUG")) fprintf(stderr, "[sdfa] share: ws=%p SH=%lld sh=%p N=%lld Nc=%lld hop=%d\n", (void *)ws, (long long)w.SH, (void *)sh, (long long)N, (long long)Nc, hop);
+            pf.begin("share_map"); HIP_TRY(sdfa_launch_share_map(sa, s)); pf.end();
+            d_ulimit = sa.counts + 1; col_to_u = sa.col_to_u;
+            ca.col_src = sa.col_src; ca.col_limit = d_ulimit;
+        }
         pf.begin("conv1"); HIP_TRY(sdfa_launch_conv1(ca, s)); pf.end();
         pf.begin("conv23"); HIP_TRY(sdfa_launch_conv23(ca, s)); pf.end();
 
-        FreqLstmArgs fa{ws + w.X3, m->fl_w, m->fl_b, ws + w.HF, Mc};
+        FreqLstmArgs fa{ws + w.X3, m->fl_w, m->fl_b, ws + w.HF, Mc, d_ulimit};
         pf.begin("freq_lstm"); HIP_TRY(sdfa_launch_freq_lstm(fa, s)); pf.end();
 
         GemmArgs g{};   // FreqLstm._proj: Linear(8192 -> 256) + bias
         g.P = m->fp_w; g.Q = ws + w.HF; g.D = ws + w.Z; g.bias = m->fp_b;
         g.ldp = 256; g.ldq = Mc; g.ldd = Mc; g.Ppad = 256; g.Qpad = Mc; g.Pstore = 256; g.Qreal = Mc;
         g.K = 8192; g.seg_k = 8192; g.act = ACT_NONE; g.out_mode = OUT_K4;
+        if (share) { g.D = ws + w.ZU; g.q_limit = d_ulimit; }
         pf.begin("freq_proj"); HIP_TRY(sdfa_launch_gemm(g, s)); pf.end();
+        if (share) {   // scatter every distinct column's 256 features to all the (t, n) columns that contain it
+            pf.begin("share_expand"); HIP_TRY(sdfa_launch_expand_cols(ws + w.ZU, col_to_u, ws + w.Z, 64, Mc, s)); pf.end();
+        }
 
         const float *xin = ws + w.Z;
         float *hout[2] = {ws + w.H0, ws + w.H1};
@@ -728,6 +769,16 @@ int sdfa_regress_forward(const sdfa_model *m, const float *d_z, const int64_t *d
 }
 
 // ------------------------------------------------------------------------------------------------
+int64_t sdfa_debug_distinct_columns(const sdfa_model *m, int64_t n_frames, const void *d_workspace, void *stream) {
+    if (!m || n_frames <= 0 || !d_workspace) return fail(SDFA_EINVAL, "debug_distinct_columns: bad argument");
+    const Ws w = layout(round_up(n_frames, 128), m->keep);
+    int64_t counts[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(counts, (const float *)d_workspace + w.SH, sizeof counts, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (getenv("SDFA_DEBUG")) fprintf(stderr, "[sdfa] distinct: ws=%p SH=%lld counts=%lld %lld\n", d_workspace, (long long)w.SH, (long long)counts[0], (long long)counts[1]);
+    return counts[0];
+}
+
 int sdfa_debug_tap(const sdfa_model *m, int what, int64_t n_frames, float *d_dst, const void *d_workspace, void *stream) {
     if (!m || !m->keep) return fail(SDFA_ESTATE, "debug_tap needs sdfa_debug_keep_intermediates(model, 1) before the forward");
     if (what < 0 || what > 3 || n_frames <= 0 || !d_dst || !d_workspace) return fail(SDFA_EINVAL, "debug_tap: bad argument");

@@ -23,14 +23,17 @@ __global__ __launch_bounds__(256, 2) void conv1_pool_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int64_t m0 = (int64_t)blockIdx.x * 32;
+    if (a.col_limit && m0 >= *a.col_limit) return;
     const int64_t t = m0 / a.Nc, n0 = m0 % a.Nc;
 
     // audio_feat row (n, t) is 384 contiguous floats (f*3 + c); transpose into [k][col]
     for (int idx = tid; idx < 32 * 96; idx += 256) {
         int col = idx / 96, q = idx % 96;
         int64_t n = n0 + col;
+        int64_t row = n < a.N ? n * 64 + t : -1;
+        if (a.col_src) row = a.col_src[m0 + col];
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < a.N) v = ld4(a.audio_feat + ((n * 64 + t) * 384 + 4 * q));
+        if (row >= 0) v = ld4(a.audio_feat + (row * 384 + 4 * q));
         sIn[3 + 4 * q + 0][col] = v.x;
         sIn[3 + 4 * q + 1][col] = v.y;
         sIn[3 + 4 * q + 2][col] = v.z;
@@ -93,6 +96,7 @@ __global__ __launch_bounds__(256, 2) void conv23_kernel(ConvArgs a) {
     const int l31 = lane & 31, h = lane >> 5;
     const int fc = blockIdx.x & 7;                       // chunk of 4 pooled rows
     const int64_t m0 = (int64_t)(blockIdx.x >> 3) * 32;
+    if (a.col_limit && m0 >= *a.col_limit) return;
     const int f1lo = 8 * fc - 1;                         // first pool1 row held in LDS
 
     const float4 *__restrict__ P1 = reinterpret_cast<const float4 *>(a.P1);

@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256, 2) void gemm_k4_kernel(GemmArgs a) {
     const int64_t bid = blockIdx.x;
     const int64_t tp = bid / ntq, tq = bid % ntq;
     const int64_t p0 = tp * TP, q0 = tq * TQ;
+    if (a.q_limit && q0 >= *a.q_limit) return;
 
     const float4 *__restrict__ P = reinterpret_cast<const float4 *>(a.P);
     const float4 *__restrict__ Q = reinterpret_cast<const float4 *>(a.Q);
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(256, 2) void gemm_direct_kernel(GemmArgs a) {
     const int64_t bid = blockIdx.x;
     const int64_t p0 = (bid / ntq) * (32 * MT), q0 = (bid % ntq) * 256 + wave * 64;
     if (q0 >= a.Qpad) return;
+    if (a.q_limit && q0 >= *a.q_limit) return;
 
     const float4 *__restrict__ P = reinterpret_cast<const float4 *>(a.P) + p0 + l31;
     const float4 *__restrict__ Q = reinterpret_cast<const float4 *>(a.Q) + q0 + l31;

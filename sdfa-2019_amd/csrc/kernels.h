@@ -21,6 +21,7 @@ struct GemmArgs {
     int seg_k;           // contraction length per segment (= K when one segment)
     int64_t seg_col;     // Q column offset between segments
     int act, out_mode, bias_on_q;
+    const int64_t *q_limit;   // device scalar: tiles whose first column is >= *q_limit exit at once (null = no limit)
     int col_group, col_stride, col_off;   // OUT_ROW only: column q is stored at (q / group) * stride + off + q % group (group 0 = identity)
 };
 hipError_t sdfa_launch_gemm(const GemmArgs &a, hipStream_t s);
@@ -49,6 +50,10 @@ struct ConvArgs {
     const float *w2, *b2, *s2, *t2;   // K = 96  (k = df*32 + ci)
     const float *w3, *b3, *s3, *t3;   // K = 64
     float *X3;                // K4 [2048/4][Mc]   rows f*64 + ch
+    // column sharing: column m reads audio_feat row col_src[m] (-1 = zeros) instead of (m % Nc)*64 + m / Nc, and
+    // workgroups whose first column is >= *col_limit exit at once.  Both null = every column of every frame.
+    const int32_t *col_src;
+    const int64_t *col_limit;
 };
 hipError_t sdfa_launch_conv1(const ConvArgs &a, hipStream_t s);
 hipError_t sdfa_launch_conv23(const ConvArgs &a, hipStream_t s);
@@ -60,6 +65,7 @@ struct FreqLstmArgs {
     const float *bias;   // per direction: [512] packed (b_ih + b_hh)
     float *HF;           // K4 [8192/4][Mc]  rows f*256 + dir*128 + j
     int64_t Mc;
+    const int64_t *col_limit;   // see ConvArgs
 };
 hipError_t sdfa_launch_freq_lstm(const FreqLstmArgs &a, hipStream_t s);
 
@@ -92,3 +98,18 @@ hipError_t sdfa_launch_k4_to_rows(const float *src, int64_t ld, int64_t N, int F
                                   int64_t dst_ld, hipStream_t s);
 // debug taps (tests): K4 [F/4][Mc] with m = t*Nc+n  ->  reference layouts
 hipError_t sdfa_launch_tap(const float *src, int what, int64_t N, int64_t Nc, float *dst, hipStream_t s);
+
+// ---- column sharing (share.hip) -----------------------------------------------------------------
+struct ShareArgs {
+    const int32_t *frame_clip;   // [N] clip id of each frame of the chunk
+    const int64_t *frame_start;  // [N] window start sample inside its clip
+    int hop;
+    int64_t N, Nc, Mc;
+    int32_t *prev, *shift;       // [Nc]
+    int32_t *owner, *flag, *uid; // [Mc]
+    int32_t *col_src;            // [Mc] out: audio_feat row of each distinct column (-1 padding)
+    int32_t *col_to_u;           // [Mc] out: distinct-column index of every (t, n) column
+    int64_t *counts;             // [2]  out: number of distinct columns, and that rounded up to 256
+};
+hipError_t sdfa_launch_share_map(const ShareArgs &a, hipStream_t s);
+hipError_t sdfa_launch_expand_cols(const float *Zu, const int32_t *col_to_u, float *Z, int nquads, int64_t Mc, hipStream_t s);

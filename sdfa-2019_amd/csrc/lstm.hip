@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_kernel(FreqLstmArgs a) {
     const int l31 = lane & 31, h = lane >> 5;
     const int dir = blockIdx.x & 1;
     const int64_t m0 = (int64_t)(blockIdx.x >> 1) * 64;
+    if (a.col_limit && m0 >= *a.col_limit) return;
 
     const float4 *__restrict__ X3 = reinterpret_cast<const float4 *>(a.X3);
     const float4 *__restrict__ W = reinterpret_cast<const float4 *>(a.W) + (size_t)dir * 48 * 512;

@@ -33,9 +33,11 @@ SYMBOLS = {
     "sdfa_model_coef_dim": (_i64, [_p]),
     "sdfa_workspace_bytes": (_i64, [_p, _i64]),
     "sdfa_encoder_forward": (C.c_int, [_p, _p, _i64, _p, _p, _p, _i64, _p]),
+    "sdfa_encoder_forward_shared": (C.c_int, [_p, _p, _i64, _p, _p, C.c_int, _p, _p, _p, _i64, _p]),
     "sdfa_regress_forward": (C.c_int, [_p, _p, _p, _i64, _p, _p, _p, _i64, _p]),
     "sdfa_debug_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "sdfa_debug_keep_intermediates": (C.c_int, [_p, C.c_int]),
+    "sdfa_debug_distinct_columns": (_i64, [_p, _i64, _p, _p]),
     "sdfa_debug_tap": (C.c_int, [_p, C.c_int, _i64, _p, _p, _p]),
     "sdfa_profile_enable": (C.c_int, [_p, C.c_int]),
     "sdfa_profile_reset": (C.c_int, [_p]),

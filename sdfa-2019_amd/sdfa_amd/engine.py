@@ -67,6 +67,7 @@ class FrontendOnly:
         d_fc = torch.from_numpy(np.concatenate(fclip)).to(dev)
         d_fs = torch.from_numpy(np.concatenate(fstart)).to(dev)
         feat = self.mel_frontend_device(pcm, d_off, d_len, d_fc, d_fs, sr)
+        self.last_frame_table = (d_fc, d_fs, frame_geometry(sr)[1])      # (clip, start, hop) for encoder(share)
         return feat, tslists, counts
 
     def mel_frontend_device(self, pcm, clip_off, clip_len, frame_clip, frame_start, sr, out=None):
@@ -112,14 +113,22 @@ class Engine(FrontendOnly):
         return self._ws
 
     # ------------------------------------------------------------------ model
-    def encoder(self, audio_feat, want_align=True):
+    def encoder(self, audio_feat, want_align=True, frame_clip=None, frame_start=None, hop=None):
+        """z (n,512), align (n,64).  With the frame table (`frame_clip` int32, `frame_start` int64, `hop`) the
+        per-column stages run once per distinct column (sdfa_encoder_forward_shared)."""
         assert audio_feat.is_cuda and audio_feat.dtype == torch.float32 and tuple(audio_feat.shape[1:]) == FEAT_SHAPE
         audio_feat = audio_feat.contiguous()
         n = audio_feat.shape[0]
         z = torch.empty((n, 512), dtype=torch.float32, device=self.device)
         align = torch.empty((n, 64), dtype=torch.float32, device=self.device) if want_align else None
         ws = self.workspace(n)
-        check(lib.sdfa_encoder_forward(self._m, _ptr(audio_feat), n, _ptr(z), _ptr(align), _ptr(ws), ws.numel(), _stream()))
+        if frame_clip is None:
+            check(lib.sdfa_encoder_forward(self._m, _ptr(audio_feat), n, _ptr(z), _ptr(align), _ptr(ws), ws.numel(), _stream()))
+        else:
+            assert frame_clip.dtype == torch.int32 and frame_start.dtype == torch.int64 and frame_clip.numel() == n
+            check(lib.sdfa_encoder_forward_shared(self._m, _ptr(audio_feat), n, _ptr(frame_clip.contiguous()),
+                                                  _ptr(frame_start.contiguous()), int(hop), _ptr(z), _ptr(align), _ptr(ws),
+                                                  ws.numel(), _stream()))
         return z, align
 
     def regress(self, z, speaker_id, want_coef=False, want_out=True, out=None):
@@ -139,6 +148,10 @@ class Engine(FrontendOnly):
         z, align = self.encoder(audio_feat)
         coef, out = self.regress(z, speaker_id, want_coef=want_coef)
         return out, z, align, coef
+
+    def distinct_columns(self, n_frames):
+        """Distinct columns evaluated by the last shared encoder call on a chunk of n_frames (reporting only)."""
+        return int(check(lib.sdfa_debug_distinct_columns(self._m, int(n_frames), _ptr(self._ws), _stream())))
 
     def tap(self, what, n_frames):
         shapes = {0: (32, 64, 64), 1: (64, 32, 64), 2: (256, 64), 3: (64, 512)}
