@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void gemm_k4_kernel(GemmArgs a) {
             float bq = 0.f;
             if (BIAS_Q) bq = (q < a.Qreal) ? a.bias[q] : 0.f;
             int spk = 0;
-            if (COND) spk = (int)a.cond_idx[q < a.Qreal ? q : 0];
+            if (COND) { spk = (int)a.cond_idx[q < a.Qreal ? q : 0]; spk = spk < 0 ? 0 : (spk > 7 ? 7 : spk); }   // ids are validated on the host; clamp keeps the read in bounds
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int64_t p = p0 + wp * 64 + i * 32 + 8 * g + 4 * h;   // rows p..p+3
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void gemm_direct_kernel(GemmArgs a) {
             float bq = 0.f;
             if (BIAS_Q) bq = (q < a.Qreal) ? a.bias[q] : 0.f;
             int spk = 0;
-            if (COND) spk = (int)a.cond_idx[q < a.Qreal ? q : 0];
+            if (COND) { spk = (int)a.cond_idx[q < a.Qreal ? q : 0]; spk = spk < 0 ? 0 : (spk > 7 ? 7 : spk); }   // ids are validated on the host; clamp keeps the read in bounds
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int64_t p = p0 + i * 32 + 8 * g + 4 * h;

@@ -121,6 +121,8 @@ class Engine(FrontendOnly):
         n = audio_feat.shape[0]
         z = torch.empty((n, 512), dtype=torch.float32, device=self.device)
         align = torch.empty((n, 64), dtype=torch.float32, device=self.device) if want_align else None
+        if n == 0:
+            return z, align
         ws = self.workspace(n)
         if frame_clip is None:
             check(lib.sdfa_encoder_forward(self._m, _ptr(audio_feat), n, _ptr(z), _ptr(align), _ptr(ws), ws.numel(), _stream()))
@@ -134,11 +136,17 @@ class Engine(FrontendOnly):
     def regress(self, z, speaker_id, want_coef=False, want_out=True, out=None):
         n = z.shape[0]
         z = z.contiguous()
+        if not speaker_id.is_cuda and speaker_id.numel():
+            lo, hi = int(speaker_id.min()), int(speaker_id.max())
+            if lo < 0 or hi >= 8:      # the reference's one_hot scatter_ raises on such an index (saber/nn/functions.py:375-378)
+                raise RuntimeError(f"index {hi if hi >= 8 else lo} is out of bounds for dimension 1 with size 8")
         spk = speaker_id.to(device=self.device, dtype=torch.int64).contiguous()
         assert spk.numel() == n
         coef = torch.empty((n, self.coef_dim), dtype=torch.float32, device=self.device) if want_coef else None
         if want_out and out is None:
             out = torch.empty((n, self.out_dim), dtype=torch.float32, device=self.device)
+        if n == 0:
+            return coef, out
         ws = self.workspace(n)
         check(lib.sdfa_regress_forward(self._m, _ptr(z), _ptr(spk), n, _ptr(coef), _ptr(out) if want_out else None,
                                        _ptr(ws), ws.numel(), _stream()))

@@ -208,3 +208,20 @@ def test_shared_columns_chunked(synth_sd):
     zb, _ = b.encoder(feat, frame_clip=fc, frame_start=fs, hop=hop)
     zc, _ = b.encoder(feat)
     assert (za - zc).abs().max().item() <= 2e-5 and (zb - zc).abs().max().item() <= 2e-5
+
+
+# ------------------------------------------------------------------------------------------- error behaviour
+def test_error_paths(eng, synth_sd):
+    from sdfa_amd._lib import SdfaError
+    with pytest.raises(SdfaError):                       # unsupported sample rate
+        eng.mel_frontend([synth.make_pcm(0, 44100)], 44100 // 2)
+    with pytest.raises(AssertionError):                  # clip shorter than one window: the reference asserts
+        eng.mel_frontend([synth.make_pcm(0, 3000)], 16000)
+    z = torch.zeros((2, 512), device="cuda")
+    with pytest.raises(RuntimeError):                    # speaker id outside the 8-way one-hot
+        eng.regress(z, torch.tensor([0, 8]))
+    zz, al = eng.encoder(torch.zeros((0, 64, 128, 3), device="cuda"))     # empty batch is a no-op
+    assert zz.shape == (0, 512) and al.shape == (0, 64)
+    bad = {k: v for k, v in synth_sd["dgrad"].items() if "proj_key" not in k}
+    with pytest.raises(SdfaError):                       # missing tensor -> SDFA_ESTATE at finalize
+        Engine(bad)
