@@ -517,7 +517,7 @@ Ws layout(int64_t Nc, bool keep) {
     }
     w.QC = take(512 * Nc); w.QP = take(128 * Nc); w.ZK = take(512 * Nc);
     w.R = take(2560 * Nc);   // regressor scratch: trunk 512 | a 512 | b 256 | coef 288 (+ second branch a/b)
-    w.SH = take(2 * Nc + 5 * Mc + 64);   // column-sharing tables (int32 / int64 counters)
+    w.SH = take(2 * Nc + 5 * Mc + Mc / 1024 + 128);   // column-sharing tables (int32 / int64 counters)
     w.ZU = keep ? take(256 * Mc) : w.P1; // freq-proj output over distinct columns (pool1 is dead by then)
     w.total = o;
     return w;
@@ -648,7 +648,7 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
             sa.counts = reinterpret_cast<int64_t *>(sh);           // 16 ints reserved
             sa.prev = sh + 16; sa.shift = sa.prev + Nc;
             sa.owner = sa.shift + Nc; sa.flag = sa.owner + Mc; sa.uid = sa.flag + Mc;
-            sa.col_src = sa.uid + Mc; sa.col_to_u = sa.col_src + Mc;
+            sa.col_src = sa.uid + Mc; sa.col_to_u = sa.col_src + Mc; sa.tile_sum = sa.col_to_u + Mc;
             if (getenv("SDFA_DEBUG")) fprintf(stderr, "[sdfa] share: ws=%p SH=%lld sh=%p N=%lld Nc=%lld hop=%d\n", (void *)ws, (long long)w.SH, (void *)sh, (long long)N, (long long)Nc, hop);
             pf.begin("share_map"); HIP_TRY(sdfa_launch_share_map(sa, s)); pf.end();
             d_ulimit = sa.counts + 1; col_to_u = sa.col_to_u;

@@ -107,6 +107,7 @@ struct ShareArgs {
     int64_t N, Nc, Mc;
     int32_t *prev, *shift;       // [Nc]
     int32_t *owner, *flag, *uid; // [Mc]
+    int32_t *tile_sum;           // [Mc/1024 + 1] scan scratch
     int32_t *col_src;            // [Mc] out: audio_feat row of each distinct column (-1 padding)
     int32_t *col_to_u;           // [Mc] out: distinct-column index of every (t, n) column
     int64_t *counts;             // [2]  out: number of distinct columns, and that rounded up to 256

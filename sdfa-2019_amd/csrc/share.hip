@@ -53,39 +53,57 @@ __global__ void share_owner_kernel(ShareArgs a) {
     a.flag[m] = o == m ? 1 : 0;
 }
 
-// single-workgroup exclusive scan of flag[0..Mc) -> uid; counts[0] = Mu, counts[1] = Mu rounded up to 256
-__global__ __launch_bounds__(1024) void share_scan_kernel(ShareArgs a) {
-    __shared__ int part[1024];
+// Exclusive scan of flag[0..Mc) -> uid in three small launches: per-tile (1024 columns) scan + tile sums, a
+// single-workgroup scan of the tile sums, then the per-tile fix-up that also writes the compacted source rows.
+__device__ __forceinline__ int block_inclusive_scan_1024(int v, int *part) {
     const int tid = threadIdx.x;
-    const int64_t per = (a.Mc + 1023) / 1024, lo = tid * per, hi = lo + per < a.Mc ? lo + per : a.Mc;
-    int sum = 0;
-    for (int64_t i = lo; i < hi; ++i) sum += a.flag[i];
-    part[tid] = sum;
+    part[tid] = v;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
-        int v = tid >= off ? part[tid - off] : 0;
+        const int x = tid >= off ? part[tid - off] : 0;
         __syncthreads();
-        part[tid] += v;
+        part[tid] += x;
         __syncthreads();
     }
-    int run = part[tid] - sum;
-    for (int64_t i = lo; i < hi; ++i) {
-        const int f = a.flag[i];
-        a.uid[i] = run;
-        if (f) {
-            const int64_t n = i % a.Nc, t = i / a.Nc;
-            a.col_src[run] = (int)(n * 64 + t);     // row of audio_feat viewed as [N*64][384]
-        }
-        run += f;
+    return part[tid];
+}
+
+__global__ __launch_bounds__(1024) void share_scan_tiles_kernel(ShareArgs a) {
+    __shared__ int part[1024];
+    const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    const int f = i < a.Mc ? a.flag[i] : 0;
+    const int inc = block_inclusive_scan_1024(f, part);
+    if (i < a.Mc) a.uid[i] = inc - f;                 // exclusive, tile-local
+    if (threadIdx.x == 1023) a.tile_sum[blockIdx.x] = inc;
+}
+
+__global__ __launch_bounds__(1024) void share_scan_sums_kernel(ShareArgs a, int ntiles) {
+    __shared__ int part[1024];
+    int carry = 0;
+    for (int base = 0; base < ntiles; base += 1024) {
+        const int t = base + threadIdx.x;
+        const int v = t < ntiles ? a.tile_sum[t] : 0;
+        const int inc = block_inclusive_scan_1024(v, part);
+        if (t < ntiles) a.tile_sum[t] = carry + inc - v;   // exclusive offset of the tile
+        carry += part[1023];
+        __syncthreads();
     }
-    if (tid == 1023) {
-        const int64_t mu = part[1023], pad = (mu + 255) / 256 * 256;
+    if (threadIdx.x == 0) {
+        const int64_t mu = carry, pad = (mu + 255) / 256 * 256;
         a.counts[0] = mu;
         a.counts[1] = pad;
     }
-    __syncthreads();
-    const int64_t mu = part[1023], pad = (mu + 255) / 256 * 256;
-    for (int64_t i = mu + tid; i < pad; i += 1024) a.col_src[i] = -1;   // padding columns read zeros
+}
+
+__global__ __launch_bounds__(1024) void share_scan_fix_kernel(ShareArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    const int64_t mu = a.counts[0], pad = a.counts[1];
+    if (i < a.Mc) {
+        const int u = a.uid[i] + a.tile_sum[blockIdx.x];
+        a.uid[i] = u;
+        if (a.flag[i]) a.col_src[u] = (int)((i % a.Nc) * 64 + i / a.Nc);     // row of audio_feat viewed as [N*64][384]
+    }
+    if (i >= mu && i < pad) a.col_src[i] = -1;        // padding columns read zeros (disjoint from the writes above: u < mu)
 }
 
 __global__ void share_assign_kernel(ShareArgs a) {
@@ -109,7 +127,10 @@ __global__ void expand_cols_kernel(const float4 *__restrict__ Zu, const int32_t 
 hipError_t sdfa_launch_share_map(const ShareArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(share_prev_kernel, dim3((unsigned)((a.Nc + 255) / 256)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(share_owner_kernel, dim3((unsigned)((a.Mc + 255) / 256)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(share_scan_kernel, dim3(1), dim3(1024), 0, s, a);
+    const int ntiles = (int)((a.Mc + 1023) / 1024);
+    hipLaunchKernelGGL(share_scan_tiles_kernel, dim3(ntiles), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(share_scan_sums_kernel, dim3(1), dim3(1024), 0, s, a, ntiles);
+    hipLaunchKernelGGL(share_scan_fix_kernel, dim3(ntiles), dim3(1024), 0, s, a);
     hipLaunchKernelGGL(share_assign_kernel, dim3((unsigned)((a.Mc + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
