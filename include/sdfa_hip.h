@@ -171,6 +171,26 @@ int   sdfa_profile_enable(sdfa_model *m, int on);
 int   sdfa_profile_reset(sdfa_model *m);
 float sdfa_profile_ms(const sdfa_model *m, const char *stage);
 
+/* ------------------------------------------------------------------------------------------
+ * NEXT ROW: dgrad -> mesh, the deformation-transfer solve that consumes this path's
+ * output.  Replaces the reference's native module deformation.set_target / deformation.get_mesh
+ * (deformation/cpp/src/pybind.cpp:13-33,101-117; deform_triangle_impl.hpp:8-140,215-310;
+ * rotation/utils_rotation.cpp:33-49), called per video frame from speech_anime/viewer/frame.py:102-141.
+ *
+ * sdfa_mesh_create = set_target(verts, faces, cnsts, reg=1e-10) without triangle correspondences: builds the
+ * per-triangle pseudo-inverse system over the free (un-constrained) vertices and factors it once (host, fp64).
+ * sdfa_mesh_from_dgrad = get_mesh for n frames at once, constrained vertices pinned to their template positions
+ * (what frame.py passes as vert_cnsts):
+ *   d_dgrad [n_frames][n_tris*9] float32 (the rows sdfa_regress_forward writes) -> d_verts [n_frames][n_verts][3].
+ * ---------------------------------------------------------------------------------------- */
+typedef struct sdfa_mesh sdfa_mesh;
+sdfa_mesh *sdfa_mesh_create(const float *h_verts, int64_t n_verts, const uint32_t *h_faces, int64_t n_tris,
+                            const uint32_t *h_cnsts, int64_t n_cnsts, double reg, void *stream);
+void       sdfa_mesh_destroy(sdfa_mesh *mesh);
+int64_t    sdfa_mesh_workspace_bytes(const sdfa_mesh *mesh, int64_t n_frames);
+int        sdfa_mesh_from_dgrad(const sdfa_mesh *mesh, const float *d_dgrad, int64_t n_frames, float *d_verts,
+                                void *d_workspace, int64_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -787,6 +788,176 @@ int sdfa_debug_tap(const sdfa_model *m, int what, int64_t n_frames, float *d_dst
     const float *ws = (const float *)d_workspace;
     const float *src = what == 0 ? ws + w.P1 : what == 1 ? ws + w.X3 : what == 2 ? ws + w.Z : ws + w.H1;
     HIP_TRY(sdfa_launch_tap(src, what, n_frames, Nc, d_dst, (hipStream_t)stream));
+    return SDFA_OK;
+}
+
+}  // extern "C"
+
+// ================================================================================================
+// next row: dgrad -> mesh (deformation transfer solve)
+// ================================================================================================
+struct sdfa_mesh {
+    int n_verts = 0, n_tris = 0, n_free = 0, free_pad = 0;
+    void *blob = nullptr;
+    const int *inc_ptr, *inc_tri, *vert_col;
+    const float *inc_coef, *tmpl, *inv_k4;
+};
+
+extern "C" {
+
+sdfa_mesh *sdfa_mesh_create(const float *h_verts, int64_t n_verts, const uint32_t *h_faces, int64_t n_tris,
+                            const uint32_t *h_cnsts, int64_t n_cnsts, double reg, void *stream) {
+    if (!h_verts || !h_faces || n_verts <= 0 || n_tris <= 0 || n_cnsts < 0 || (n_cnsts && !h_cnsts)) {
+        fail(SDFA_EINVAL, "mesh_create: bad argument");
+        return nullptr;
+    }
+    // vertex -> free column (deform_triangle_impl.hpp:36-72: constrained vertices leave A for Ar)
+    std::vector<int> col(n_verts, 0);
+    for (int64_t i = 0; i < n_cnsts; ++i) {
+        if (h_cnsts[i] >= (uint32_t)n_verts) { fail(SDFA_EINVAL, "mesh_create: constraint index out of range"); return nullptr; }
+        col[h_cnsts[i]] = -1;
+    }
+    int nf = 0;
+    for (int64_t v = 0; v < n_verts; ++v) col[v] = col[v] < 0 ? -1 : nf++;
+    if (nf == 0) { fail(SDFA_EINVAL, "mesh_create: every vertex is constrained"); return nullptr; }
+    const int fp = (int)round_up(nf, 128);
+    // per-triangle U = pinv([v2-v1, v3-v1]) (2x3); A rows 3j..3j+2: v1 -> -U0-U1, v2 -> U0, v3 -> U1   (:81-118)
+    std::vector<std::vector<std::pair<int, std::array<double, 3>>>> inc(nf);
+    std::vector<double> AtA((size_t)nf * nf, 0.0);
+    for (int64_t j = 0; j < n_tris; ++j) {
+        const uint32_t vi[3] = {h_faces[3 * j], h_faces[3 * j + 1], h_faces[3 * j + 2]};
+        for (int k = 0; k < 3; ++k)
+            if (vi[k] >= (uint32_t)n_verts) { fail(SDFA_EINVAL, "mesh_create: face index out of range"); return nullptr; }
+        double e1[3], e2[3];
+        for (int k = 0; k < 3; ++k) {   // the reference subtracts in float (Eigen::Vector3f) before widening
+            e1[k] = (double)(float)(h_verts[3 * vi[1] + k] - h_verts[3 * vi[0] + k]);
+            e2[k] = (double)(float)(h_verts[3 * vi[2] + k] - h_verts[3 * vi[0] + k]);
+        }
+        const double g11 = e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2], g22 = e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2];
+        const double g12 = e1[0] * e2[0] + e1[1] * e2[1] + e1[2] * e2[2], det = g11 * g22 - g12 * g12;
+        if (!(det > 0)) { fail(SDFA_EINVAL, "mesh_create: degenerate triangle %lld", (long long)j); return nullptr; }
+        std::array<double, 3> u0, u1, c[3];
+        for (int k = 0; k < 3; ++k) {
+            u0[k] = (g22 * e1[k] - g12 * e2[k]) / det;
+            u1[k] = (-g12 * e1[k] + g11 * e2[k]) / det;
+            c[0][k] = -u0[k] - u1[k]; c[1][k] = u0[k]; c[2][k] = u1[k];
+        }
+        for (int a = 0; a < 3; ++a) {
+            const int ca = col[vi[a]];
+            if (ca < 0) continue;
+            inc[ca].push_back({(int)j, c[a]});
+            for (int b = 0; b < 3; ++b) {
+                const int cb = col[vi[b]];
+                if (cb >= 0) AtA[(size_t)ca * nf + cb] += c[a][0] * c[b][0] + c[a][1] * c[b][1] + c[a][2] * c[b][2];
+            }
+        }
+    }
+    for (int i = 0; i < nf; ++i) AtA[(size_t)i * nf + i] += reg;   // :125-131
+    // dense Cholesky A^T A = L L^T, then (A^T A)^-1 = L^-T L^-1, all in fp64
+    std::vector<double> &L = AtA;
+    for (int j = 0; j < nf; ++j) {
+        double d = L[(size_t)j * nf + j];
+        for (int k = 0; k < j; ++k) d -= L[(size_t)j * nf + k] * L[(size_t)j * nf + k];
+        if (!(d > 0)) { fail(SDFA_EINVAL, "mesh_create: system matrix not positive definite (column %d)", j); return nullptr; }
+        const double ljj = std::sqrt(d);
+        L[(size_t)j * nf + j] = ljj;
+        for (int i = j + 1; i < nf; ++i) {
+            double v = L[(size_t)i * nf + j];
+            const double *li = &L[(size_t)i * nf], *lj = &L[(size_t)j * nf];
+            for (int k = 0; k < j; ++k) v -= li[k] * lj[k];
+            L[(size_t)i * nf + j] = v / ljj;
+        }
+    }
+    std::vector<double> Li((size_t)nf * nf, 0.0);   // L^-1 (lower), row-major
+    for (int c0 = 0; c0 < nf; ++c0) {
+        Li[(size_t)c0 * nf + c0] = 1.0 / L[(size_t)c0 * nf + c0];
+        for (int i = c0 + 1; i < nf; ++i) {
+            double v = 0.0;
+            const double *li = &L[(size_t)i * nf];
+            for (int k = c0; k < i; ++k) v -= li[k] * Li[(size_t)k * nf + c0];
+            Li[(size_t)i * nf + c0] = v / li[i];
+        }
+    }
+    // pack: Inv (symmetric) as K4 [fp/4][fp][4], incidence CSR, vertex map, template
+    size_t nnz = 0;
+    for (auto &v : inc) nnz += v.size();
+    const size_t o_inv = 0, o_ptr = o_inv + (size_t)fp * fp, o_tri = o_ptr + round_up(nf + 1, 64), o_coef = o_tri + round_up(nnz, 64),
+                 o_col = o_coef + round_up(3 * nnz, 64), o_tm = o_col + round_up(n_verts, 64), total = o_tm + round_up(3 * n_verts, 64);
+    std::vector<float> hostf(total, 0.f);
+    {   // Inv[i][j] = sum_k Li[k][i] Li[k][j], k >= max(i, j); transpose Li first for unit-stride inner loops
+        std::vector<double> LiT((size_t)nf * nf);
+        for (int i = 0; i < nf; ++i)
+            for (int j = 0; j < nf; ++j) LiT[(size_t)j * nf + i] = Li[(size_t)i * nf + j];
+        for (int i = 0; i < nf; ++i)
+            for (int j = 0; j <= i; ++j) {
+                double v = 0.0;
+                const double *a = &LiT[(size_t)i * nf], *b = &LiT[(size_t)j * nf];
+                for (int k = i; k < nf; ++k) v += a[k] * b[k];
+                hostf[o_inv + ((size_t)(j / 4) * fp + i) * 4 + (j % 4)] = (float)v;   // row k = j, output p = i
+                hostf[o_inv + ((size_t)(i / 4) * fp + j) * 4 + (i % 4)] = (float)v;
+            }
+    }
+    int *hp = reinterpret_cast<int *>(&hostf[o_ptr]), *ht = reinterpret_cast<int *>(&hostf[o_tri]), *hc = reinterpret_cast<int *>(&hostf[o_col]);
+    size_t p = 0;
+    for (int v = 0; v < nf; ++v) {
+        hp[v] = (int)p;
+        for (auto &e : inc[v]) {
+            ht[p] = e.first;
+            for (int k = 0; k < 3; ++k) hostf[o_coef + 3 * p + k] = (float)e.second[k];
+            ++p;
+        }
+    }
+    hp[nf] = (int)p;
+    for (int64_t v = 0; v < n_verts; ++v) hc[v] = col[v];
+    memcpy(&hostf[o_tm], h_verts, (size_t)n_verts * 3 * 4);
+    auto *m = new sdfa_mesh();
+    if (hipMalloc(&m->blob, total * 4) != hipSuccess ||
+        hipMemcpyAsync(m->blob, hostf.data(), total * 4, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+        fail(SDFA_EHIP, "mesh_create: device upload failed");
+        if (m->blob) (void)hipFree(m->blob);
+        delete m;
+        return nullptr;
+    }
+    const float *d = (const float *)m->blob;
+    m->n_verts = (int)n_verts; m->n_tris = (int)n_tris; m->n_free = nf; m->free_pad = fp;
+    m->inv_k4 = d + o_inv; m->inc_ptr = (const int *)(d + o_ptr); m->inc_tri = (const int *)(d + o_tri);
+    m->inc_coef = d + o_coef; m->vert_col = (const int *)(d + o_col); m->tmpl = d + o_tm;
+    return m;
+}
+
+void sdfa_mesh_destroy(sdfa_mesh *m) {
+    if (!m) return;
+    if (m->blob) (void)hipFree(m->blob);
+    delete m;
+}
+
+int64_t sdfa_mesh_workspace_bytes(const sdfa_mesh *m, int64_t n_frames) {
+    if (!m || n_frames <= 0) return fail(SDFA_EINVAL, "mesh_workspace_bytes: bad argument");
+    return 2 * (int64_t)m->free_pad * round_up(3 * n_frames, 128) * 4;
+}
+
+int sdfa_mesh_from_dgrad(const sdfa_mesh *m, const float *d_dgrad, int64_t n_frames, float *d_verts, void *d_workspace,
+                         int64_t workspace_bytes, void *stream) {
+    if (!m) return fail(SDFA_EINVAL, "mesh_from_dgrad: null mesh");
+    if (n_frames == 0) return SDFA_OK;
+    if (!d_dgrad || !d_verts || !d_workspace || n_frames < 0) return fail(SDFA_EINVAL, "mesh_from_dgrad: bad argument");
+    if (workspace_bytes < sdfa_mesh_workspace_bytes(m, n_frames)) return fail(SDFA_ENOSPACE, "mesh_from_dgrad: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t ld = round_up(3 * n_frames, 128);
+    float *rhs = (float *)d_workspace, *sol = rhs + (int64_t)m->free_pad * ld;
+    MeshArgs a{};
+    a.dgrad = d_dgrad; a.n_frames = n_frames; a.n_tris = m->n_tris; a.n_verts = m->n_verts; a.n_free = m->n_free; a.free_pad = m->free_pad;
+    a.inc_ptr = m->inc_ptr; a.inc_tri = m->inc_tri; a.inc_coef = m->inc_coef; a.vert_col = m->vert_col; a.tmpl = m->tmpl;
+    a.rhs = rhs; a.sol = sol; a.verts = d_verts; a.ld = ld;
+    HIP_TRY(hipMemsetAsync(rhs, 0, (size_t)m->free_pad * ld * 4, s));   // padding columns / rows feed the GEMM
+    HIP_TRY(sdfa_launch_mesh_rhs(a, s));
+    GemmArgs g{};
+    g.P = m->inv_k4; g.Q = rhs; g.D = sol;
+    g.ldp = m->free_pad; g.ldq = ld; g.ldd = ld; g.Ppad = m->free_pad; g.Qpad = ld; g.Pstore = m->free_pad; g.Qreal = ld;
+    g.K = m->free_pad; g.seg_k = g.K; g.act = ACT_NONE; g.out_mode = OUT_K4;
+    HIP_TRY(sdfa_launch_gemm(g, s));
+    HIP_TRY(sdfa_launch_mesh_scatter(a, s));
     return SDFA_OK;
 }
 

@@ -114,3 +114,21 @@ struct ShareArgs {
 };
 hipError_t sdfa_launch_share_map(const ShareArgs &a, hipStream_t s);
 hipError_t sdfa_launch_expand_cols(const float *Zu, const int32_t *col_to_u, float *Z, int nquads, int64_t Mc, hipStream_t s);
+
+// ---- dgrad -> mesh (mesh.hip) -----------------------------------------------------------------------
+struct MeshArgs {
+    const float *dgrad;        // [n_frames][n_tris][9]
+    int64_t n_frames;
+    int n_tris, n_verts, n_free, free_pad;
+    const int *inc_ptr;        // [n_free + 1] CSR over free vertices
+    const int *inc_tri;        // [nnz] triangle of each incidence
+    const float *inc_coef;     // [nnz][3] the A entries of that (triangle, vertex) pair
+    const int *vert_col;       // [n_verts] free-vertex row or -1
+    const float *tmpl;         // [n_verts][3] template positions
+    float *rhs;                // K4 [free_pad/4][ld]   ld = columns = 3 * frames padded to 128
+    const float *sol;          // K4 [free_pad/4][ld]   Inv * rhs
+    float *verts;              // out [n_frames][n_verts][3]
+    int64_t ld;
+};
+hipError_t sdfa_launch_mesh_rhs(const MeshArgs &a, hipStream_t s);
+hipError_t sdfa_launch_mesh_scatter(const MeshArgs &a, hipStream_t s);

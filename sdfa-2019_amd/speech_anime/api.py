@@ -34,6 +34,9 @@ def evaluate_model(args):
         hparams.trainer.evaluate.set_key("test", [rec])
     if hparams.get("load_from") is None:
         raise ValueError("--load_from <checkpoint> is required for evaluation")
+    if args.get("template_mesh"):                                       # tools/config.py:75-85
+        from . import viewer
+        viewer.set_template_mesh(args["template_mesh"], args.get("mesh_constraints"), args.get("mesh_tricorres"))
     ckpt = _load_checkpoint(os.path.expanduser(hparams.load_from))
     model = build_model(hparams, ckpt["state"])
     model.current_epoch = ckpt.get("epoch", 0)

@@ -182,11 +182,15 @@ class SaberSpeechDrivenAnimation:
                 np.save(os.path.join(out_dir, "tslist.npy"), np.asarray(tslist, np.int64))
                 np.save(os.path.join(out_dir, f"{self._face_type}.npy"), animes)
                 if export_frames:                                                              # model.py:201-212
+                    from .. import viewer
                     max_frame = int(tslist[-1] * fps / 1000.0)
-                    for i_frame in range(max_frame + 1):
-                        data_frame = _stream.seek(i_frame * 1000.0 / fps, tslist, animes)
+                    frames = np.stack([_stream.seek(i * 1000.0 / fps, tslist, animes) for i in range(max_frame + 1)])
+                    for i_frame, data_frame in enumerate(frames):
                         np.save(os.path.join(out_dir, f"{i_frame:06d}_dgrad.npy"), data_frame)
-                print(f"[speech_anime] {name}: {len(tslist)} animation frames -> {out_dir} "
-                      "(mesh solve and video rendering are outside this path)")
+                    if viewer.has_template():          # --template_mesh given: one batched GPU solve, then .obj per frame
+                        verts, faces = viewer.frames_to_mesh(frames.astype(np.float32), self._face_type)
+                        for i_frame in range(len(frames)):
+                            viewer.write_obj(os.path.join(out_dir, f"{i_frame:06d}.obj"), verts[i_frame], faces)
+                print(f"[speech_anime] {name}: {len(tslist)} animation frames -> {out_dir} (video rendering is outside this path)")
                 results.append((path, tslist, animes))
         return results
