@@ -63,3 +63,13 @@ def test_stream_seek_interpolates():
     assert np.allclose(stream.seek(-100, ts, seq), 1.0)
     assert np.allclose(stream.seek(-91.5, ts, seq), 1.5)
     assert np.allclose(stream.seek(-500, ts, seq), 0.0) and np.allclose(stream.seek(500, ts, seq), 3.0)
+
+
+def test_rms_normalize_and_seek_match_reference_fixture(golden):
+    g = golden["host_rows"]
+    for i in range(3):
+        got = audio.rms_normalize(g[f"rms_in_{i}"], -24.5)
+        assert np.abs(np.asarray(got, np.float64) - g[f"rms_out_{i}"]).max() <= 1e-7
+    ts = [int(t) for t in g["seek_ts"]]
+    for q, ref in zip(g["seek_q"], g["seek_out"]):
+        assert np.abs(np.asarray(stream.seek(float(q), ts, g["seek_seq"]), np.float64) - ref).max() <= 1e-12

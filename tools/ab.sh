@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_ab.sh "<opt list A>" "<opt list B>" ...   (each arg = extra bench.py flags); prints value + stage times
+# usage: tools/ab.sh "<opt list A>" "<opt list B>" ...   (each arg = extra bench.py flags); prints value + stage times
 mkdir -p gpurun_out
 i=0
 for args in "$@"; do
