@@ -22,11 +22,31 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+#ifdef SDFA_OPERAND_TERMS
+// ANALYSIS BUILD ONLY (make TERMS=n, tools/precision_sweep.py): every MFMA operand is first reduced to the sum of
+// its n leading bfloat16 terms (round-to-nearest-even each), i.e. what a split-bf16 MFMA path with n operand
+// planes would see.  The product library is built without this macro.
+__device__ __forceinline__ float bf16_rne(float x) {
+    unsigned u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return __uint_as_float(u & 0xFFFF0000u);
+}
+__device__ __forceinline__ float keep_terms(float x) {
+    float s = bf16_rne(x);
+#pragma unroll
+    for (int t = 1; t < SDFA_OPERAND_TERMS; ++t) s += bf16_rne(x - s);
+    return s;
+}
+#define SDFA_OP(x) keep_terms(x)
+#else
+#define SDFA_OP(x) (x)
+#endif
+
 __device__ __forceinline__ void mfma4(f32x16 &acc, const float4 &a, const float4 &b) {
-    acc = MFMA(a.x, b.x, acc);
-    acc = MFMA(a.y, b.y, acc);
-    acc = MFMA(a.z, b.z, acc);
-    acc = MFMA(a.w, b.w, acc);
+    acc = MFMA(SDFA_OP(a.x), SDFA_OP(b.x), acc);
+    acc = MFMA(SDFA_OP(a.y), SDFA_OP(b.y), acc);
+    acc = MFMA(SDFA_OP(a.z), SDFA_OP(b.z), acc);
+    acc = MFMA(SDFA_OP(a.w), SDFA_OP(b.w), acc);
 }
 
 __device__ __forceinline__ float lrelu02(float x) { return x >= 0.f ? x : 0.2f * x; }

@@ -64,8 +64,8 @@ __global__ __launch_bounds__(256, 2) void conv1_pool_kernel(ConvArgs a) {
         for (int s = 0; s < 5; ++s) {
             float b0 = sIn[(2 * p) * 3 + 2 * s + h][l31];
             float b1 = sIn[(2 * p + 1) * 3 + 2 * s + h][l31];
-            acc0 = MFMA(wa[s], b0, acc0);
-            acc1 = MFMA(wa[s], b1, acc1);
+            acc0 = MFMA(SDFA_OP(wa[s]), SDFA_OP(b0), acc0);
+            acc1 = MFMA(SDFA_OP(wa[s]), SDFA_OP(b1), acc1);
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {

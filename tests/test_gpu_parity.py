@@ -225,3 +225,20 @@ def test_error_paths(eng, synth_sd):
     bad = {k: v for k, v in synth_sd["dgrad"].items() if "proj_key" not in k}
     with pytest.raises(SdfaError):                       # missing tensor -> SDFA_ESTATE at finalize
         Engine(bad)
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_gemm_variants_agree(eng, golden, variant):
+    """The alternative GEMM data paths (register-direct MT 4 / MT 2, LDS-DMA) give the reference's numbers too."""
+    from sdfa_amd import _lib
+    g = golden["model_dgrad"]
+    x = _t(g["audio_feat"])
+    spk = torch.full((x.shape[0],), int(g["speaker"]), dtype=torch.int64)
+    try:
+        _lib.set_option("gemm_variant", variant)
+        out, z, align, coef = eng.forward(x, spk, want_coef=True)
+        out = out.cpu().numpy()
+    finally:
+        _lib.set_option("gemm_variant", 0)
+    assert np.abs(out[:, ::97] - g["dgrad_stride97"]).max() <= TOL_DGRAD
+    assert np.abs(align.cpu().numpy() - g["align"][:, 0]).max() <= 1e-5
