@@ -16,9 +16,50 @@
 #include "common.h"
 #include "kernels.h"
 
+#ifdef SDFA_STAMPS
+__device__ unsigned long long g_stamp[8];
+#endif
+
 namespace {
 
 constexpr int TP = 128, TQ = 128, KQ = 8;   // tile p, tile q, k-quads per stage
+
+// Epilogue of one 32x32 accumulator tile: rows p_tile + (r&3) + 8*(r>>2) + 4*h, column q (this lane's).
+template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
+__device__ __forceinline__ void store_tile(const GemmArgs &a, const f32x16 &acc, int64_t p_tile, int64_t q, int h) {
+    float bq = 0.f;
+    if (BIAS_Q) bq = (q < a.Qreal) ? a.bias[q] : 0.f;
+    int spk = 0;
+    if (COND) { spk = (int)a.cond_idx[q < a.Qreal ? q : 0]; spk = spk < 0 ? 0 : (spk > 7 ? 7 : spk); }   // ids are validated on the host; clamp keeps the read in bounds
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int64_t p = p_tile + 8 * g + 4 * h;   // rows p..p+3
+        float v[4] = {acc[4 * g + 0], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        if (BIAS_P) {
+            float4 b = ld4(a.bias + p);
+            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+        if (COND) {
+            float4 c = ld4(a.cond_w + (p / 4 * 8 + spk) * 4);
+            v[0] += c.x; v[1] += c.y; v[2] += c.z; v[3] += c.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (BIAS_Q) v[e] += bq;
+            if (ACT == ACT_LRELU) v[e] = lrelu02(v[e]);
+            if (ACT == ACT_TANH) v[e] = tanhf_acc(v[e]);
+        }
+        if (OUT_MODE == OUT_K4) {
+            if (p < a.Pstore) st4(a.D + ((p / 4) * a.ldd + q) * 4, make_float4(v[0], v[1], v[2], v[3]));
+        } else if (q < a.Qreal) {
+            const int64_t o = a.col_group ? (q / a.col_group) * a.col_stride + a.col_off + q % a.col_group : q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (p + e < a.Pstore) a.D[(p + e) * a.ldd + o] = v[e];
+        }
+    }
+}
+
 
 template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND, bool DMA = false>
 __global__ __launch_bounds__(256, 2) void gemm_k4_kernel(GemmArgs a) {
@@ -30,10 +71,11 @@ __global__ __launch_bounds__(256, 2) void gemm_k4_kernel(GemmArgs a) {
     const int wp = wave >> 1, wq = wave & 1;
     const int l31 = lane & 31, h = lane >> 5;
 
-    // XCD-aware tile order: consecutive q-tiles of one p-tile share the weight slab in one L2
-    const int64_t ntq = a.Qpad / TQ;
+    // tile order: all p-tiles of one q-tile are dispatched together, so the streamed activation tile (Q) comes
+    // from HBM once and from L2 for the other row blocks; the weight slab (P) is small and L2-resident anyway
+    const int64_t ntp = a.Ppad / TP;
     const int64_t bid = blockIdx.x;
-    const int64_t tp = bid / ntq, tq = bid % ntq;
+    const int64_t tp = bid % ntp, tq = bid / ntp;
     const int64_t p0 = tp * TP, q0 = tq * TQ;
     if (a.q_limit && q0 >= *a.q_limit) return;
 
@@ -43,7 +85,12 @@ __global__ __launch_bounds__(256, 2) void gemm_k4_kernel(GemmArgs a) {
     const int seg_kq = a.seg_k / 4;
     const int nstage = nkq_total / KQ;
 
-    float4 rp0, rp1, rp2, rp3, rq0, rq1, rq2, rq3;
+    // Register staging runs TWO tiles ahead of the MFMAs: while tile st is multiplied out of LDS, tile st+1 sits
+    // in one register set (written to the other LDS buffer at the end of the stage) and the loads of tile st+2 are
+    // in flight into the second set.  One stage is ~4,100 MFMA cycles per wave; an HBM-streamed operand (the 8192-deep
+    // frequency projection) takes longer than that to arrive, which held the kernel at 76 % with a single tile ahead.
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;   // set A: P quads ra*, Q quads rb*
+    float4 rc0, rc1, rc2, rc3, rd0, rd1, rd2, rd3;   // set B
 #define GEMM_GLOAD1(st, i, RP, RQ)                                                           \
     {                                                                                        \
         const int idx = (i)*256 + tid, kq = idx >> 7, c = idx & 127, gkq = (st)*KQ + kq;     \
@@ -51,23 +98,16 @@ __global__ __launch_bounds__(256, 2) void gemm_k4_kernel(GemmArgs a) {
         const int seg = gkq / seg_kq, kin = gkq - seg * seg_kq;                              \
         RQ = Q[(int64_t)kin * a.ldq + (int64_t)seg * a.seg_col + q0 + c];                    \
     }
-#define GEMM_GLOAD(st) GEMM_GLOAD1(st, 0, rp0, rq0) GEMM_GLOAD1(st, 1, rp1, rq1) GEMM_GLOAD1(st, 2, rp2, rq2) GEMM_GLOAD1(st, 3, rp3, rq3)
+#define GEMM_GLOAD_A(st) GEMM_GLOAD1(st, 0, ra0, rb0) GEMM_GLOAD1(st, 1, ra1, rb1) GEMM_GLOAD1(st, 2, ra2, rb2) GEMM_GLOAD1(st, 3, ra3, rb3)
+#define GEMM_GLOAD_B(st) GEMM_GLOAD1(st, 0, rc0, rd0) GEMM_GLOAD1(st, 1, rc1, rd1) GEMM_GLOAD1(st, 2, rc2, rd2) GEMM_GLOAD1(st, 3, rc3, rd3)
 #define GEMM_LSTORE1(buf, i, RP, RQ)                                   \
     {                                                                  \
         const int idx = (i)*256 + tid, kq = idx >> 7, c = idx & 127;   \
         sP[buf][kq][c] = RP;                                           \
         sQ[buf][kq][c] = RQ;                                           \
     }
-#define GEMM_LSTORE(buf) GEMM_LSTORE1(buf, 0, rp0, rq0) GEMM_LSTORE1(buf, 1, rp1, rq1) GEMM_LSTORE1(buf, 2, rp2, rq2) GEMM_LSTORE1(buf, 3, rp3, rq3)
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
+#define GEMM_LSTORE_A(buf) GEMM_LSTORE1(buf, 0, ra0, rb0) GEMM_LSTORE1(buf, 1, ra1, rb1) GEMM_LSTORE1(buf, 2, ra2, rb2) GEMM_LSTORE1(buf, 3, ra3, rb3)
+#define GEMM_LSTORE_B(buf) GEMM_LSTORE1(buf, 0, rc0, rd0) GEMM_LSTORE1(buf, 1, rc1, rd1) GEMM_LSTORE1(buf, 2, rc2, rd2) GEMM_LSTORE1(buf, 3, rc3, rd3)
     // DMA variant: tiles go HBM/L2 -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction, no VGPR
     // staging and no ds_write); wave w, piece i fills k-quad row 2i + (w>>1), columns (w&1)*64 .. +63.
 #define GEMM_DMA(st, buf)                                                                                        \
@@ -81,71 +121,78 @@ __global__ __launch_bounds__(256, 2) void gemm_k4_kernel(GemmArgs a) {
             (const void __attribute__((address_space(1))) *)(Q + (int64_t)kin * a.ldq + (int64_t)seg * a.seg_col + q0 + c0 + lane), \
             (void __attribute__((address_space(3))) *)(&sQ[buf][kq][c0]), 16, 0, 0);                             \
     }
+#define GEMM_COMPUTE(buf)                                                                                              \
+    _Pragma("unroll") for (int kb = 0; kb < KQ / 2; ++kb) {                                                            \
+        const float4 a0 = sP[buf][2 * kb + h][wp * 64 + l31], a1 = sP[buf][2 * kb + h][wp * 64 + 32 + l31];            \
+        const float4 b0 = sQ[buf][2 * kb + h][wq * 64 + l31], b1 = sQ[buf][2 * kb + h][wq * 64 + 32 + l31];            \
+        mfma4(acc[0][0], a0, b0); mfma4(acc[0][1], a0, b1);                                                            \
+        mfma4(acc[1][0], a1, b0); mfma4(acc[1][1], a1, b1);                                                            \
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
     if (DMA) {
         GEMM_DMA(0, 0)
+        __syncthreads();
+        for (int st = 0; st < nstage; ++st) {
+            const int buf = st & 1;
+            if (st + 1 < nstage) { GEMM_DMA(st + 1, buf ^ 1) }
+            GEMM_COMPUTE(buf)
+            __syncthreads();   // also drains the LDS-DMA of the next tile (vmcnt(0) is part of the barrier's fence)
+        }
     } else {
-        GEMM_GLOAD(0)
-        GEMM_LSTORE(0)
-    }
-    __syncthreads();
-    for (int st = 0; st < nstage; ++st) {
-        const int buf = st & 1;
-        const bool reload = st + 1 < nstage;
-        if (reload) {
-            if (DMA) { GEMM_DMA(st + 1, buf ^ 1) } else { GEMM_GLOAD(st + 1) }
+#ifdef SDFA_STAMPS
+        // DIAGNOSTIC BUILD ONLY (make STAMPS=1): where do a stage's cycles go?  s_memtime around each phase, summed per wave.
+        unsigned long long t0, t1, t2, t3, t4, sum_load = 0, sum_mfma = 0, sum_store = 0, sum_bar = 0;
+#define STAMP(t) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define STAMP(t)
+#endif
+        GEMM_GLOAD_A(0)
+        GEMM_LSTORE_A(0)
+        if (nstage > 1) { GEMM_GLOAD_A(1) }
+        __syncthreads();
+        for (int st = 0; st < nstage; st += 2) {
+            // even stage: LDS buffer 0 holds tile st, set A holds tile st+1
+            STAMP(t0)
+            if (st + 2 < nstage) { GEMM_GLOAD_B(st + 2) }
+            STAMP(t1)
+            GEMM_COMPUTE(0)
+            STAMP(t2)
+            if (st + 1 < nstage) { GEMM_LSTORE_A(1) }
+            STAMP(t3)
+            __syncthreads();
+            STAMP(t4)
+#ifdef SDFA_STAMPS
+            sum_load += t1 - t0; sum_mfma += t2 - t1; sum_store += t3 - t2; sum_bar += t4 - t3;
+#endif
+            if (st + 1 >= nstage) break;
+            // odd stage: LDS buffer 1 holds tile st+1, set B holds tile st+2
+            if (st + 3 < nstage) { GEMM_GLOAD_A(st + 3) }
+            GEMM_COMPUTE(1)
+            if (st + 2 < nstage) { GEMM_LSTORE_B(0) }
+            __syncthreads();
         }
-#pragma unroll
-        for (int kb = 0; kb < KQ / 2; ++kb) {
-            const float4 a0 = sP[buf][2 * kb + h][wp * 64 + l31], a1 = sP[buf][2 * kb + h][wp * 64 + 32 + l31];
-            const float4 b0 = sQ[buf][2 * kb + h][wq * 64 + l31], b1 = sQ[buf][2 * kb + h][wq * 64 + 32 + l31];
-            mfma4(acc[0][0], a0, b0); mfma4(acc[0][1], a0, b1);
-            mfma4(acc[1][0], a1, b0); mfma4(acc[1][1], a1, b1);
+#ifdef SDFA_STAMPS
+        if (lane == 0 && nstage >= 64) {
+            atomicAdd(&g_stamp[0], sum_load); atomicAdd(&g_stamp[1], sum_mfma); atomicAdd(&g_stamp[2], sum_store);
+            atomicAdd(&g_stamp[3], sum_bar); atomicAdd(&g_stamp[4], (unsigned long long)((nstage + 1) / 2));
         }
-        if (!DMA && reload) { GEMM_LSTORE(buf ^ 1) }
-        __syncthreads();   // also drains the LDS-DMA of the next tile (vmcnt(0) is part of the barrier's fence)
+#endif
     }
 
     // ---------------------------------------------------------------- epilogue
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int64_t q = q0 + wq * 64 + j * 32 + l31;
-            float bq = 0.f;
-            if (BIAS_Q) bq = (q < a.Qreal) ? a.bias[q] : 0.f;
-            int spk = 0;
-            if (COND) { spk = (int)a.cond_idx[q < a.Qreal ? q : 0]; spk = spk < 0 ? 0 : (spk > 7 ? 7 : spk); }   // ids are validated on the host; clamp keeps the read in bounds
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int64_t p = p0 + wp * 64 + i * 32 + 8 * g + 4 * h;   // rows p..p+3
-                float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                if (BIAS_P) {
-                    float4 b = ld4(a.bias + p);
-                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-                }
-                if (COND) {
-                    float4 c = ld4(a.cond_w + (p / 4 * 8 + spk) * 4);
-                    v[0] += c.x; v[1] += c.y; v[2] += c.z; v[3] += c.w;
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (BIAS_Q) v[e] += bq;
-                    if (ACT == ACT_LRELU) v[e] = lrelu02(v[e]);
-                    if (ACT == ACT_TANH) v[e] = tanhf_acc(v[e]);
-                }
-                if (OUT_MODE == OUT_K4) {
-                    if (p < a.Pstore) st4(a.D + ((p / 4) * a.ldd + q) * 4, make_float4(v[0], v[1], v[2], v[3]));
-                } else {
-                    if (q < a.Qreal) {
-                        const int64_t o = a.col_group ? (q / a.col_group) * a.col_stride + a.col_off + q % a.col_group : q;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (p + e < a.Pstore) a.D[(p + e) * a.ldd + o] = v[e];
-                    }
-                }
-            }
-        }
-    }
+        for (int j = 0; j < 2; ++j)
+            store_tile<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, acc[i][j], p0 + wp * 64 + i * 32, q0 + wq * 64 + j * 32 + l31, h);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -209,45 +256,10 @@ __global__ __launch_bounds__(256, 2) void gemm_direct_kernel(GemmArgs a) {
 #undef GD_LOAD
 
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int64_t q = q0 + j * 32 + l31;
-            float bq = 0.f;
-            if (BIAS_Q) bq = (q < a.Qreal) ? a.bias[q] : 0.f;
-            int spk = 0;
-            if (COND) { spk = (int)a.cond_idx[q < a.Qreal ? q : 0]; spk = spk < 0 ? 0 : (spk > 7 ? 7 : spk); }   // ids are validated on the host; clamp keeps the read in bounds
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int64_t p = p0 + i * 32 + 8 * g + 4 * h;
-                float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                if (BIAS_P) {
-                    float4 b = ld4(a.bias + p);
-                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-                }
-                if (COND) {
-                    float4 c = ld4(a.cond_w + (p / 4 * 8 + spk) * 4);
-                    v[0] += c.x; v[1] += c.y; v[2] += c.z; v[3] += c.w;
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (BIAS_Q) v[e] += bq;
-                    if (ACT == ACT_LRELU) v[e] = lrelu02(v[e]);
-                    if (ACT == ACT_TANH) v[e] = tanhf_acc(v[e]);
-                }
-                if (OUT_MODE == OUT_K4) {
-                    if (p < a.Pstore) st4(a.D + ((p / 4) * a.ldd + q) * 4, make_float4(v[0], v[1], v[2], v[3]));
-                } else {
-                    if (q < a.Qreal) {
-                        const int64_t o = a.col_group ? (q / a.col_group) * a.col_stride + a.col_off + q % a.col_group : q;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (p + e < a.Pstore) a.D[(p + e) * a.ldd + o] = v[e];
-                    }
-                }
-            }
-        }
-    }
+        for (int j = 0; j < 2; ++j)
+            store_tile<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, acc[i][j], p0 + i * 32, q0 + j * 32 + l31, h);
 }
 
 template <int MT, int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
@@ -264,15 +276,221 @@ hipError_t launch(const GemmArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split-bf16 variant (opt-in, gemm_variant 4): fp32 operands are split on the fly into hi = bf16(x) and
+// lo = bf16(x - hi) while they are staged into LDS, and every product runs as three bf16 MFMAs
+//   a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi      (v_mfma_f32_32x32x16_bf16, fp32 accumulate)
+// i.e. 16 significand bits per operand at 16/3 = 5.3x the fp32 MFMA rate.  Measured operand-truncation error of
+// the whole model at 2 bf16 terms: 3.5e-6 on dgrad against the 1e-4 budget (profiles/r01_precision_sweep.json).
+// LDS image per plane: [k/8][column][8 bf16], so one ds_read_b128 is one MFMA fragment (lane = column, half = k-group).
+// The accumulator layout equals the fp32 MFMA's, so the epilogue is shared.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split8(const float4 &x0, const float4 &x1, bf16x8 &hi, bf16x8 &lo) {
+    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 hb = (__bf16)x[e];
+        hi[e] = hb;
+        lo[e] = (__bf16)(x[e] - (float)hb);
+    }
+}
+
+template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
+    __shared__ bf16x8 sPh[2][4][TP], sPl[2][4][TP], sQh[2][4][TQ], sQl[2][4][TQ];   // 4 x 16 KiB
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave >> 1, wq = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const int64_t ntp = a.Ppad / TP, bid = blockIdx.x;
+    const int64_t p0 = (bid % ntp) * TP, q0 = (bid / ntp) * TQ;
+    if (a.q_limit && q0 >= *a.q_limit) return;
+
+    const float4 *__restrict__ P = reinterpret_cast<const float4 *>(a.P);
+    const float4 *__restrict__ Q = reinterpret_cast<const float4 *>(a.Q);
+    const int seg_kq = a.seg_k / 4, nstage = a.K / 32;
+
+    float4 rp[2][2], rq[2][2];   // [item][quad of the k-group]
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#define BX_GLOAD(st)                                                                              \
+    _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                            \
+        const int idx = it * 256 + tid, g = idx >> 7, c = idx & 127, gkq = (st)*8 + 2 * g;        \
+        const int seg = gkq / seg_kq, kin = gkq - seg * seg_kq;                                   \
+        rp[it][0] = P[(int64_t)gkq * a.ldp + p0 + c];                                             \
+        rp[it][1] = P[(int64_t)(gkq + 1) * a.ldp + p0 + c];                                       \
+        rq[it][0] = Q[(int64_t)kin * a.ldq + (int64_t)seg * a.seg_col + q0 + c];                  \
+        rq[it][1] = Q[(int64_t)(kin + 1) * a.ldq + (int64_t)seg * a.seg_col + q0 + c];            \
+    }
+#define BX_LSTORE(buf)                                                                            \
+    _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                            \
+        const int idx = it * 256 + tid, g = idx >> 7, c = idx & 127;                              \
+        bf16x8 hi, lo;                                                                            \
+        split8(rp[it][0], rp[it][1], hi, lo); sPh[buf][g][c] = hi; sPl[buf][g][c] = lo;           \
+        split8(rq[it][0], rq[it][1], hi, lo); sQh[buf][g][c] = hi; sQl[buf][g][c] = lo;           \
+    }
+
+    BX_GLOAD(0)
+    BX_LSTORE(0)
+    __syncthreads();
+    for (int st = 0; st < nstage; ++st) {
+        const int buf = st & 1;
+        const bool reload = st + 1 < nstage;
+        if (reload) { BX_GLOAD(st + 1) }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {   // two k-steps of 16
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = sPh[buf][2 * m + h][wp * 64 + i * 32 + l31]; al[i] = sPl[buf][2 * m + h][wp * 64 + i * 32 + l31];
+                bh[i] = sQh[buf][2 * m + h][wq * 64 + i * 32 + l31]; bl[i] = sQl[buf][2 * m + h][wq * 64 + i * 32 + l31];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (reload) { BX_LSTORE(buf ^ 1) }
+        __syncthreads();
+    }
+#undef BX_GLOAD
+#undef BX_LSTORE
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            store_tile<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, acc[i][j], p0 + wp * 64 + i * 32, q0 + wq * 64 + j * 32 + l31, h);
+}
+
+template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
+hipError_t launch_bf16x3(const GemmArgs &a, hipStream_t s) {
+    const int64_t nblk = (a.Ppad / TP) * (a.Qpad / TQ);
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>), dim3((unsigned)nblk), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 tile, 8 waves (2 x 4, each 128 x 64 = 4 x 2 MFMA tiles), 128 KiB LDS, one workgroup per CU.
+// Half the staged bytes per FLOP of the 128 x 128 tile: the 128-tile kernel's time did not move when its MFMA work
+// was cut 5x (split-bf16 experiment) -- it is bound by the global->LDS staging stream -- so the big GEMMs
+// (frequency projection, BiLSTM input projections) use this shape whenever P and Q are multiples of 256.
+// ------------------------------------------------------------------------------------------------
+template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
+__global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs a) {
+    extern __shared__ float4 sBig[];                       // [2 bufs][P | Q][KQ][256]
+    constexpr int BT = 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave >> 2, wq = wave & 3, l31 = lane & 31, h = lane >> 5;
+    const int64_t ntp = a.Ppad / BT, bid = blockIdx.x;
+    const int64_t p0 = (bid % ntp) * BT, q0 = (bid / ntp) * BT;
+    if (a.q_limit && q0 >= *a.q_limit) return;
+
+    const float4 *__restrict__ P = reinterpret_cast<const float4 *>(a.P);
+    const float4 *__restrict__ Q = reinterpret_cast<const float4 *>(a.Q);
+    const int seg_kq = a.seg_k / 4, nstage = a.K / 32;
+    auto SP = [&](int buf) { return sBig + (size_t)buf * 2 * KQ * BT; };
+    auto SQ = [&](int buf) { return sBig + (size_t)buf * 2 * KQ * BT + KQ * BT; };
+
+    float4 rp0, rp1, rp2, rp3, rq0, rq1, rq2, rq3;
+#define BG_GLOAD1(st, i, RP, RQ)                                                             \
+    {                                                                                        \
+        const int idx = (i)*512 + tid, kq = idx >> 8, c = idx & 255, gkq = (st)*KQ + kq;     \
+        RP = P[(int64_t)gkq * a.ldp + p0 + c];                                               \
+        const int seg = gkq / seg_kq, kin = gkq - seg * seg_kq;                              \
+        RQ = Q[(int64_t)kin * a.ldq + (int64_t)seg * a.seg_col + q0 + c];                    \
+    }
+#define BG_GLOAD(st) BG_GLOAD1(st, 0, rp0, rq0) BG_GLOAD1(st, 1, rp1, rq1) BG_GLOAD1(st, 2, rp2, rq2) BG_GLOAD1(st, 3, rp3, rq3)
+#define BG_LSTORE1(buf, i, RP, RQ)                                     \
+    {                                                                  \
+        const int idx = (i)*512 + tid;                                 \
+        SP(buf)[idx] = RP;                                             \
+        SQ(buf)[idx] = RQ;                                             \
+    }
+#define BG_LSTORE(buf) BG_LSTORE1(buf, 0, rp0, rq0) BG_LSTORE1(buf, 1, rp1, rq1) BG_LSTORE1(buf, 2, rp2, rq2) BG_LSTORE1(buf, 3, rp3, rq3)
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    BG_GLOAD(0)
+    BG_LSTORE(0)
+    __syncthreads();
+    for (int st = 0; st < nstage; ++st) {
+        const int buf = st & 1;
+        const bool reload = st + 1 < nstage;
+        if (reload) { BG_GLOAD(st + 1) }
+        const float4 *sp = SP(buf), *sq = SQ(buf);
+#pragma unroll
+        for (int kb = 0; kb < KQ / 2; ++kb) {
+            float4 fa[4], fb[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = sp[(2 * kb + h) * BT + wp * 128 + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = sq[(2 * kb + h) * BT + wq * 64 + j * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { mfma4(acc[i][0], fa[i], fb[0]); mfma4(acc[i][1], fa[i], fb[1]); }
+        }
+        if (reload) { BG_LSTORE(buf ^ 1) }
+        __syncthreads();
+    }
+#undef BG_GLOAD
+#undef BG_LSTORE
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            store_tile<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, acc[i][j], p0 + wp * 128 + i * 32, q0 + wq * 64 + j * 32 + l31, h);
+}
+
+template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
+hipError_t launch_big(const GemmArgs &a, hipStream_t s) {
+    static bool attr_set = false;
+    const size_t lds = 2 * 2 * KQ * 256 * sizeof(float4);   // 128 KiB
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_big_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int64_t nblk = (a.Ppad / 256) * (a.Qpad / 256);
+    hipLaunchKernelGGL((gemm_big_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>), dim3((unsigned)nblk), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
 }  // namespace
 
-int g_sdfa_gemm_variant = 0;   // 0 = LDS-tiled (default), 1/2 = register-direct (MT 4 / 2), 3 = LDS-tiled fed by LDS-DMA; all measured within 2 %
+#ifdef SDFA_STAMPS
+extern "C" int sdfa_debug_read_stamps(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 8) != hipSuccess) return -3;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof z) != hipSuccess) return -3; }
+    return 0;
+}
+#endif
+
+int g_sdfa_gemm_variant = 0;   // 0 = LDS-tiled (default), 1/2 = register-direct (MT 4 / 2), 3 = LDS-tiled fed by LDS-DMA (all fp32, within 2 % of each other); 4 = split-bf16 x3 (opt-in, not exact fp32)
 
 template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
 hipError_t launch_any(const GemmArgs &a, hipStream_t s) {
     if (g_sdfa_gemm_variant == 1 && a.Ppad % 128 == 0) return launch_direct<4, OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
     if (g_sdfa_gemm_variant == 2 && a.Ppad % 64 == 0) return launch_direct<2, OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
     if (g_sdfa_gemm_variant == 3) return launch<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, true>(a, s);
+    if (g_sdfa_gemm_variant == 4) return launch_bf16x3<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
+    if (g_sdfa_gemm_variant == 5 && a.Ppad % 256 == 0 && a.Qpad % 256 == 0) return launch_big<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
     return launch<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
 }
 
