@@ -220,8 +220,9 @@ def main():
             dt_s, st_s, distinct = shared
             last = min(F - (n_chunks - 1) * a.chunk, a.chunk)
             res["column_sharing"] = {
-                "note": "same outputs (<=1e-4 of the reference), per-column stages evaluated once per DISTINCT column "
-                        "(SURVEY App. B legal redundancy); NOT the headline value",
+                "note": "outputs BITWISE identical to the headline run; the per-column stages (conv, freq-LSTM, projection) are "
+                        "evaluated once per DISTINCT column (SURVEY App. B legal redundancy); reported next to, not as, "
+                        "the headline value",
                 "value": round(F * world * a.steps / dt_s, 1), "unit": "frames/s", "ms_per_step": round(dt_s / a.steps * 1e3, 3),
                 "distinct_column_fraction_last_chunk": round(distinct / (64.0 * last), 4),
                 "stage_ms_per_step": {k: round(v, 3) for k, v in st_s.items()}}

@@ -127,7 +127,7 @@ int sdfa_encoder_forward(const sdfa_model *m, const float *d_audio_feat, int64_t
 
 /* Same result, fewer evaluations ("legal redundancy"): the per-column stages (conv stack,
  * frequency LSTM, its projection) are run once per DISTINCT column.  Windows of one clip whose starts differ by
- * a whole number of hops contain identical interior columns (t in [5,59]); the library finds them on the device
+ * a whole number of hops contain bit-identical interior columns (t in [6,58]); the library finds them on the device
  * from the frame table of sdfa_frame_index / sdfa_mel_frontend, on every call.
  *   d_frame_clip  [n_frames] int32 clip id        d_frame_start [n_frames] int64 window start in its clip
  *   hop           STFT hop in samples (int(0.008*sr))

@@ -60,10 +60,23 @@ __global__ __launch_bounds__(256) void frontend_kernel(FrontendConsts c, const f
     }
     __syncthreads();
 
+    // STFT columns are transformed in PAIRS (one complex FFT = two real columns).  The pairing follows the ABSOLUTE
+    // hop index of a column, floor(start / hop) + t, not its position in the window: two frames of one clip that
+    // contain the same column (starts a whole number of hops apart) then give it the same partner, so their mel
+    // values -- and every interior feature column -- are bit-identical, which is what makes column sharing
+    // (share.hip) exact.  With an odd base the first and last column have no partner and run alone.
+    const int64_t hop_base = (s0 >= 0 ? s0 : s0 - (HOP - 1)) / HOP;         // floor division
+    const int odd = (int)(hop_base & 1);
+    const int njobs = 32 + odd;                                              // 32 pairs, or solo + 31 pairs + solo
     float2 *buf = sFft[wave];
-    for (int pi = wave; pi < 32; pi += 4) {      // all four waves run 8 iterations: block barriers are uniform
-        const int t0 = 2 * pi;
-        const float *ya = sY + t0 * HOP, *yb = sY + (t0 + 1) * HOP;
+    for (int it = 0; it < 9; ++it) {             // 36 job slots over 4 waves: every wave hits every block barrier
+        const int job = it * 4 + wave;
+        const bool live = job < njobs;
+        int t0 = 2 * job - odd, t1 = t0 + 1;                                 // columns in the real / imaginary part
+        if (!live) { t0 = 0; t1 = 1; }                                       // idle slot: harmless recomputation, results dropped
+        const bool has0 = t0 >= 0, has1 = t1 <= 63;
+        const float *ya = sY + (has0 ? t0 : 0) * HOP, *yb = sY + (has1 ? t1 : 63) * HOP;
+        const float ga = has0 ? 1.f : 0.f, gb = has1 ? 1.f : 0.f;
         float2 v[NR4][4];
         // ---- stage 0 (Ns = 1) straight from the windowed signal
 #pragma unroll
@@ -73,7 +86,7 @@ __global__ __launch_bounds__(256) void frontend_kernel(FrontendConsts c, const f
             for (int r = 0; r < 4; ++r) {
                 const int nidx = j + r * (WIN / 4);
                 const float w = sHamm[nidx];
-                v[b][r] = make_float2(w * ya[nidx], w * yb[nidx]);
+                v[b][r] = make_float2(ga * (w * ya[nidx]), gb * (w * yb[nidx]));
             }
         }
         int Ns = 1;
@@ -143,7 +156,8 @@ __global__ __launch_bounds__(256) void frontend_kernel(FrontendConsts c, const f
                 for (int e = sPtr[band]; e < sPtr[band + 1]; ++e) m += sW[e] * sPow[wave][col][sBin[e]];
                 float db = __fmul_rn(10.0f, log10f(fmaxf(m, 1.1920929e-07f)));
                 float nv = __fdiv_rn(__fadd_rn(__fsub_rn(db, 20.0f), 80.0f), 80.0f);
-                sMel[t0 + col][band] = fminf(fmaxf(nv, 0.f), 1.f);
+                const int tt = col ? t1 : t0;
+                if (live && tt >= 0 && tt <= 63) sMel[tt][band] = fminf(fmaxf(nv, 0.f), 1.f);
             }
         __syncthreads();
     }

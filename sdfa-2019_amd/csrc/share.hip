@@ -1,9 +1,11 @@
 // Column sharing ("legal redundancy"): the conv stack, the frequency LSTM and its projection act
 // on every (frame, time-step) column independently, and windows of the same clip whose starts differ by a whole
 // number of hops contain the SAME columns (frames 12 apart at 60 fps / 16 kHz / hop 128 share 39 of 64).  A column
-// is bit-for-bit the same feature vector in both frames when it is interior in both -- t in [5, 59]: the delta
-// filters see true neighbours (edge replication touches t < 4 and t > 59, get_features.py:199-207) and none of
-// them is window column 0, whose first sample is not pre-emphasised (misc.py:17).  Each distinct column is then
+// is bit-for-bit the same feature vector in both frames when it is interior in both -- t in [6, 58]: the delta
+// filters then see true neighbours (edge replication touches t < 4 and t > 59, get_features.py:199-207) and their
+// 9-tap stencil [t-4, t+4] avoids window column 0 (its first sample is not pre-emphasised, misc.py:17), column 1
+// (which may share column 0's FFT) and column 63 (which may be transformed alone): frontend.hip pairs STFT columns
+// by absolute hop index, so every other column has the same FFT partner, hence the same bits, in every frame.  Each distinct column is then
 // evaluated once and scattered to every frame that contains it.  The map is rebuilt on the device for every call
 // from the per-frame (clip, start) table; nothing is cached between calls.
 #include "common.h"
@@ -11,7 +13,7 @@
 
 namespace {
 
-constexpr int T_LO = 5, T_HI = 59;
+constexpr int T_LO = 6, T_HI = 58;
 
 // prev[n] = nearest earlier frame of the same clip whose start differs by d whole hops, 1 <= d <= T_HI - T_LO
 __global__ void share_prev_kernel(ShareArgs a) {

@@ -1,6 +1,6 @@
 """Audio ingest helpers on the host (numpy): the steps around the hot path that evaluate() needs.
 
-  rms_normalize -- saber/data/audio/rms.py:45-78 (analyze_db + normalize), called at speech_anime/model/model.py:165
+  rms_normalize -- saber.audio.rms.normalize (saber/data/audio/rms.py:45-78), called at speech_anime/model/model.py:165
   load_source   -- the .wav branch of speech_anime/model/eval_utils.py:50-93
 
 The reference loads everything through librosa at 44.1 kHz and resamples with resampy (kaiser_best); neither
@@ -12,24 +12,20 @@ import os
 import numpy as np
 
 
-def analyze_db(wav, threshold=None):
-    db = 20.0 * np.log10(np.maximum(np.abs(wav), 1e-10))
-    max_db = db.max()
-    if threshold is None:
-        threshold = db.min()
-    mask = db >= threshold
-    if mask.sum() == 0:
-        return None, None
-    rms = np.sqrt(np.mean(wav[mask] ** 2))
-    return 20.0 * np.log10(rms), max_db
-
-
 def rms_normalize(wav, target_db=-20, threshold=None):
-    rms_db, max_db = analyze_db(wav, threshold=threshold)
-    if rms_db is None:
+    """Scale `wav` so that the RMS of its non-silent samples sits at `target_db` dBFS, then clip to +-0.999.
+
+    Behaviour of saber.audio.rms.normalize (saber/data/audio/rms.py:45-78): per-sample level 20*log10(max(|x|, 1e-10));
+    samples at or above `threshold` dB (default: the quietest sample, i.e. all of them) enter the RMS; an empty
+    selection returns the input untouched.  Pinned by tests/golden/host_rows.npz.
+    """
+    level = 20.0 * np.log10(np.maximum(np.abs(wav), 1e-10))
+    keep = level >= (level.min() if threshold is None else threshold)
+    if not keep.any():
         return wav
-    scale = np.power(10.0, (target_db - rms_db) / 20.0)
-    return np.clip(wav * scale, -0.999, 0.999)
+    rms_db = 20.0 * np.log10(np.sqrt(np.mean(wav[keep] ** 2)))
+    gain = np.power(10.0, (target_db - rms_db) / 20.0)
+    return np.clip(wav * gain, -0.999, 0.999)
 
 
 def load_source(path, sr):

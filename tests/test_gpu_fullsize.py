@@ -92,4 +92,4 @@ def test_column_sharing_at_full_size(run):
     for f0 in range(0, 20352, 8192):
         f1 = min(20352, f0 + 8192)
         z2[f0:f1], _ = eng.encoder(run["feat"][f0:f1], want_align=False, frame_clip=fc[f0:f1], frame_start=fs[f0:f1], hop=hop)
-    assert (z2 - run["z"]).abs().max().item() <= 2e-5
+    assert torch.equal(z2, run["z"])            # bitwise: shared columns are identical feature vectors
