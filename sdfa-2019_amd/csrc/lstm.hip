@@ -17,6 +17,13 @@
 #include "common.h"
 #include "kernels.h"
 
+#ifdef SDFA_STAMPS
+__device__ unsigned long long g_lstamp[8];
+#define LSTAMP(t) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define LSTAMP(t)
+#endif
+
 namespace {
 
 __device__ __forceinline__ void lstm_cell_quad(const f32x16 &ai, const f32x16 &af, const f32x16 &ag, const f32x16 &ao,
@@ -72,9 +79,13 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_kernel(FreqLstmArgs a) {
 
     const float4 *__restrict__ Ww = W + wave * 128 + l31;   // + quad*512 + gate*32
 
+#ifdef SDFA_STAMPS
+    unsigned long long q0, q1, q2, q3, q4, q5, s_init = 0, s_ld = 0, s_mf = 0, s_b1 = 0, s_ep = 0, s_b2 = 0, s_math = 0, s_lds = 0;
+#endif
     for (int s = 0; s < 32; ++s) {
         const int f = dir ? 31 - s : s;
         const int cur = s & 1;
+        LSTAMP(q0)
         if (s + 1 < 32) { XLOAD(dir ? 30 - s : s + 1) }
 
         f32x16 acc[4][2];
@@ -96,21 +107,60 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_kernel(FreqLstmArgs a) {
         const float4 *__restrict__ wp = Ww + h * 512;
         float4 wn0 = wp[0], wn1 = wp[32], wn2 = wp[64], wn3 = wp[96];
         float4 bn0 = sX[cur][h][l31], bn1 = sX[cur][h][32 + l31];
+        LSTAMP(q1)
+#ifdef SDFA_STAMPS
+        s_init += q1 - q0;
+#endif
+#ifdef SDFA_STAMPS
+#pragma unroll 1
+#else
 #pragma unroll 2
+#endif
         for (int kb = 0; kb < nkb; ++kb) {
             const float4 w0 = wn0, w1 = wn1, w2 = wn2, w3 = wn3, b0 = bn0, b1 = bn1;
+            LSTAMP(q2)
             if (kb + 1 < nkb) {
                 const float4 *__restrict__ wq = wp + (kb + 1) * 1024;
                 wn0 = wq[0]; wn1 = wq[32]; wn2 = wq[64]; wn3 = wq[96];
                 const float4 *bsrc = kb + 1 < 8 ? &sX[cur][2 * kb + 2 + h][0] : &sH[2 * (kb - 7) + h][0];
                 bn0 = bsrc[l31]; bn1 = bsrc[32 + l31];
             }
+            LSTAMP(q3)
             mfma4(acc[0][0], w0, b0); mfma4(acc[0][1], w0, b1);
             mfma4(acc[1][0], w1, b0); mfma4(acc[1][1], w1, b1);
             mfma4(acc[2][0], w2, b0); mfma4(acc[2][1], w2, b1);
             mfma4(acc[3][0], w3, b0); mfma4(acc[3][1], w3, b1);
+            LSTAMP(q4)
+#ifdef SDFA_STAMPS
+            s_ld += q3 - q2; s_mf += q4 - q3;
+#endif
         }
+        LSTAMP(q2)
         __syncthreads();   // every wave has finished reading sH / sX[cur]
+        LSTAMP(q3)
+#ifdef SDFA_STAMPS
+        {   // diagnostic split: math first, then LDS writes, then global stores
+            float4 hq[2][4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) lstm_cell_quad(acc[0][j], acc[1][j], acc[2][j], acc[3][j], c[j], g, hq[j][g]);
+            unsigned long long e1, e2, e3;
+            LSTAMP(e1)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) sH[8 * wave + 2 * g + h][j * 32 + l31] = hq[j][g];
+            if (s + 1 < 32) { XSTORE(cur ^ 1) }
+            LSTAMP(e2)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) HF[(int64_t)(f * 64 + dir * 32 + 8 * wave + 2 * g + h) * a.Mc + m0 + j * 32 + l31] = hq[j][g];
+            LSTAMP(e3)
+            s_math += e1 - q3; s_lds += e2 - e1;
+        }
+#else
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -122,8 +172,21 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_kernel(FreqLstmArgs a) {
                 HF[(int64_t)(f * 64 + dir * 32 + hq_idx) * a.Mc + m0 + j * 32 + l31] = hq;
             }
         if (s + 1 < 32) { XSTORE(cur ^ 1) }
+#endif
+        LSTAMP(q4)
         __syncthreads();
+        LSTAMP(q5)
+#ifdef SDFA_STAMPS
+        s_b1 += q3 - q2; s_ep += q4 - q3; s_b2 += q5 - q4;
+#endif
     }
+#ifdef SDFA_STAMPS
+    if (lane == 0) {
+        atomicAdd(&g_lstamp[0], s_init); atomicAdd(&g_lstamp[1], s_ld); atomicAdd(&g_lstamp[2], s_mf); atomicAdd(&g_lstamp[3], s_b1);
+        atomicAdd(&g_lstamp[4], s_ep); atomicAdd(&g_lstamp[5], s_math); atomicAdd(&g_lstamp[6], 32ull); atomicAdd(&g_lstamp[7], s_lds);
+        atomicAdd(&g_lstamp[3], s_b2);
+    }
+#endif
 }
 
 // ----------------------------------------------------------------------------------------- time LSTM
@@ -200,6 +263,14 @@ __global__ __launch_bounds__(512, 2) void time_lstm_kernel(TimeLstmArgs a) {
 }
 
 }  // namespace
+
+#ifdef SDFA_STAMPS
+extern "C" int sdfa_debug_read_lstm_stamps(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lstamp), sizeof(unsigned long long) * 8) != hipSuccess) return -3;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_lstamp), z, sizeof z) != hipSuccess) return -3; }
+    return 0;
+}
+#endif
 
 hipError_t sdfa_launch_freq_lstm(const FreqLstmArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(freq_lstm_kernel, dim3((unsigned)(a.Mc / 64 * 2)), dim3(256), 0, s, a);
