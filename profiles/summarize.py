@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Per-kernel, per-launch-shape averages from a rocprofv3 --kernel-trace CSV (profiles/*_kernel_trace.csv).
+
+rocprofv3's --stats averages every launch of a kernel symbol; bench.py launches the hot kernels in chunks of 8192,
+8192 and 3968 frames (and once more on the 2 s parity sample), so the figure that corresponds to `roofline.launch_ms`
+is the average over the three chunk launches of a step.  Usage: python profiles/summarize.py <kernel_trace.csv>"""
+import collections
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+acc = collections.defaultdict(list)
+for r in rows:
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+    acc[(name, int(r["Grid_Size_X"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+tot = collections.defaultdict(lambda: [0, 0.0])
+print(f"{'kernel':48s} {'grid':>10s} {'calls':>6s} {'avg ms':>10s}")
+for (name, grid), v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+    if sum(v) < 0.05:
+        continue
+    print(f"{name[:48]:48s} {grid:10d} {len(v):6d} {sum(v) / len(v):10.4f}")
+    tot[name][0] += len(v); tot[name][1] += sum(v)
+print()
+for name, (n, t) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
+    print(f"{name[:48]:48s} all launches: {n:5d} calls, avg {t / n:9.4f} ms, total {t:9.2f} ms")

@@ -44,6 +44,9 @@ __device__ __forceinline__ void lstm_cell_quad(const f32x16 &ai, const f32x16 &a
 }
 
 // ------------------------------------------------------------------------------------ frequency LSTM
+// SHARED = launched over the compacted distinct-column list (column sharing): same code, separate symbol so that
+// profiles keep the two launch shapes apart.
+template <bool SHARED>
 __global__ __launch_bounds__(256, 2) void freq_lstm_kernel(FreqLstmArgs a) {
     __shared__ float4 sH[32][64];       // h_{s-1}: 128 hidden as 32 k-quads x 64 sequences
     __shared__ float4 sX[2][16][64];    // x_f tile, double buffered
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_kernel(FreqLstmArgs a) {
     const int l31 = lane & 31, h = lane >> 5;
     const int dir = blockIdx.x & 1;
     const int64_t m0 = (int64_t)(blockIdx.x >> 1) * 64;
-    if (a.col_limit && m0 >= *a.col_limit) return;
+    if (SHARED && m0 >= *a.col_limit) return;
 
     const float4 *__restrict__ X3 = reinterpret_cast<const float4 *>(a.X3);
     const float4 *__restrict__ W = reinterpret_cast<const float4 *>(a.W) + (size_t)dir * 48 * 512;
@@ -273,7 +276,10 @@ extern "C" int sdfa_debug_read_lstm_stamps(unsigned long long *out, int reset) {
 #endif
 
 hipError_t sdfa_launch_freq_lstm(const FreqLstmArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(freq_lstm_kernel, dim3((unsigned)(a.Mc / 64 * 2)), dim3(256), 0, s, a);
+    if (a.col_limit)
+        hipLaunchKernelGGL(freq_lstm_kernel<true>, dim3((unsigned)(a.Mc / 64 * 2)), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(freq_lstm_kernel<false>, dim3((unsigned)(a.Mc / 64 * 2)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
