@@ -664,7 +664,7 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
         GemmArgs g{};   // FreqLstm._proj: Linear(8192 -> 256) + bias
         g.P = m->fp_w; g.Q = ws + w.HF; g.D = ws + w.Z; g.bias = m->fp_b;
         g.ldp = 256; g.ldq = Mc; g.ldd = Mc; g.Ppad = 256; g.Qpad = Mc; g.Pstore = 256; g.Qreal = Mc;
-        g.K = 8192; g.seg_k = 8192; g.act = ACT_NONE; g.out_mode = OUT_K4;
+        g.K = 8192; g.seg_k = 8192; g.act = ACT_NONE; g.out_mode = OUT_K4; g.q_tile_major = 1;
         if (share) { g.D = ws + w.ZU; g.q_limit = d_ulimit; }
         pf.begin("freq_proj"); HIP_TRY(sdfa_launch_gemm(g, s)); pf.end();
         if (share) {   // scatter every distinct column's 256 features to all the (t, n) columns that contain it

@@ -96,7 +96,8 @@ __global__ __launch_bounds__(256, 2) void gemm_k4_kernel(GemmArgs a) {
         const int idx = (i)*256 + tid, kq = idx >> 7, c = idx & 127, gkq = (st)*KQ + kq;     \
         RP = P[(int64_t)gkq * a.ldp + p0 + c];                                               \
         const int seg = gkq / seg_kq, kin = gkq - seg * seg_kq;                              \
-        RQ = Q[(int64_t)kin * a.ldq + (int64_t)seg * a.seg_col + q0 + c];                    \
+        RQ = a.q_tile_major ? Q[((q0 >> 7) * (int64_t)nkq_total + gkq) * 128 + c]           \
+                            : Q[(int64_t)kin * a.ldq + (int64_t)seg * a.seg_col + q0 + c];   \
     }
 #define GEMM_GLOAD_A(st) GEMM_GLOAD1(st, 0, ra0, rb0) GEMM_GLOAD1(st, 1, ra1, rb1) GEMM_GLOAD1(st, 2, ra2, rb2) GEMM_GLOAD1(st, 3, ra3, rb3)
 #define GEMM_GLOAD_B(st) GEMM_GLOAD1(st, 0, rc0, rd0) GEMM_GLOAD1(st, 1, rc1, rd1) GEMM_GLOAD1(st, 2, rc2, rd2) GEMM_GLOAD1(st, 3, rc3, rd3)
@@ -472,6 +473,88 @@ hipError_t launch_big(const GemmArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Producer / consumer variant (gemm_variant 6): 4 MFMA waves + 2 loader waves per workgroup.  The in-kernel stamps
+// showed an MFMA wave losing ~3,900 of 10,600 cycles per stage just ISSUING its eight global loads (the CU's miss
+// path is latency-bound when an operand streams from HBM) -- an in-order wave issues no MFMAs meanwhile.  Here the
+// MFMA waves never execute a vector-memory instruction: waves 4 and 5 move the next tile HBM/L2 -> LDS with LDS-DMA
+// (global_load_lds_dwordx4, 16 x 1 KiB pieces each) and absorb the queueing; one workgroup barrier per stage.
+// ------------------------------------------------------------------------------------------------
+template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
+__global__ __launch_bounds__(384) void gemm_pc_kernel(GemmArgs a) {
+    __shared__ float4 sP[2][KQ][TP];
+    __shared__ float4 sQ[2][KQ][TQ];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t ntp = a.Ppad / TP, bid = blockIdx.x;
+    const int64_t p0 = (bid % ntp) * TP, q0 = (bid / ntp) * TQ;
+    if (a.q_limit && q0 >= *a.q_limit) return;
+    const float4 *__restrict__ P = reinterpret_cast<const float4 *>(a.P);
+    const float4 *__restrict__ Q = reinterpret_cast<const float4 *>(a.Q);
+    const int nkq_total = a.K / 4, seg_kq = a.seg_k / 4, nstage = nkq_total / KQ;
+
+    if (wave >= 4) {
+        // ---------------- loader waves: wave 4 fills k-quad rows 0..3 of a tile, wave 5 rows 4..7
+        const int pw = wave - 4;
+#define PC_DMA(st, buf)                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
+            const int kq = 4 * pw + i, gkq = (st)*KQ + kq;                                                         \
+            const int seg = gkq / seg_kq, kin = gkq - seg * seg_kq;                                                \
+            _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) {                                                     \
+                const int c0 = hf * 64;                                                                            \
+                __builtin_amdgcn_global_load_lds(                                                                  \
+                    (const void __attribute__((address_space(1))) *)(P + (int64_t)gkq * a.ldp + p0 + c0 + lane),   \
+                    (void __attribute__((address_space(3))) *)(&sP[buf][kq][c0]), 16, 0, 0);                       \
+                const float4 *qsrc = a.q_tile_major ? Q + ((q0 >> 7) * (int64_t)nkq_total + gkq) * 128 + c0 + lane \
+                                                    : Q + (int64_t)kin * a.ldq + (int64_t)seg * a.seg_col + q0 + c0 + lane; \
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)qsrc,             \
+                                                 (void __attribute__((address_space(3))) *)(&sQ[buf][kq][c0]), 16, 0, 0); \
+            }                                                                                                      \
+        }
+        PC_DMA(0, 0)
+        __syncthreads();
+        for (int st = 0; st < nstage; ++st) {
+            if (st + 1 < nstage) { PC_DMA(st + 1, (st & 1) ^ 1) }
+            __syncthreads();   // the barrier's fence drains this wave's LDS-DMA (vmcnt(0)): tile st+1 is in LDS for everyone
+        }
+#undef PC_DMA
+        return;
+    }
+    // ---------------- MFMA waves
+    const int wp = wave >> 1, wq = wave & 1, l31 = lane & 31, h = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    __syncthreads();
+    for (int st = 0; st < nstage; ++st) {
+        const int buf = st & 1;
+#pragma unroll
+        for (int kb = 0; kb < KQ / 2; ++kb) {
+            const float4 a0 = sP[buf][2 * kb + h][wp * 64 + l31], a1 = sP[buf][2 * kb + h][wp * 64 + 32 + l31];
+            const float4 b0 = sQ[buf][2 * kb + h][wq * 64 + l31], b1 = sQ[buf][2 * kb + h][wq * 64 + 32 + l31];
+            mfma4(acc[0][0], a0, b0); mfma4(acc[0][1], a0, b1);
+            mfma4(acc[1][0], a1, b0); mfma4(acc[1][1], a1, b1);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            store_tile<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, acc[i][j], p0 + wp * 64 + i * 32, q0 + wq * 64 + j * 32 + l31, h);
+}
+
+template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
+hipError_t launch_pc(const GemmArgs &a, hipStream_t s) {
+    const int64_t nblk = (a.Ppad / TP) * (a.Qpad / TQ);
+    hipLaunchKernelGGL((gemm_pc_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>), dim3((unsigned)nblk), dim3(384), 0, s, a);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 #ifdef SDFA_STAMPS
@@ -486,6 +569,8 @@ int g_sdfa_gemm_variant = 0;   // 0 = LDS-tiled (default), 1/2 = register-direct
 
 template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
 hipError_t launch_any(const GemmArgs &a, hipStream_t s) {
+    if (g_sdfa_gemm_variant == 6) return launch_pc<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
+    if (a.q_tile_major) return launch<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);   // only the LDS-tiled kernels read that layout
     if (g_sdfa_gemm_variant == 1 && a.Ppad % 128 == 0) return launch_direct<4, OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
     if (g_sdfa_gemm_variant == 2 && a.Ppad % 64 == 0) return launch_direct<2, OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
     if (g_sdfa_gemm_variant == 3) return launch<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, true>(a, s);

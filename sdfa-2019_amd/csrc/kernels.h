@@ -21,6 +21,7 @@ struct GemmArgs {
     int seg_k;           // contraction length per segment (= K when one segment)
     int64_t seg_col;     // Q column offset between segments
     int act, out_mode, bias_on_q;
+    int q_tile_major;         // Q is stored tile-major: float4[column block of 128][K/4][128] (the freq-LSTM hidden states)
     const int64_t *q_limit;   // device scalar: tiles whose first column is >= *q_limit exit at once (null = no limit)
     int col_group, col_stride, col_off;   // OUT_ROW only: column q is stored at (q / group) * stride + off + q % group (group 0 = identity)
 };

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_kernel(FreqLstmArgs a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) HF[(int64_t)(f * 64 + dir * 32 + 8 * wave + 2 * g + h) * a.Mc + m0 + j * 32 + l31] = hq[j][g];
+                for (int g = 0; g < 4; ++g) HF[((m0 >> 7) * (int64_t)2048 + (f * 64 + dir * 32 + 8 * wave + 2 * g + h)) * 128 + (m0 & 127) + j * 32 + l31] = hq[j][g];
             LSTAMP(e3)
             s_math += e1 - q3; s_lds += e2 - e1;
         }
@@ -172,7 +172,9 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_kernel(FreqLstmArgs a) {
                 lstm_cell_quad(acc[0][j], acc[1][j], acc[2][j], acc[3][j], c[j], g, hq);
                 const int hq_idx = 8 * wave + 2 * g + h;
                 sH[hq_idx][j * 32 + l31] = hq;
-                HF[(int64_t)(f * 64 + dir * 32 + hq_idx) * a.Mc + m0 + j * 32 + l31] = hq;
+                // hidden states go out TILE-MAJOR: float4[column block of 128][8192/4 rows][128]: a workgroup's 32 KB of a
+                // step are contiguous, and the projection GEMM streams each column block front to back
+                HF[((m0 >> 7) * (int64_t)2048 + (f * 64 + dir * 32 + hq_idx)) * 128 + (m0 & 127) + j * 32 + l31] = hq;
             }
         if (s + 1 < 32) { XSTORE(cur ^ 1) }
 #endif

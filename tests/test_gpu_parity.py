@@ -227,9 +227,10 @@ def test_error_paths(eng, synth_sd):
         Engine(bad)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
 def test_gemm_variants_agree(eng, golden, variant):
-    """The alternative GEMM data paths (register-direct MT 4 / MT 2, LDS-DMA) give the reference's numbers too."""
+    """The alternative GEMM data paths (register-direct MT 4 / MT 2, LDS-DMA, split-bf16 x3, 256-tile,
+    producer/consumer) give the reference's numbers too."""
     from sdfa_amd import _lib
     g = golden["model_dgrad"]
     x = _t(g["audio_feat"])
