@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-column-sharing", action="store_true", help="skip the second, column-sharing measurement")
+    ap.add_argument("--precision", choices=["fp32", "bf16_attention", "bf16x3", "bf16"], default="fp32",
+                    help="matrix instruction of the headline run (fp32 = the reference's arithmetic; the others are BASELINE configs[3] modes)")
+    ap.add_argument("--no-mixed-precision", action="store_true", help="skip the extra split-bf16 (configs[3]) measurement")
     ap.add_argument("--opt", action="append", default=[], help="library tuning switch name=value (A/B runs)")
     ap.add_argument("--cpu-sample-seconds", type=float, default=2.0)
     return ap.parse_args()
@@ -67,12 +70,16 @@ def cpu_baseline(sr, seconds, eng, state_dict):
     t0 = time.perf_counter()
     ts, ref = O.generate_animation(orc, pcm, sr, 2)
     dt = time.perf_counter() - t0
-    feat, tslists, counts = eng.mel_frontend([pcm], sr)
-    out, *_ = eng.forward(feat, torch.full((feat.shape[0],), 2, dtype=torch.int64))
-    err = float(np.abs(out.cpu().numpy() - ref.reshape(len(ref), -1)).max())
-    ts_equal = bool(tslists[0] == list(ts))
+    ref = ref.reshape(len(ref), -1)
+
+    def gpu_err(precision):
+        eng.set_precision(precision)
+        feat, tslists, counts = eng.mel_frontend([pcm], sr)
+        out, *_ = eng.forward(feat, torch.full((feat.shape[0],), 2, dtype=torch.int64))
+        return float(np.abs(out.cpu().numpy() - ref).max()), bool(tslists[0] == list(ts))
+
     return dict(value=round(len(ref) / dt, 2), unit="frames/s", cores=int(cores), kind="port",
-                sample=f"1 clip x {seconds:g} s @ {sr} Hz = {len(ref)} frames, oracle/sdfa_oracle.py (numpy fp32), {dt:.1f} s"), err, ts_equal
+                sample=f"1 clip x {seconds:g} s @ {sr} Hz = {len(ref)} frames, oracle/sdfa_oracle.py (numpy fp32), {dt:.1f} s"), gpu_err
 
 
 def traffic_from_profile(frames_per_launch):
@@ -115,7 +122,7 @@ def main():
         _lib.check(_lib.lib.sdfa_debug_set_option(k.encode(), int(v)))
     sr, L = a.sample_rate, int(a.seconds * a.sample_rate)
     sd = synth.make_state_dict("dgrad", 1234)
-    eng = Engine(sd, device=dev, max_frames=a.chunk)
+    eng = Engine(sd, device=dev, max_frames=a.chunk, precision=a.precision)
 
     # ---- this rank's clips: global clip ids [rank*C, (rank+1)*C), PCM resident in HBM before timing
     C = a.clips_per_gpu
@@ -184,6 +191,13 @@ def main():
         dt_s, st_s = timed(True)
         distinct = eng.distinct_columns(min(F - (n_chunks - 1) * a.chunk, a.chunk))
         shared = (dt_s, st_s, distinct)
+    mixed = None
+    if a.precision == "fp32" and not a.no_mixed_precision:      # BASELINE configs[3]: same workload on split-bf16 MFMA
+        eng.set_precision("bf16x3")
+        dt_m, st_m = timed(False)
+        dt_ms = None if a.no_column_sharing else timed(True)[0]
+        eng.set_precision("fp32")
+        mixed = (dt_m, st_m, dt_ms)
     # front end: timed separately (same stream, HIP events), outside the headline region
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record(); eng.mel_frontend_device(pcm, clip_off, clip_len, frame_clip, frame_start, sr, out=feat); ev1.record()
@@ -201,7 +215,9 @@ def main():
             "metric": "animation frames/s/node (10 s@16 kHz clips); max|Δdgrad| vs CPU ref",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"fp32": "f32", "bf16_attention": "f32 (attention projections bf16)",
+                                           "bf16x3": "split-bf16 x3 (fp32 accumulate)", "bf16": "bf16 (fp32 accumulate)"}[a.precision],
+            "data": "synthetic",
             "config": {"workload": f"batch={C} x {a.seconds:g} s@{sr} Hz synthetic PCM per GPU -> dgrad (BASELINE configs[1])",
                        "clips_per_gpu": C, "frames_per_gpu": F, "head": "dgrad", "chunk_frames": a.chunk,
                        "gather": a.gather if world > 1 else "none (1 GPU)", "weights": "synthetic seed 1234"},
@@ -226,11 +242,23 @@ def main():
                 "value": round(F * world * a.steps / dt_s, 1), "unit": "frames/s", "ms_per_step": round(dt_s / a.steps * 1e3, 3),
                 "distinct_column_fraction_last_chunk": round(distinct / (64.0 * last), 4),
                 "stage_ms_per_step": {k: round(v, 3) for k, v in st_s.items()}}
+        if mixed is not None:
+            dt_m, st_m, dt_ms = mixed
+            res["mixed_precision"] = {
+                "note": "BASELINE configs[3]: same workload with the frequency LSTM and every GEMM on split-bf16 MFMA (operands as "
+                        "hi+lo bf16, three v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate/state/activations; front end, conv "
+                        "stack, BiLSTM recurrences, softmax fp32); NOT the headline, which stays exact fp32",
+                "mode": "bf16x3", "value": round(F * world * a.steps / dt_m, 1), "unit": "frames/s",
+                "ms_per_step": round(dt_m / a.steps * 1e3, 3),
+                "with_column_sharing": None if dt_ms is None else round(F * world * a.steps / dt_ms, 1),
+                "stage_ms_per_step": {k: round(v, 3) for k, v in st_m.items()}}
         if world == 1 and not a.no_cpu_baseline:
-            cb, err, ts_ok = cpu_baseline(sr, a.cpu_sample_seconds, eng, sd)
+            cb, gpu_err = cpu_baseline(sr, a.cpu_sample_seconds, eng, sd)
             res["cpu_baseline"] = cb
-            res["max_abs_dgrad_err_vs_cpu_ref"] = err
-            res["tslist_bit_exact"] = ts_ok
+            res["max_abs_dgrad_err_vs_cpu_ref"], res["tslist_bit_exact"] = gpu_err(a.precision)
+            if mixed is not None:
+                res["mixed_precision"]["max_abs_dgrad_err_vs_cpu_ref"] = gpu_err("bf16x3")[0]
+                eng.set_precision("fp32")
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -129,6 +129,8 @@ struct sdfa_model {
     // device pointers into blob
     const float *w1, *b1, *s1, *t1, *w2, *b2, *s2, *t2, *w3, *b3, *s3, *t3;
     const float *fl_w, *fl_b, *fp_w, *fp_b;
+    const void *fl_wb = nullptr;   // frequency-LSTM weights as bf16 hi/lo planes (mixed-precision modes)
+    int precision = SDFA_PREC_FP32;
     const float *gx_w[2], *tl_w[2];
     const float *kp_w, *qc_w, *qp_w, *at_v, *at_b;
     struct Fc { const float *w, *b, *cw; int K, P, Ppad, Pstore; int act; };
@@ -183,6 +185,42 @@ std::vector<int> gate_perm(int H) {
         for (int g = 0; g < 4; ++g)
             for (int jj = 0; jj < 32; ++jj) perm[w * 128 + g * 32 + jj] = g * H + 32 * w + jj;
     return perm;
+}
+
+uint16_t bf16_rne_bits(float x) {   // round-to-nearest-even, as the device's float -> __bf16 conversion
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7F800000u) == 0x7F800000u) return (uint16_t)(u >> 16);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+float bf16_bits_to_float(uint16_t b) {
+    const uint32_t u = (uint32_t)b << 16;
+    float x;
+    memcpy(&x, &u, 4);
+    return x;
+}
+
+// Frequency-LSTM weights for freq_lstm_bf16_kernel: per direction [plane hi | lo][24 octets][512 gate rows][8] bf16.
+// cat = [W_ih | W_hh] rows in torch order, perm = packed gate row -> torch row.  Octets 0..7 are the 64 input features
+// in order; octet 8 + o' (o' = 4w + 2q + hh) holds hidden units 32w+16q+4hh+{0..3} and 32w+16q+8+4hh+{0..3} -- the order
+// in which a lane of the kernel owns its accumulator rows (lstm.hip).
+void pack_freq_lstm_bf16(uint16_t *dst, const float *cat, const int *perm) {
+    for (int O = 0; O < 24; ++O)
+        for (int p = 0; p < 512; ++p)
+            for (int e = 0; e < 8; ++e) {
+                int k;
+                if (O < 8) k = 8 * O + e;
+                else {
+                    const int o = O - 8, w = o >> 2, q = (o >> 1) & 1, hh = o & 1;
+                    k = 64 + 32 * w + 16 * q + 4 * hh + (e & 3) + 8 * (e >> 2);
+                }
+                const float x = cat[(size_t)perm[p] * 192 + k];
+                const uint16_t hi = bf16_rne_bits(x);
+                const uint16_t lo = bf16_rne_bits(x - bf16_bits_to_float(hi));
+                dst[((size_t)O * 512 + p) * 8 + e] = hi;
+                dst[((size_t)(24 + O) * 512 + p) * 8 + e] = lo;
+            }
 }
 
 int pack_fc(sdfa_model *m, Packer &pk, const std::string &key, int P, int Kin, bool cond, int act, size_t off[3],
@@ -343,8 +381,9 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
         }
     }
     // ---- frequency LSTM: [W_ih | W_hh] concatenated along K, gate rows packed per wave; bias = b_ih + b_hh
-    size_t o_flw = pk.add(0), o_flb;
+    size_t o_flw = pk.add(0), o_flb, o_flwb;
     {
+        o_flwb = pk.add((size_t)2 * 2 * 24 * 512 * 8 / 2);   // bf16 planes, two per float slot
         const auto perm = gate_perm(128);
         const char *suf[2] = {"", "_reverse"};
         std::vector<float> cat((size_t)512 * 192);
@@ -360,6 +399,7 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
                 memcpy(&cat[(size_t)r * 192 + 64], &(*whh)[(size_t)r * 128], 128 * 4);
             }
             size_t o = pack_k4(pk, cat.data(), 512, 192, 192, 0, 192, 512, perm.data());
+            pack_freq_lstm_bf16(reinterpret_cast<uint16_t *>(&pk.buf[o_flwb]) + (size_t)d * 2 * 24 * 512 * 8, cat.data(), perm.data());
             if (d == 0) first = o;
             else if (o != first + (size_t)48 * 512 * 4) return fail(SDFA_ESTATE, "internal: freq-lstm weights not contiguous");
             for (int p = 0; p < 512; ++p) bias[d * 512 + p] = (*bih)[perm[p]] + (*bhh)[perm[p]];
@@ -471,6 +511,7 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
     m->w1 = d + o_conv[0][0]; m->b1 = d + o_conv[0][1]; m->s1 = d + o_conv[0][2]; m->t1 = d + o_conv[0][3];
     m->w2 = d + o_conv[1][0]; m->b2 = d + o_conv[1][1]; m->s2 = d + o_conv[1][2]; m->t2 = d + o_conv[1][3];
     m->w3 = d + o_conv[2][0]; m->b3 = d + o_conv[2][1]; m->s3 = d + o_conv[2][2]; m->t3 = d + o_conv[2][3];
+    m->fl_wb = d + o_flwb;
     m->fl_w = d + o_flw; m->fl_b = d + o_flb; m->fp_w = d + o_fpw; m->fp_b = d + o_fpb;
     for (int l = 0; l < 2; ++l) { m->gx_w[l] = d + o_gx[l]; m->tl_w[l] = d + o_tl[l]; }
     m->kp_w = d + o_kp; m->qc_w = d + o_qc; m->qp_w = d + o_qp; m->at_v = d + o_v; m->at_b = d + o_b;
@@ -565,8 +606,10 @@ int64_t sdfa_workspace_bytes(const sdfa_model *m, int64_t max_frames) {
 }
 
 extern int g_sdfa_gemm_variant;
+int g_sdfa_freq_lstm_shape = 0;
 int sdfa_debug_set_option(const char *name, int value) {
     if (name && !strcmp(name, "gemm_variant")) { g_sdfa_gemm_variant = value; return SDFA_OK; }
+    if (name && !strcmp(name, "freq_lstm_shape")) { g_sdfa_freq_lstm_shape = value; return SDFA_OK; }
     return fail(SDFA_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }
 
@@ -604,6 +647,28 @@ int sdfa_profile_reset(sdfa_model *m) { return m ? sdfa_profile_enable(m, m->pro
 static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t n_frames, const int32_t *d_frame_clip,
                         const int64_t *d_frame_start, int hop, float *d_z, float *d_align, void *d_workspace,
                         int64_t workspace_bytes, void *stream);
+
+// Mixed-precision modes (BASELINE configs[3]).  Which MFMA each stage runs on: 0 = fp32, 1 = bf16 operands,
+// 3 = split-bf16 (hi/lo operands, three MFMAs per product).  The conv stack, the BiLSTM recurrences, softmax/context and
+// every accumulation, bias and activation stay fp32 in all modes.
+enum { STAGE_BODY = 0, STAGE_ATTENTION = 1, STAGE_REGRESSOR = 2 };
+static int stage_terms(const sdfa_model *m, int stage) {
+    switch (m->precision) {
+    case SDFA_PREC_BF16_ATTENTION: return stage == STAGE_ATTENTION ? 1 : 0;
+    case SDFA_PREC_BF16X3: return 3;
+    case SDFA_PREC_BF16: return 1;
+    default: return 0;
+    }
+}
+
+int sdfa_model_set_precision(sdfa_model *m, int mode) {
+    if (!m) return fail(SDFA_EINVAL, "null model");
+    if (mode < SDFA_PREC_FP32 || mode > SDFA_PREC_BF16) return fail(SDFA_EINVAL, "unknown precision mode %d", mode);
+    m->precision = mode;
+    return SDFA_OK;
+}
+
+int sdfa_model_precision(const sdfa_model *m) { return m ? m->precision : SDFA_EINVAL; }
 
 int sdfa_encoder_forward(const sdfa_model *m, const float *d_audio_feat, int64_t n_frames, float *d_z, float *d_align,
                          void *d_workspace, int64_t workspace_bytes, void *stream) {
@@ -658,13 +723,14 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
         pf.begin("conv1"); HIP_TRY(sdfa_launch_conv1(ca, s)); pf.end();
         pf.begin("conv23"); HIP_TRY(sdfa_launch_conv23(ca, s)); pf.end();
 
-        FreqLstmArgs fa{ws + w.X3, m->fl_w, m->fl_b, ws + w.HF, Mc, d_ulimit};
+        FreqLstmArgs fa{ws + w.X3, m->fl_w, m->fl_b, ws + w.HF, Mc, d_ulimit, m->fl_wb, stage_terms(m, STAGE_BODY)};
         pf.begin("freq_lstm"); HIP_TRY(sdfa_launch_freq_lstm(fa, s)); pf.end();
 
         GemmArgs g{};   // FreqLstm._proj: Linear(8192 -> 256) + bias
         g.P = m->fp_w; g.Q = ws + w.HF; g.D = ws + w.Z; g.bias = m->fp_b;
         g.ldp = 256; g.ldq = Mc; g.ldd = Mc; g.Ppad = 256; g.Qpad = Mc; g.Pstore = 256; g.Qreal = Mc;
         g.K = 8192; g.seg_k = 8192; g.act = ACT_NONE; g.out_mode = OUT_K4; g.q_tile_major = 1;
+        g.terms = stage_terms(m, STAGE_BODY);
         if (share) { g.D = ws + w.ZU; g.q_limit = d_ulimit; }
         pf.begin("freq_proj"); HIP_TRY(sdfa_launch_gemm(g, s)); pf.end();
         if (share) {   // scatter every distinct column's 256 features to all the (t, n) columns that contain it
@@ -679,6 +745,7 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
             gi.P = m->gx_w[l]; gi.Q = xin; gi.D = ws + w.GX;
             gi.ldp = 2048; gi.ldq = Mc; gi.ldd = Mc; gi.Ppad = 2048; gi.Qpad = Mc; gi.Pstore = 2048; gi.Qreal = Mc;
             gi.K = l == 0 ? 256 : 512; gi.seg_k = gi.K; gi.act = ACT_NONE; gi.out_mode = OUT_K4;
+            gi.terms = stage_terms(m, STAGE_BODY);
             pf.begin(gxn[l]); HIP_TRY(sdfa_launch_gemm(gi, s)); pf.end();
             TimeLstmArgs ta{ws + w.GX, m->tl_w[l], hout[l], Nc, Mc};
             pf.begin(lsn[l]); HIP_TRY(sdfa_launch_time_lstm(ta, s)); pf.end();
@@ -689,17 +756,17 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
         GemmArgs gk{};
         gk.P = m->kp_w; gk.Q = ws + w.H1; gk.D = ws + w.KP;
         gk.ldp = 128; gk.ldq = Mc; gk.ldd = Mc; gk.Ppad = 128; gk.Qpad = Mc; gk.Pstore = 128; gk.Qreal = Mc;
-        gk.K = 512; gk.seg_k = 512; gk.act = ACT_NONE; gk.out_mode = OUT_K4;
+        gk.K = 512; gk.seg_k = 512; gk.act = ACT_NONE; gk.out_mode = OUT_K4; gk.terms = stage_terms(m, STAGE_ATTENTION);
         HIP_TRY(sdfa_launch_gemm(gk, s));
         GemmArgs gc{};
         gc.P = m->qc_w; gc.Q = ws + w.H1 + 31 * Nc * 4; gc.D = ws + w.QC;
         gc.ldp = 512; gc.ldq = Mc; gc.ldd = Nc; gc.Ppad = 512; gc.Qpad = Nc; gc.Pstore = 512; gc.Qreal = Nc;
-        gc.K = 1536; gc.seg_k = 512; gc.seg_col = Nc; gc.act = ACT_NONE; gc.out_mode = OUT_K4;
+        gc.K = 1536; gc.seg_k = 512; gc.seg_col = Nc; gc.act = ACT_NONE; gc.out_mode = OUT_K4; gc.terms = gk.terms;
         HIP_TRY(sdfa_launch_gemm(gc, s));
         GemmArgs gq{};
         gq.P = m->qp_w; gq.Q = ws + w.QC; gq.D = ws + w.QP;
         gq.ldp = 128; gq.ldq = Nc; gq.ldd = Nc; gq.Ppad = 128; gq.Qpad = Nc; gq.Pstore = 128; gq.Qreal = Nc;
-        gq.K = 512; gq.seg_k = 512; gq.act = ACT_NONE; gq.out_mode = OUT_K4;
+        gq.K = 512; gq.seg_k = 512; gq.act = ACT_NONE; gq.out_mode = OUT_K4; gq.terms = gk.terms;
         HIP_TRY(sdfa_launch_gemm(gq, s));
         pf.end();
 
@@ -724,6 +791,11 @@ int sdfa_regress_forward(const sdfa_model *m, const float *d_z, const int64_t *d
     hipStream_t s = (hipStream_t)stream;
     Prof pf{m, s};
     float *ws = (float *)d_workspace;
+    auto fcg = [m](const sdfa_model::Fc &fc, const float *Q, int64_t ldq, float *D, int64_t Nc, const int64_t *spk, int64_t nreal) {
+        GemmArgs g = gemm_fc(fc, Q, ldq, D, Nc, spk, nreal);
+        g.terms = stage_terms(m, STAGE_REGRESSOR);
+        return g;
+    };
     for (int64_t f0 = 0; f0 < n_frames; f0 += cap) {
         const int64_t N = std::min(cap, n_frames - f0);
         const int64_t Nc = round_up(N, 128);
@@ -734,20 +806,20 @@ int sdfa_regress_forward(const sdfa_model *m, const float *d_z, const int64_t *d
         pf.begin("mlp");
         HIP_TRY(sdfa_launch_rows_to_k4(d_z + f0 * 512, N, 512, zk, Nc, s));
         if (m->head == SDFA_HEAD_DGRAD) {
-            HIP_TRY(sdfa_launch_gemm(gemm_fc(m->trunk, zk, Nc, trunk, Nc, spk, N), s));
+            HIP_TRY(sdfa_launch_gemm(fcg(m->trunk, zk, Nc, trunk, Nc, spk, N), s));
             for (int b = 0; b < 2; ++b) {
-                HIP_TRY(sdfa_launch_gemm(gemm_fc(m->br[b][0], trunk, Nc, a0, Nc, spk, N), s));
-                HIP_TRY(sdfa_launch_gemm(gemm_fc(m->br[b][1], a0, Nc, a1, Nc, spk, N), s));
-                HIP_TRY(sdfa_launch_gemm(gemm_fc(m->br[b][2], a1, Nc, coef + (b ? 96 * Nc : 0), Nc, spk, N), s));
+                HIP_TRY(sdfa_launch_gemm(fcg(m->br[b][0], trunk, Nc, a0, Nc, spk, N), s));
+                HIP_TRY(sdfa_launch_gemm(fcg(m->br[b][1], a0, Nc, a1, Nc, spk, N), s));
+                HIP_TRY(sdfa_launch_gemm(fcg(m->br[b][2], a1, Nc, coef + (b ? 96 * Nc : 0), Nc, spk, N), s));
             }
             if (d_coef) {
                 HIP_TRY(sdfa_launch_k4_to_rows(coef, Nc, N, 288, 0, SDFA_COEF_SCALE, d_coef + f0 * m->coef_dim, m->coef_dim, s));
                 HIP_TRY(sdfa_launch_k4_to_rows(coef, Nc, N, 288, 96, SDFA_COEF_ROTAT, d_coef + f0 * m->coef_dim + SDFA_COEF_SCALE, m->coef_dim, s));
             }
         } else {
-            HIP_TRY(sdfa_launch_gemm(gemm_fc(m->off[0], zk, Nc, a0, Nc, spk, N), s));
-            HIP_TRY(sdfa_launch_gemm(gemm_fc(m->off[1], a0, Nc, a1, Nc, spk, N), s));
-            HIP_TRY(sdfa_launch_gemm(gemm_fc(m->off[2], a1, Nc, coef, Nc, spk, N), s));
+            HIP_TRY(sdfa_launch_gemm(fcg(m->off[0], zk, Nc, a0, Nc, spk, N), s));
+            HIP_TRY(sdfa_launch_gemm(fcg(m->off[1], a0, Nc, a1, Nc, spk, N), s));
+            HIP_TRY(sdfa_launch_gemm(fcg(m->off[2], a1, Nc, coef, Nc, spk, N), s));
             if (d_coef) HIP_TRY(sdfa_launch_k4_to_rows(coef, Nc, N, 64, 0, SDFA_COEF_OFFSETS, d_coef + f0 * m->coef_dim, m->coef_dim, s));
         }
         pf.end();
@@ -761,6 +833,7 @@ int sdfa_regress_forward(const sdfa_model *m, const float *d_z, const int64_t *d
                 g.ldp = Nc; g.ldq = m->pca_ld[b]; g.ldd = m->out_dim; g.Ppad = Nc; g.Qpad = m->pca_ld[b]; g.Pstore = N;
                 g.Qreal = m->pca_cols[b]; g.K = m->pca_K[b]; g.seg_k = g.K; g.act = ACT_NONE; g.out_mode = OUT_ROW;
                 g.col_group = m->pca_group[b]; g.col_stride = 9; g.col_off = m->pca_off[b];
+                g.terms = stage_terms(m, STAGE_REGRESSOR);
                 HIP_TRY(sdfa_launch_gemm(g, s));
             }
             pf.end();

@@ -278,8 +278,9 @@ hipError_t launch(const GemmArgs &a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Split-bf16 variant (opt-in, gemm_variant 4): fp32 operands are split on the fly into hi = bf16(x) and
-// lo = bf16(x - hi) while they are staged into LDS, and every product runs as three bf16 MFMAs
+// bf16-MFMA GEMM of the mixed-precision modes (GemmArgs.terms, set by sdfa_model_set_precision; also reachable as
+// gemm_variant 4 = TERMS 3 for A/B runs).  TERMS 1: operands rounded to bf16 while they are staged into LDS.
+// TERMS 3 (split-bf16): operands are split into hi = bf16(x) and lo = bf16(x - hi) and every product runs as three MFMAs
 //   a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi      (v_mfma_f32_32x32x16_bf16, fp32 accumulate)
 // i.e. 16 significand bits per operand at 16/3 = 5.3x the fp32 MFMA rate.  Measured operand-truncation error of
 // the whole model at 2 bf16 terms: 3.5e-6 on dgrad against the 1e-4 budget (profiles/r01_precision_sweep.json).
@@ -298,9 +299,11 @@ __device__ __forceinline__ void split8(const float4 &x0, const float4 &x1, bf16x
     }
 }
 
-template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
-__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
-    __shared__ bf16x8 sPh[2][4][TP], sPl[2][4][TP], sQh[2][4][TQ], sQl[2][4][TQ];   // 4 x 16 KiB
+template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND, int TERMS>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
+    constexpr bool LO = TERMS > 1;               // TERMS 1: plain bf16 operands; 3: hi/lo planes, three MFMAs per product
+    constexpr int NB = LO ? 2 : 1;
+    __shared__ bf16x8 sPh[2][4][TP], sQh[2][4][TQ], sPl[NB][4][TP], sQl[NB][4][TQ];   // 4 x 16 KiB (2 + 2 x 8 for TERMS 1)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp = wave >> 1, wq = wave & 1, l31 = lane & 31, h = lane >> 5;
@@ -327,15 +330,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
         const int seg = gkq / seg_kq, kin = gkq - seg * seg_kq;                                   \
         rp[it][0] = P[(int64_t)gkq * a.ldp + p0 + c];                                             \
         rp[it][1] = P[(int64_t)(gkq + 1) * a.ldp + p0 + c];                                       \
-        rq[it][0] = Q[(int64_t)kin * a.ldq + (int64_t)seg * a.seg_col + q0 + c];                  \
-        rq[it][1] = Q[(int64_t)(kin + 1) * a.ldq + (int64_t)seg * a.seg_col + q0 + c];            \
+        if (a.q_tile_major) {                                                                     \
+            rq[it][0] = Q[((q0 >> 7) * (int64_t)(a.K / 4) + gkq) * 128 + c];                      \
+            rq[it][1] = Q[((q0 >> 7) * (int64_t)(a.K / 4) + gkq + 1) * 128 + c];                  \
+        } else {                                                                                  \
+            rq[it][0] = Q[(int64_t)kin * a.ldq + (int64_t)seg * a.seg_col + q0 + c];              \
+            rq[it][1] = Q[(int64_t)(kin + 1) * a.ldq + (int64_t)seg * a.seg_col + q0 + c];        \
+        }                                                                                         \
     }
 #define BX_LSTORE(buf)                                                                            \
     _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                            \
         const int idx = it * 256 + tid, g = idx >> 7, c = idx & 127;                              \
         bf16x8 hi, lo;                                                                            \
-        split8(rp[it][0], rp[it][1], hi, lo); sPh[buf][g][c] = hi; sPl[buf][g][c] = lo;           \
-        split8(rq[it][0], rq[it][1], hi, lo); sQh[buf][g][c] = hi; sQl[buf][g][c] = lo;           \
+        split8(rp[it][0], rp[it][1], hi, lo); sPh[buf][g][c] = hi; if (LO) sPl[buf][g][c] = lo;   \
+        split8(rq[it][0], rq[it][1], hi, lo); sQh[buf][g][c] = hi; if (LO) sQl[buf][g][c] = lo;   \
     }
 
     BX_GLOAD(0)
@@ -350,15 +358,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
             bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                ah[i] = sPh[buf][2 * m + h][wp * 64 + i * 32 + l31]; al[i] = sPl[buf][2 * m + h][wp * 64 + i * 32 + l31];
-                bh[i] = sQh[buf][2 * m + h][wq * 64 + i * 32 + l31]; bl[i] = sQl[buf][2 * m + h][wq * 64 + i * 32 + l31];
+                ah[i] = sPh[buf][2 * m + h][wp * 64 + i * 32 + l31];
+                bh[i] = sQh[buf][2 * m + h][wq * 64 + i * 32 + l31];
+                if (LO) { al[i] = sPl[buf][2 * m + h][wp * 64 + i * 32 + l31]; bl[i] = sQl[buf][2 * m + h][wq * 64 + i * 32 + l31]; }
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    if (LO) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
@@ -374,10 +385,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
             store_tile<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, acc[i][j], p0 + wp * 64 + i * 32, q0 + wq * 64 + j * 32 + l31, h);
 }
 
-template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
-hipError_t launch_bf16x3(const GemmArgs &a, hipStream_t s) {
+template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND, int TERMS>
+hipError_t launch_bf16(const GemmArgs &a, hipStream_t s) {
     const int64_t nblk = (a.Ppad / TP) * (a.Qpad / TQ);
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>), dim3((unsigned)nblk), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((gemm_bf16_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, TERMS>), dim3((unsigned)nblk), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -569,12 +580,14 @@ int g_sdfa_gemm_variant = 0;   // 0 = LDS-tiled (default), 1/2 = register-direct
 
 template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
 hipError_t launch_any(const GemmArgs &a, hipStream_t s) {
+    if (a.terms == 1) return launch_bf16<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 1>(a, s);   // mixed-precision modes
+    if (a.terms == 3) return launch_bf16<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 3>(a, s);
+    if (g_sdfa_gemm_variant == 4 && !a.q_tile_major) return launch_bf16<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 3>(a, s);
     if (g_sdfa_gemm_variant == 6) return launch_pc<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
     if (a.q_tile_major) return launch<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);   // only the LDS-tiled kernels read that layout
     if (g_sdfa_gemm_variant == 1 && a.Ppad % 128 == 0) return launch_direct<4, OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
     if (g_sdfa_gemm_variant == 2 && a.Ppad % 64 == 0) return launch_direct<2, OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
     if (g_sdfa_gemm_variant == 3) return launch<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, true>(a, s);
-    if (g_sdfa_gemm_variant == 4) return launch_bf16x3<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
     if (g_sdfa_gemm_variant == 5 && a.Ppad % 256 == 0 && a.Qpad % 256 == 0) return launch_big<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
     return launch<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
 }

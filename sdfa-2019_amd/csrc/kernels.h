@@ -21,6 +21,7 @@ struct GemmArgs {
     int seg_k;           // contraction length per segment (= K when one segment)
     int64_t seg_col;     // Q column offset between segments
     int act, out_mode, bias_on_q;
+    int terms;                // 0 = fp32 MFMA; 1 = operands rounded to bf16; 3 = split-bf16, three bf16 MFMAs per product
     int q_tile_major;         // Q is stored tile-major: float4[column block of 128][K/4][128] (the freq-LSTM hidden states)
     const int64_t *q_limit;   // device scalar: tiles whose first column is >= *q_limit exit at once (null = no limit)
     int col_group, col_stride, col_off;   // OUT_ROW only: column q is stored at (q / group) * stride + off + q % group (group 0 = identity)
@@ -67,6 +68,8 @@ struct FreqLstmArgs {
     float *HF;           // K4 [8192/4][Mc]  rows f*256 + dir*128 + j
     int64_t Mc;
     const int64_t *col_limit;   // see ConvArgs
+    const void *Wb;      // mixed-precision modes: per direction bf16x8 [hi | lo][24 octets][512 rows] (lstm.hip)
+    int terms;           // 0 = fp32 MFMA; 1 = bf16 MFMA; 3 = split-bf16 (hi/lo) MFMA
 };
 hipError_t sdfa_launch_freq_lstm(const FreqLstmArgs &a, hipStream_t s);
 

@@ -46,16 +46,17 @@ __device__ __forceinline__ void lstm_cell_quad(const f32x16 &ai, const f32x16 &a
 // ------------------------------------------------------------------------------------ frequency LSTM
 // SHARED = launched over the compacted distinct-column list (column sharing): same code, separate symbol so that
 // profiles keep the two launch shapes apart.
-template <bool SHARED>
-__global__ __launch_bounds__(256, 2) void freq_lstm_kernel(FreqLstmArgs a) {
-    __shared__ float4 sH[32][64];       // h_{s-1}: 128 hidden as 32 k-quads x 64 sequences
-    __shared__ float4 sX[2][16][64];    // x_f tile, double buffered
+template <bool SHARED, int NJ, int WGS>
+__global__ __launch_bounds__(256, WGS) void freq_lstm_kernel(FreqLstmArgs a) {
+    constexpr int BT = 32 * NJ;         // sequences (columns) per workgroup
+    __shared__ float4 sH[32][BT];       // h_{s-1}: 128 hidden as 32 k-quads x BT sequences
+    __shared__ float4 sX[2][16][BT];    // x_f tile, double buffered
     __shared__ float sBias[512];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int dir = blockIdx.x & 1;
-    const int64_t m0 = (int64_t)(blockIdx.x >> 1) * 64;
+    const int64_t m0 = (int64_t)(blockIdx.x >> 1) * BT;
     if (SHARED && m0 >= *a.col_limit) return;
 
     const float4 *__restrict__ X3 = reinterpret_cast<const float4 *>(a.X3);
@@ -66,17 +67,17 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_kernel(FreqLstmArgs a) {
     sBias[256 + tid] = a.bias[dir * 512 + 256 + tid];
 
     float4 xr0, xr1, xr2, xr3;
-#define XLOAD1(f, i, R) { const int idx = (i)*256 + tid; R = X3[(int64_t)((f)*16 + (idx >> 6)) * a.Mc + m0 + (idx & 63)]; }
+#define XLOAD1(f, i, R) if ((i) < 2 * NJ) { const int idx = (i)*256 + tid; R = X3[(int64_t)((f)*16 + idx / BT) * a.Mc + m0 + idx % BT]; }
 #define XLOAD(f) XLOAD1(f, 0, xr0) XLOAD1(f, 1, xr1) XLOAD1(f, 2, xr2) XLOAD1(f, 3, xr3)
-#define XSTORE1(buf, i, R) { const int idx = (i)*256 + tid; sX[buf][idx >> 6][idx & 63] = R; }
+#define XSTORE1(buf, i, R) if ((i) < 2 * NJ) { const int idx = (i)*256 + tid; sX[buf][idx / BT][idx % BT] = R; }
 #define XSTORE(buf) XSTORE1(buf, 0, xr0) XSTORE1(buf, 1, xr1) XSTORE1(buf, 2, xr2) XSTORE1(buf, 3, xr3)
     XLOAD(dir ? 31 : 0)
     XSTORE(0)
     __syncthreads();
 
-    f32x16 c[2];
+    f32x16 c[NJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) c[j][r] = 0.f;
 
@@ -91,25 +92,27 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_kernel(FreqLstmArgs a) {
         LSTAMP(q0)
         if (s + 1 < 32) { XLOAD(dir ? 30 - s : s + 1) }
 
-        f32x16 acc[4][2];
+        f32x16 acc[4][NJ];
 #pragma unroll
         for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float4 b = *reinterpret_cast<const float4 *>(&sBias[wave * 128 + gt * 32 + 8 * g + 4 * h]);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     acc[gt][j][4 * g + 0] = b.x; acc[gt][j][4 * g + 1] = b.y;
                     acc[gt][j][4 * g + 2] = b.z; acc[gt][j][4 * g + 3] = b.w;
                 }
             }
         // one loop over the concatenated K: k-quads 0..15 = x_f (from sX), 16..47 = h_{s-1} (from sH; h_{-1} = 0 is
-        // skipped on the first step).  Weights for k-block kb+1 are requested before the 32 MFMAs of kb are issued,
-        // so the L2 round trip hides behind 2048 cycles of matrix work.
+        // skipped on the first step).  Weights for k-block kb+1 are requested before the MFMAs of kb are issued,
+        // so the L2 round trip hides behind the matrix work.
         const int nkb = s > 0 ? 24 : 8;
         const float4 *__restrict__ wp = Ww + h * 512;
         float4 wn0 = wp[0], wn1 = wp[32], wn2 = wp[64], wn3 = wp[96];
-        float4 bn0 = sX[cur][h][l31], bn1 = sX[cur][h][32 + l31];
+        float4 bn[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bn[j] = sX[cur][h][j * 32 + l31];
         LSTAMP(q1)
 #ifdef SDFA_STAMPS
         s_init += q1 - q0;
@@ -120,19 +123,27 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_kernel(FreqLstmArgs a) {
 #pragma unroll 2
 #endif
         for (int kb = 0; kb < nkb; ++kb) {
-            const float4 w0 = wn0, w1 = wn1, w2 = wn2, w3 = wn3, b0 = bn0, b1 = bn1;
+            const float4 w0 = wn0, w1 = wn1, w2 = wn2, w3 = wn3;
+            float4 b[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) b[j] = bn[j];
             LSTAMP(q2)
             if (kb + 1 < nkb) {
                 const float4 *__restrict__ wq = wp + (kb + 1) * 1024;
                 wn0 = wq[0]; wn1 = wq[32]; wn2 = wq[64]; wn3 = wq[96];
                 const float4 *bsrc = kb + 1 < 8 ? &sX[cur][2 * kb + 2 + h][0] : &sH[2 * (kb - 7) + h][0];
-                bn0 = bsrc[l31]; bn1 = bsrc[32 + l31];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) bn[j] = bsrc[j * 32 + l31];
             }
             LSTAMP(q3)
-            mfma4(acc[0][0], w0, b0); mfma4(acc[0][1], w0, b1);
-            mfma4(acc[1][0], w1, b0); mfma4(acc[1][1], w1, b1);
-            mfma4(acc[2][0], w2, b0); mfma4(acc[2][1], w2, b1);
-            mfma4(acc[3][0], w3, b0); mfma4(acc[3][1], w3, b1);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) mfma4(acc[0][j], w0, b[j]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) mfma4(acc[1][j], w1, b[j]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) mfma4(acc[2][j], w2, b[j]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) mfma4(acc[3][j], w3, b[j]);
             LSTAMP(q4)
 #ifdef SDFA_STAMPS
             s_ld += q3 - q2; s_mf += q4 - q3;
@@ -141,23 +152,25 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_kernel(FreqLstmArgs a) {
         LSTAMP(q2)
         __syncthreads();   // every wave has finished reading sH / sX[cur]
         LSTAMP(q3)
+        // hidden states go out TILE-MAJOR: float4[column block of 128][8192/4 rows][128]: a workgroup's share of a
+        // step is contiguous runs, and the projection GEMM streams each column block front to back
 #ifdef SDFA_STAMPS
         {   // diagnostic split: math first, then LDS writes, then global stores
-            float4 hq[2][4];
+            float4 hq[NJ][4];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) lstm_cell_quad(acc[0][j], acc[1][j], acc[2][j], acc[3][j], c[j], g, hq[j][g]);
             unsigned long long e1, e2, e3;
             LSTAMP(e1)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) sH[8 * wave + 2 * g + h][j * 32 + l31] = hq[j][g];
             if (s + 1 < 32) { XSTORE(cur ^ 1) }
             LSTAMP(e2)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) HF[((m0 >> 7) * (int64_t)2048 + (f * 64 + dir * 32 + 8 * wave + 2 * g + h)) * 128 + (m0 & 127) + j * 32 + l31] = hq[j][g];
             LSTAMP(e3)
@@ -165,15 +178,13 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_kernel(FreqLstmArgs a) {
         }
 #else
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float4 hq;
                 lstm_cell_quad(acc[0][j], acc[1][j], acc[2][j], acc[3][j], c[j], g, hq);
                 const int hq_idx = 8 * wave + 2 * g + h;
                 sH[hq_idx][j * 32 + l31] = hq;
-                // hidden states go out TILE-MAJOR: float4[column block of 128][8192/4 rows][128]: a workgroup's 32 KB of a
-                // step are contiguous, and the projection GEMM streams each column block front to back
                 HF[((m0 >> 7) * (int64_t)2048 + (f * 64 + dir * 32 + hq_idx)) * 128 + (m0 & 127) + j * 32 + l31] = hq;
             }
         if (s + 1 < 32) { XSTORE(cur ^ 1) }
@@ -192,6 +203,165 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_kernel(FreqLstmArgs a) {
         atomicAdd(&g_lstamp[3], s_b2);
     }
 #endif
+}
+
+// --------------------------------------------------------------------- frequency LSTM on bf16 MFMA
+// Mixed-precision modes (BASELINE configs[3]; sdfa_model_set_precision): the same recurrence on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation, fp32 cell state and fp32 gate math.
+//   TERMS 1: operands rounded to bf16 (8 significand bits).
+//   TERMS 3: operands split into hi = bf16(x), lo = bf16(x - hi) (16 bits); a*b = a_lo*b_hi + a_hi*b_lo + a_hi*b_hi.
+// Operand image ("K8"): bf16x8[k/8][column] -- one ds_read_b128 / global_load_dwordx4 is one MFMA fragment (lane =
+// row/column, lane half = which 8 of the 16 k).  x_f is split while it is staged (octet o = K4 quads 2o, 2o+1);
+// h is split by the lane that produced it, which owns rows 32w+8g+4h+{0..3} for g = 0..3 -- so octet 4w+2q+h holds
+// hidden units 32w+16q+4h+{0..3} and 32w+16q+8+4h+{0..3}, and the host packs W_hh's K axis in that same order
+// (api.cpp: pack_freq_lstm_bf16).  Weights arrive pre-split (hi plane, lo plane) and stream from L2 as before.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ void split_octet(const float4 &x0, const float4 &x1, bf16x8 &hi, bf16x8 &lo) {
+    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 hb = (__bf16)x[e];
+        hi[e] = hb;
+        lo[e] = (__bf16)(x[e] - (float)hb);
+    }
+}
+
+template <bool SHARED, int TERMS>
+__global__ __launch_bounds__(256, 2) void freq_lstm_bf16_kernel(FreqLstmArgs a) {
+    constexpr bool LO = TERMS > 1;
+    constexpr int NPL = LO ? 2 : 1;              // operand planes
+    __shared__ bf16x8 sH[NPL][16][64];           // h_{s-1}: 128 hidden as 16 octets x 64 sequences, per plane
+    __shared__ bf16x8 sX[2][NPL][8][64];         // x_f: 64 features as 8 octets, double buffered
+    __shared__ float sBias[512];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int dir = blockIdx.x & 1;
+    const int64_t m0 = (int64_t)(blockIdx.x >> 1) * 64;
+    if (SHARED && m0 >= *a.col_limit) return;
+
+    const float4 *__restrict__ X3 = reinterpret_cast<const float4 *>(a.X3);
+    // per direction: [plane hi | lo][24 octets][512 gate rows]
+    const bf16x8 *__restrict__ Wh = reinterpret_cast<const bf16x8 *>(a.Wb) + (size_t)dir * 2 * 24 * 512 + wave * 128 + l31;
+    const bf16x8 *__restrict__ Wl = Wh + 24 * 512;
+    float4 *__restrict__ HF = reinterpret_cast<float4 *>(a.HF);
+
+    sBias[tid] = a.bias[dir * 512 + tid];
+    sBias[256 + tid] = a.bias[dir * 512 + 256 + tid];
+
+    // staging of x_f: thread -> (octet, column) pairs p = i*256 + tid, i = 0, 1
+    float4 xr0, xr1, xr2, xr3;
+#define BXLOAD(f)                                                                                  \
+    {                                                                                              \
+        const int o0 = tid >> 6, o1 = 4 + (tid >> 6), col = tid & 63;                              \
+        xr0 = X3[(int64_t)((f)*16 + 2 * o0) * a.Mc + m0 + col];                                    \
+        xr1 = X3[(int64_t)((f)*16 + 2 * o0 + 1) * a.Mc + m0 + col];                                \
+        xr2 = X3[(int64_t)((f)*16 + 2 * o1) * a.Mc + m0 + col];                                    \
+        xr3 = X3[(int64_t)((f)*16 + 2 * o1 + 1) * a.Mc + m0 + col];                                \
+    }
+#define BXSTORE(buf)                                                                               \
+    {                                                                                              \
+        const int o0 = tid >> 6, o1 = 4 + (tid >> 6), col = tid & 63;                              \
+        bf16x8 hi, lo;                                                                             \
+        split_octet(xr0, xr1, hi, lo); sX[buf][0][o0][col] = hi; if (LO) sX[buf][NPL - 1][o0][col] = lo; \
+        split_octet(xr2, xr3, hi, lo); sX[buf][0][o1][col] = hi; if (LO) sX[buf][NPL - 1][o1][col] = lo; \
+    }
+    BXLOAD(dir ? 31 : 0)
+    BXSTORE(0)
+    __syncthreads();
+
+    f32x16 c[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[j][r] = 0.f;
+
+    for (int s = 0; s < 32; ++s) {
+        const int f = dir ? 31 - s : s;
+        const int cur = s & 1;
+
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 b = *reinterpret_cast<const float4 *>(&sBias[wave * 128 + gt * 32 + 8 * g + 4 * h]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[gt][j][4 * g + 0] = b.x; acc[gt][j][4 * g + 1] = b.y;
+                    acc[gt][j][4 * g + 2] = b.z; acc[gt][j][4 * g + 3] = b.w;
+                }
+            }
+        // k-steps of 16: 0..3 = x_f (octets 0..7 of sX), 4..11 = h_{s-1} (octets 0..15 of sH; skipped on the first step).
+        // Weight fragments of k-step ks+1 are requested before the MFMAs of ks are issued.
+        const int nks = s > 0 ? 12 : 4;
+        // The hi plane is requested one k-step ahead; the lo plane at the top of its own k-step -- it is only needed by
+        // the last third of the step's MFMAs (order hi*hi, hi*lo, lo*hi), which keeps the kernel at 256 VGPRs.
+        bf16x8 whn[4];
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt) whn[gt] = Wh[h * 512 + gt * 32];
+#pragma unroll 1
+        for (int ks = 0; ks < nks; ++ks) {
+            bf16x8 wh[4], wl[4], bh[2], bl[2];
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt) {
+                wh[gt] = whn[gt];
+                if (LO) wl[gt] = Wl[(2 * ks + h) * 512 + gt * 32];
+            }
+            if (ks + 1 < nks) {
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt) whn[gt] = Wh[(2 * (ks + 1) + h) * 512 + gt * 32];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (ks < 4) {
+                    bh[j] = sX[cur][0][2 * ks + h][j * 32 + l31];
+                    if (LO) bl[j] = sX[cur][NPL - 1][2 * ks + h][j * 32 + l31];
+                } else {
+                    bh[j] = sH[0][2 * (ks - 4) + h][j * 32 + l31];
+                    if (LO) bl[j] = sH[NPL - 1][2 * (ks - 4) + h][j * 32 + l31];
+                }
+            }
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[gt][j] = MFMA_BF16(wh[gt], bh[j], acc[gt][j]);
+            if (LO) {
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[gt][j] = MFMA_BF16(wh[gt], bl[j], acc[gt][j]);
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[gt][j] = MFMA_BF16(wl[gt], bh[j], acc[gt][j]);
+            }
+        }
+        __syncthreads();   // every wave has finished reading sH / sX[cur]
+        if (s + 1 < 32) { BXLOAD(dir ? 30 - s : s + 1) }   // lands while the cell update runs
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float4 hq[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                lstm_cell_quad(acc[0][j], acc[1][j], acc[2][j], acc[3][j], c[j], g, hq[g]);
+                HF[((m0 >> 7) * (int64_t)2048 + (f * 64 + dir * 32 + 8 * wave + 2 * g + h)) * 128 + (m0 & 127) + j * 32 + l31] = hq[g];
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                bf16x8 hi, lo;
+                split_octet(hq[2 * q], hq[2 * q + 1], hi, lo);
+                sH[0][4 * wave + 2 * q + h][j * 32 + l31] = hi;
+                if (LO) sH[NPL - 1][4 * wave + 2 * q + h][j * 32 + l31] = lo;
+            }
+        }
+        if (s + 1 < 32) { BXSTORE(cur ^ 1) }
+        __syncthreads();
+    }
+#undef BXLOAD
+#undef BXSTORE
 }
 
 // ----------------------------------------------------------------------------------------- time LSTM
@@ -277,12 +447,32 @@ extern "C" int sdfa_debug_read_lstm_stamps(unsigned long long *out, int reset) {
 }
 #endif
 
-hipError_t sdfa_launch_freq_lstm(const FreqLstmArgs &a, hipStream_t s) {
-    if (a.col_limit)
-        hipLaunchKernelGGL(freq_lstm_kernel<true>, dim3((unsigned)(a.Mc / 64 * 2)), dim3(256), 0, s, a);
+extern int g_sdfa_freq_lstm_shape;   // api.cpp ("freq_lstm_shape" option): 0 = 64 columns x 2 workgroups/CU, 1 = 32 x 4, 2 = 32 x 3
+
+template <bool SHARED>
+static hipError_t launch_freq(const FreqLstmArgs &a, hipStream_t s) {
+    if (g_sdfa_freq_lstm_shape == 1)
+        hipLaunchKernelGGL((freq_lstm_kernel<SHARED, 1, 4>), dim3((unsigned)(a.Mc / 32 * 2)), dim3(256), 0, s, a);
+    else if (g_sdfa_freq_lstm_shape == 2)
+        hipLaunchKernelGGL((freq_lstm_kernel<SHARED, 1, 3>), dim3((unsigned)(a.Mc / 32 * 2)), dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL(freq_lstm_kernel<false>, dim3((unsigned)(a.Mc / 64 * 2)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((freq_lstm_kernel<SHARED, 2, 2>), dim3((unsigned)(a.Mc / 64 * 2)), dim3(256), 0, s, a);
     return hipGetLastError();
+}
+
+template <bool SHARED>
+static hipError_t launch_freq_bf16(const FreqLstmArgs &a, hipStream_t s) {
+    if (!a.Wb) return hipErrorInvalidValue;
+    if (a.terms == 1)
+        hipLaunchKernelGGL((freq_lstm_bf16_kernel<SHARED, 1>), dim3((unsigned)(a.Mc / 64 * 2)), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((freq_lstm_bf16_kernel<SHARED, 3>), dim3((unsigned)(a.Mc / 64 * 2)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t sdfa_launch_freq_lstm(const FreqLstmArgs &a, hipStream_t s) {
+    if (a.terms) return a.col_limit ? launch_freq_bf16<true>(a, s) : launch_freq_bf16<false>(a, s);
+    return a.col_limit ? launch_freq<true>(a, s) : launch_freq<false>(a, s);
 }
 
 template <int NT>

@@ -82,7 +82,9 @@ class FrontendOnly:
 class Engine(FrontendOnly):
     """One model replica on one GPU."""
 
-    def __init__(self, state_dict, device="cuda:0", max_frames=8192, debug_keep=False):
+    PRECISIONS = {"fp32": 0, "bf16_attention": 1, "bf16x3": 2, "bf16": 3}      # include/sdfa_hip.h SDFA_PREC_*
+
+    def __init__(self, state_dict, device="cuda:0", max_frames=8192, debug_keep=False, precision="fp32"):
         super().__init__(device)
         folded = fold_state_dict(state_dict)
         self.head = head_of(state_dict)
@@ -98,6 +100,14 @@ class Engine(FrontendOnly):
         self.coef_dim = int(lib.sdfa_model_coef_dim(self._m))
         self.max_frames = int(max_frames)
         self._ws = None
+        self.set_precision(precision)
+
+    def set_precision(self, precision):
+        """Matrix instruction of the dense contractions (BASELINE configs[3]); "fp32" is the reference's arithmetic."""
+        if precision not in self.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}, got {precision!r}")
+        check(lib.sdfa_model_set_precision(self._m, self.PRECISIONS[precision]))
+        self.precision = precision
 
     def __del__(self):
         m, self._m = getattr(self, "_m", None), None

@@ -50,6 +50,7 @@ DEFAULTS = dict(
     model=dict(face_data_type="dgrad_3d", prediction_type="face_data", weight_norm=True,
                speaker_embedding=dict(using_onehot=True, num_speakers=8)),
     trainer=dict(evaluate=dict(test=[])),
+    precision="fp32",       # not in the reference (fp32 only): MFMA mode of this build, see include/sdfa_hip.h SDFA_PREC_*
     device="cuda:0", eval_input=None, eval_spk_cond=None, load_from=None, log_dir=None,
 )
 

@@ -30,7 +30,8 @@ class SpeechDrivenAnimation:
         want = "dgrad" if self._face_type == "dgrad_3d" else "offsets"
         if head != want:
             raise RuntimeError(f"checkpoint holds a '{head}' output module but hparams.model.face_data_type = {self._face_type}")
-        self._engine = Engine(state_dict, device=self.hp.get("device", "cuda:0") or "cuda:0")
+        self._engine = Engine(state_dict, device=self.hp.get("device", "cuda:0") or "cuda:0",
+                              precision=self.hp.get("precision", "fp32") or "fp32")
         return self
 
     def eval(self):
