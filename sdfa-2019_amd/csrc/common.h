@@ -49,6 +49,22 @@ __device__ __forceinline__ void mfma4(f32x16 &acc, const float4 &a, const float4
     acc = MFMA(SDFA_OP(a.w), SDFA_OP(b.w), acc);
 }
 
+__device__ __forceinline__ float f4c(const float4 &v, int q) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; }
+
+// One k-quad of A (M row tiles) against one k-quad of B (N column tiles) into an M x N block of accumulators, issued
+// COMPONENT-major: consecutive MFMAs go to different accumulators.  A 32x32x2 MFMA that reads the accumulator the
+// previous one writes cannot start until that one has drained (16 passes + write-back), which a lone wave feels as
+// ~10 % lost issue slots (tools/mfma_peak3.hip: 138 vs 155 TFLOP/s); with M*N >= 4 independent tiles in between it does not.
+template <int M, int N>
+__device__ __forceinline__ void mfma_block(f32x16 (&acc)[M][N], const float4 (&a)[M], const float4 (&b)[N]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc[i][j] = MFMA(SDFA_OP(f4c(a[i], q)), SDFA_OP(f4c(b[j], q)), acc[i][j]);
+}
+
 __device__ __forceinline__ float lrelu02(float x) { return x >= 0.f ? x : 0.2f * x; }
 
 // v_exp_f32 / v_rcp_f32 based, branch-free (1-2 ulp each; absolute error ~1e-7, which is what the

@@ -84,6 +84,13 @@ __global__ __launch_bounds__(256, 2) void gemm_k4_kernel(GemmArgs a) {
     const int nkq_total = a.K / 4;
     const int seg_kq = a.seg_k / 4;
     const int nstage = nkq_total / KQ;
+    // tile-major Q (frequency-LSTM hidden states): a column block of 128 is one contiguous [K/4][128] slab
+    const int64_t qrow = a.q_tile_major ? 128 : a.ldq;               // float4 elements between consecutive k-quads
+    const float4 *Pn = P + p0;
+    const float4 *Qn = a.q_tile_major ? Q + (q0 >> 7) * (int64_t)nkq_total * 128 : Q + q0;
+    int kin_n = 0;
+    const unsigned boffP = (unsigned)(((tid >> 7) * a.ldp + (tid & 127)) * 16);
+    const unsigned boffQ = (unsigned)(((tid >> 7) * qrow + (tid & 127)) * 16);
 
     // Register staging runs TWO tiles ahead of the MFMAs: while tile st is multiplied out of LDS, tile st+1 sits
     // in one register set (written to the other LDS buffer at the end of the stage) and the loads of tile st+2 are
@@ -91,16 +98,27 @@ __global__ __launch_bounds__(256, 2) void gemm_k4_kernel(GemmArgs a) {
     // frequency projection) takes longer than that to arrive, which held the kernel at 76 % with a single tile ahead.
     float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;   // set A: P quads ra*, Q quads rb*
     float4 rc0, rc1, rc2, rc3, rd0, rd1, rd2, rd3;   // set B
-#define GEMM_GLOAD1(st, i, RP, RQ)                                                           \
-    {                                                                                        \
-        const int idx = (i)*256 + tid, kq = idx >> 7, c = idx & 127, gkq = (st)*KQ + kq;     \
-        RP = P[(int64_t)gkq * a.ldp + p0 + c];                                               \
-        const int seg = gkq / seg_kq, kin = gkq - seg * seg_kq;                              \
-        RQ = a.q_tile_major ? Q[((q0 >> 7) * (int64_t)nkq_total + gkq) * 128 + c]           \
-                            : Q[(int64_t)kin * a.ldq + (int64_t)seg * a.seg_col + q0 + c];   \
+    // Addressing of the staging loads: a UNIFORM running base per operand (scalar registers, advanced by scalar adds)
+    // plus one loop-invariant 32-bit byte offset per thread -- the global_load "saddr + voffset" form, so a load costs
+    // no vector-ALU instruction.  (fp32 MFMA and VALU instructions share the SIMD's issue cycles: measured with
+    // tools/mfma_valu.hip, every VALU instruction takes ~4 cycles away from the matrix pipe.  The first version of
+    // this kernel recomputed 64-bit addresses and the segment division per load: ~170 VALU instructions per stage of
+    // 64 MFMAs, i.e. 15 % of the pipe.)
+#define GEMM_GLOAD1(i, RP, RQ)                                                                          \
+    {                                                                                                   \
+        RP = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Pn + (i) * 2 * a.ldp) + boffP); \
+        RQ = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Qn + (i) * 2 * qrow) + boffQ);  \
     }
-#define GEMM_GLOAD_A(st) GEMM_GLOAD1(st, 0, ra0, rb0) GEMM_GLOAD1(st, 1, ra1, rb1) GEMM_GLOAD1(st, 2, ra2, rb2) GEMM_GLOAD1(st, 3, ra3, rb3)
-#define GEMM_GLOAD_B(st) GEMM_GLOAD1(st, 0, rc0, rd0) GEMM_GLOAD1(st, 1, rc1, rd1) GEMM_GLOAD1(st, 2, rc2, rd2) GEMM_GLOAD1(st, 3, rc3, rd3)
+#define GEMM_ADVANCE()                                                                                  \
+    {                                                                                                   \
+        Pn += KQ * a.ldp;                                                                               \
+        kin_n += KQ;                                                                                    \
+        if (kin_n == seg_kq) { kin_n = 0; Qn += a.seg_col - (int64_t)(seg_kq - KQ) * qrow; }            \
+        else Qn += KQ * qrow;                                                                           \
+    }
+    // stages are requested strictly in order (0, 1, 2, ...), so the bases just run forward
+#define GEMM_GLOAD_A(st) GEMM_GLOAD1(0, ra0, rb0) GEMM_GLOAD1(1, ra1, rb1) GEMM_GLOAD1(2, ra2, rb2) GEMM_GLOAD1(3, ra3, rb3) GEMM_ADVANCE()
+#define GEMM_GLOAD_B(st) GEMM_GLOAD1(0, rc0, rd0) GEMM_GLOAD1(1, rc1, rd1) GEMM_GLOAD1(2, rc2, rd2) GEMM_GLOAD1(3, rc3, rd3) GEMM_ADVANCE()
 #define GEMM_LSTORE1(buf, i, RP, RQ)                                   \
     {                                                                  \
         const int idx = (i)*256 + tid, kq = idx >> 7, c = idx & 127;   \
@@ -124,10 +142,9 @@ __global__ __launch_bounds__(256, 2) void gemm_k4_kernel(GemmArgs a) {
     }
 #define GEMM_COMPUTE(buf)                                                                                              \
     _Pragma("unroll") for (int kb = 0; kb < KQ / 2; ++kb) {                                                            \
-        const float4 a0 = sP[buf][2 * kb + h][wp * 64 + l31], a1 = sP[buf][2 * kb + h][wp * 64 + 32 + l31];            \
-        const float4 b0 = sQ[buf][2 * kb + h][wq * 64 + l31], b1 = sQ[buf][2 * kb + h][wq * 64 + 32 + l31];            \
-        mfma4(acc[0][0], a0, b0); mfma4(acc[0][1], a0, b1);                                                            \
-        mfma4(acc[1][0], a1, b0); mfma4(acc[1][1], a1, b1);                                                            \
+        const float4 fa[2] = {sP[buf][2 * kb + h][wp * 64 + l31], sP[buf][2 * kb + h][wp * 64 + 32 + l31]};            \
+        const float4 fb[2] = {sQ[buf][2 * kb + h][wq * 64 + l31], sQ[buf][2 * kb + h][wq * 64 + 32 + l31]};            \
+        mfma_block<2, 2>(acc, fa, fb);                                                                                 \
     }
 
     f32x16 acc[2][2];
@@ -159,27 +176,28 @@ __global__ __launch_bounds__(256, 2) void gemm_k4_kernel(GemmArgs a) {
         GEMM_LSTORE_A(0)
         if (nstage > 1) { GEMM_GLOAD_A(1) }
         __syncthreads();
-        for (int st = 0; st < nstage; st += 2) {
+        int st = 0;
+        for (; st + 1 < nstage; st += 2) {
             // even stage: LDS buffer 0 holds tile st, set A holds tile st+1
             STAMP(t0)
             if (st + 2 < nstage) { GEMM_GLOAD_B(st + 2) }
             STAMP(t1)
             GEMM_COMPUTE(0)
             STAMP(t2)
-            if (st + 1 < nstage) { GEMM_LSTORE_A(1) }
+            GEMM_LSTORE_A(1)
             STAMP(t3)
             __syncthreads();
             STAMP(t4)
 #ifdef SDFA_STAMPS
             sum_load += t1 - t0; sum_mfma += t2 - t1; sum_store += t3 - t2; sum_bar += t4 - t3;
 #endif
-            if (st + 1 >= nstage) break;
             // odd stage: LDS buffer 1 holds tile st+1, set B holds tile st+2
             if (st + 3 < nstage) { GEMM_GLOAD_A(st + 3) }
             GEMM_COMPUTE(1)
             if (st + 2 < nstage) { GEMM_LSTORE_B(0) }
             __syncthreads();
         }
+        if (st < nstage) { GEMM_COMPUTE(0) }   // odd stage count: the last tile is already in LDS buffer 0
 #ifdef SDFA_STAMPS
         if (lane == 0 && nstage >= 64) {
             atomicAdd(&g_stamp[0], sum_load); atomicAdd(&g_stamp[1], sum_mfma); atomicAdd(&g_stamp[2], sum_store);

@@ -24,6 +24,17 @@ __device__ unsigned long long g_lstamp[8];
 #define LSTAMP(t)
 #endif
 
+#ifdef SDFA_CLOCKPROBE
+// DIAGNOSTIC BUILD ONLY (make EXP=CLOCKPROBE, tools/clock_probe.py): shader-clock cycles (s_memtime) and 100 MHz
+// reference ticks (s_memrealtime) spent inside freq_lstm_kernel workgroups -> the clock the kernel actually ran at.
+__device__ unsigned long long g_clockprobe[3];
+extern "C" int sdfa_debug_read_clockprobe(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clockprobe), sizeof(unsigned long long) * 3) != hipSuccess) return -3;
+    if (reset) { unsigned long long z[3] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_clockprobe), z, sizeof z) != hipSuccess) return -3; }
+    return 0;
+}
+#endif
+
 namespace {
 
 __device__ __forceinline__ void lstm_cell_quad(const f32x16 &ai, const f32x16 &af, const f32x16 &ag, const f32x16 &ao,
@@ -32,6 +43,9 @@ __device__ __forceinline__ void lstm_cell_quad(const f32x16 &ai, const f32x16 &a
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int r = 4 * g + e;
+#ifdef SDFA_FAKE_CELL   /* timing experiment only: what does the cell math cost? */
+        { float cn = af[r] * c[r] + ai[r] * ag[r]; c[r] = cn; hv[e] = ao[r] * cn; continue; }
+#endif
         float ig = sigmoidf_acc(ai[r]);
         float fg = sigmoidf_acc(af[r]);
         float gg = tanhf_acc(ag[r]);
@@ -65,6 +79,9 @@ __global__ __launch_bounds__(256, WGS) void freq_lstm_kernel(FreqLstmArgs a) {
 
     sBias[tid] = a.bias[dir * 512 + tid];
     sBias[256 + tid] = a.bias[dir * 512 + 256 + tid];
+#ifdef SDFA_CLOCKPROBE
+    const unsigned long long cp_c0 = clock64(), cp_r0 = wall_clock64();
+#endif
 
     float4 xr0, xr1, xr2, xr3;
 #define XLOAD1(f, i, R) if ((i) < 2 * NJ) { const int idx = (i)*256 + tid; R = X3[(int64_t)((f)*16 + idx / BT) * a.Mc + m0 + idx % BT]; }
@@ -90,7 +107,6 @@ __global__ __launch_bounds__(256, WGS) void freq_lstm_kernel(FreqLstmArgs a) {
         const int f = dir ? 31 - s : s;
         const int cur = s & 1;
         LSTAMP(q0)
-        if (s + 1 < 32) { XLOAD(dir ? 30 - s : s + 1) }
 
         f32x16 acc[4][NJ];
 #pragma unroll
@@ -109,46 +125,53 @@ __global__ __launch_bounds__(256, WGS) void freq_lstm_kernel(FreqLstmArgs a) {
         // so the L2 round trip hides behind the matrix work.
         const int nkb = s > 0 ? 24 : 8;
         const float4 *__restrict__ wp = Ww + h * 512;
-        float4 wn0 = wp[0], wn1 = wp[32], wn2 = wp[64], wn3 = wp[96];
-        float4 bn[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) bn[j] = sX[cur][h][j * 32 + l31];
+        // Two named operand sets (A, B) alternate, so the prefetched quads are consumed where they landed -- a
+        // "current = next" hand-over costs 12 v_mov_b64 per k-block, and vector-ALU cycles come out of the MFMA pipe.
+        float4 wa0, wa1, wa2, wa3, wb0, wb1, wb2, wb3, ba[NJ], bb[NJ];
+#ifdef SDFA_FAKE_WLOAD   /* timing experiment only: every k-block re-reads the SAME weight quads (L1 hits) */
+#define FL_WSTEP(kb) ((kb) & 1)
+#else
+#define FL_WSTEP(kb) (kb)
+#endif
+#define FL_LOAD(kb, W0, W1, W2, W3, B)                                                                       \
+    {                                                                                                        \
+        const float4 *__restrict__ wq = wp + (FL_WSTEP(kb)) * 1024;                                          \
+        W0 = wq[0]; W1 = wq[32]; W2 = wq[64]; W3 = wq[96];                                                   \
+        const float4 *bsrc = (kb) < 8 ? &sX[cur][2 * (kb) + h][0] : &sH[2 * ((kb) - 8) + h][0];              \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) B[j] = bsrc[j * 32 + l31];                            \
+    }
+#define FL_MFMA(W0, W1, W2, W3, B)                                                \
+    {                                                                             \
+        const float4 wq4[4] = {W0, W1, W2, W3};                                   \
+        mfma_block<4, NJ>(acc, wq4, B);                                           \
+    }
+        FL_LOAD(0, wa0, wa1, wa2, wa3, ba)
         LSTAMP(q1)
 #ifdef SDFA_STAMPS
         s_init += q1 - q0;
 #endif
-#ifdef SDFA_STAMPS
 #pragma unroll 1
-#else
-#pragma unroll 2
-#endif
-        for (int kb = 0; kb < nkb; ++kb) {
-            const float4 w0 = wn0, w1 = wn1, w2 = wn2, w3 = wn3;
-            float4 b[NJ];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) b[j] = bn[j];
+        for (int kb = 0; kb < nkb; kb += 2) {      // nkb is even (8 or 24)
             LSTAMP(q2)
-            if (kb + 1 < nkb) {
-                const float4 *__restrict__ wq = wp + (kb + 1) * 1024;
-                wn0 = wq[0]; wn1 = wq[32]; wn2 = wq[64]; wn3 = wq[96];
-                const float4 *bsrc = kb + 1 < 8 ? &sX[cur][2 * kb + 2 + h][0] : &sH[2 * (kb - 7) + h][0];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) bn[j] = bsrc[j * 32 + l31];
-            }
+            FL_LOAD(kb + 1, wb0, wb1, wb2, wb3, bb)
+            __builtin_amdgcn_sched_barrier(0);   // keep all six requests ahead of the MFMAs (the scheduler otherwise sinks
+                                                 // half of them to their first use to save registers, exposing the L2 latency)
             LSTAMP(q3)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) mfma4(acc[0][j], w0, b[j]);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) mfma4(acc[1][j], w1, b[j]);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) mfma4(acc[2][j], w2, b[j]);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) mfma4(acc[3][j], w3, b[j]);
+            FL_MFMA(wa0, wa1, wa2, wa3, ba)
             LSTAMP(q4)
 #ifdef SDFA_STAMPS
             s_ld += q3 - q2; s_mf += q4 - q3;
 #endif
+            // unconditional (the last iteration re-requests k-block 0 and drops it): a branch here would let the
+            // optimiser sink the requests above into the block of their first use
+            const int kb2 = kb + 2 < nkb ? kb + 2 : 0;
+            FL_LOAD(kb2, wa0, wa1, wa2, wa3, ba)
+            __builtin_amdgcn_sched_barrier(0);
+            FL_MFMA(wb0, wb1, wb2, wb3, bb)
         }
+#undef FL_LOAD
+#undef FL_MFMA
+        if (s + 1 < 32) { XLOAD(dir ? 30 - s : s + 1) }   // next x_f tile: in flight during the cell update, staged after it
         LSTAMP(q2)
         __syncthreads();   // every wave has finished reading sH / sX[cur]
         LSTAMP(q3)
@@ -196,6 +219,13 @@ __global__ __launch_bounds__(256, WGS) void freq_lstm_kernel(FreqLstmArgs a) {
         s_b1 += q3 - q2; s_ep += q4 - q3; s_b2 += q5 - q4;
 #endif
     }
+#ifdef SDFA_CLOCKPROBE
+    if (tid == 0) {
+        atomicAdd(&g_clockprobe[0], (unsigned long long)(clock64() - cp_c0));
+        atomicAdd(&g_clockprobe[1], (unsigned long long)(wall_clock64() - cp_r0));
+        atomicAdd(&g_clockprobe[2], 1ull);
+    }
+#endif
 #ifdef SDFA_STAMPS
     if (lane == 0) {
         atomicAdd(&g_lstamp[0], s_init); atomicAdd(&g_lstamp[1], s_ld); atomicAdd(&g_lstamp[2], s_mf); atomicAdd(&g_lstamp[3], s_b1);
