@@ -607,9 +607,11 @@ int64_t sdfa_workspace_bytes(const sdfa_model *m, int64_t max_frames) {
 
 extern int g_sdfa_gemm_variant;
 int g_sdfa_freq_lstm_shape = 0;
+int g_sdfa_pca_unfused = 0;
 int sdfa_debug_set_option(const char *name, int value) {
     if (name && !strcmp(name, "gemm_variant")) { g_sdfa_gemm_variant = value; return SDFA_OK; }
     if (name && !strcmp(name, "freq_lstm_shape")) { g_sdfa_freq_lstm_shape = value; return SDFA_OK; }
+    if (name && !strcmp(name, "pca_unfused")) { g_sdfa_pca_unfused = value; return SDFA_OK; }
     return fail(SDFA_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }
 
@@ -826,6 +828,14 @@ int sdfa_regress_forward(const sdfa_model *m, const float *d_z, const int64_t *d
         if (d_out) {
             // PCA expansion: out[n][o] = sum_k coef[k][n] * basis[k][o] + means[o]   (rows = frames)
             pf.begin("pca");
+            if (m->pca_n == 2 && stage_terms(m, STAGE_REGRESSOR) == 0 && !g_sdfa_pca_unfused) {
+                // dgrad head, fp32: both bases in one kernel so that every output line is written once, whole (pca.hip)
+                PcaArgs pa{};
+                pa.coef = coef; pa.basis_s = m->pca_q[0]; pa.basis_r = m->pca_q[1]; pa.mean_s = m->pca_bias[0]; pa.mean_r = m->pca_bias[1];
+                pa.out = d_out + f0 * m->out_dim; pa.N = N; pa.Nc = Nc; pa.out_dim = m->out_dim;
+                pa.ld_s = m->pca_ld[0]; pa.ld_r = m->pca_ld[1]; pa.cols_s = m->pca_cols[0]; pa.cols_r = m->pca_cols[1];
+                HIP_TRY(sdfa_launch_pca_dgrad(pa, s));
+            } else
             for (int b = 0; b < m->pca_n; ++b) {
                 GemmArgs g{};
                 g.P = coef + (int64_t)m->pca_k0[b] * Nc; g.Q = m->pca_q[b]; g.D = d_out + f0 * m->out_dim;

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256, 2) void conv1_pool_kernel(ConvArgs a) {
 // 1x1 conv3 (2 tiles, K = 64).
 __global__ __launch_bounds__(256, 2) void conv23_kernel(ConvArgs a) {
     __shared__ float4 sP1[80][32];   // 10 pool1 rows x 32 ci as 80 k-quads
+    __shared__ float sPar[6][64];    // bias / BN scale / BN shift of conv2 and conv3 (epilogue operands: LDS latency, not L2)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -107,13 +108,20 @@ __global__ __launch_bounds__(256, 2) void conv23_kernel(ConvArgs a) {
         if (f1 >= 0 && f1 < 64) v = P1[(int64_t)(f1 * 8 + (qd & 7)) * a.Mc + m0 + col];
         sP1[qd][col] = v;
     }
-    __syncthreads();
+    if (tid < 64) {
+        sPar[0][tid] = a.b2[tid]; sPar[1][tid] = a.s2[tid]; sPar[2][tid] = a.t2[tid];
+        sPar[3][tid] = a.b3[tid]; sPar[4][tid] = a.s3[tid]; sPar[5][tid] = a.t3[tid];
+    }
 
-    const float4 *__restrict__ W2 = reinterpret_cast<const float4 *>(a.w2);
+    const float4 *__restrict__ W2 = reinterpret_cast<const float4 *>(a.w2) + h * 64 + l31;   // + kb * 128 (+32 for the second tile)
     const float4 *__restrict__ W3 = reinterpret_cast<const float4 *>(a.w3);
     const int fo = fc * 4 + wave;
+    // conv2 weight quads run one k-block ahead of the MFMAs in two alternating register sets (L2 latency off the
+    // critical path, no hand-over copies); the first request goes out before the barrier
+    float4 wa[2] = {W2[0], W2[32]}, wb[2];
+    __syncthreads();
 
-    f32x16 acc[2][2];   // [conv row a/b][out tile]
+    f32x16 acc[2][2];   // [out tile][conv row a/b]
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -121,16 +129,21 @@ __global__ __launch_bounds__(256, 2) void conv23_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-#pragma unroll 2
-    for (int kb = 0; kb < 12; ++kb) {
-        float4 wa0 = W2[(2 * kb + h) * 64 + l31];
-        float4 wa1 = W2[(2 * kb + h) * 64 + 32 + l31];
-        float4 xa = sP1[16 * wave + 2 * kb + h][l31];
-        float4 xb = sP1[16 * wave + 8 + 2 * kb + h][l31];
-        mfma4(acc[0][0], wa0, xa);
-        mfma4(acc[0][1], wa1, xa);
-        mfma4(acc[1][0], wa0, xb);
-        mfma4(acc[1][1], wa1, xb);
+#pragma unroll 1
+    for (int kb = 0; kb < 12; kb += 2) {
+        wb[0] = W2[(kb + 1) * 128]; wb[1] = W2[(kb + 1) * 128 + 32];
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const float4 x[2] = {sP1[16 * wave + 2 * kb + h][l31], sP1[16 * wave + 8 + 2 * kb + h][l31]};
+            mfma_block<2, 2>(acc, wa, x);
+        }
+        const int kn = kb + 2 < 12 ? kb + 2 : 0;      // branch-free: the last request is dropped
+        wa[0] = W2[kn * 128]; wa[1] = W2[kn * 128 + 32];
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const float4 x[2] = {sP1[16 * wave + 2 * (kb + 1) + h][l31], sP1[16 * wave + 8 + 2 * (kb + 1) + h][l31]};
+            mfma_block<2, 2>(acc, wb, x);
+        }
     }
     // LeakyReLU -> BN -> max over the row pair: pooled tile, rows = channels
     f32x16 p2[2];
@@ -138,43 +151,41 @@ __global__ __launch_bounds__(256, 2) void conv23_kernel(ConvArgs a) {
     for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float4 b = ld4(a.b2 + ot * 32 + 8 * g + 4 * h), s = ld4(a.s2 + ot * 32 + 8 * g + 4 * h),
-                   t = ld4(a.t2 + ot * 32 + 8 * g + 4 * h);
+            const int ch = ot * 32 + 8 * g + 4 * h;
+            float4 b = ld4(&sPar[0][ch]), s = ld4(&sPar[1][ch]), t = ld4(&sPar[2][ch]);
             const float bq[4] = {b.x, b.y, b.z, b.w}, sq[4] = {s.x, s.y, s.z, s.w}, tq[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float v0 = lrelu02(acc[0][ot][4 * g + e] + bq[e]) * sq[e] + tq[e];
-                float v1 = lrelu02(acc[1][ot][4 * g + e] + bq[e]) * sq[e] + tq[e];
+                float v0 = lrelu02(acc[ot][0][4 * g + e] + bq[e]) * sq[e] + tq[e];
+                float v1 = lrelu02(acc[ot][1][4 * g + e] + bq[e]) * sq[e] + tq[e];
                 p2[ot][4 * g + e] = fmaxf(v0, v1);
             }
         }
     // conv3 (1x1): contract over the pooled tile's ROW index straight from registers
-    f32x16 acc3[2];
+    f32x16 acc3[2][1];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc3[j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc3[j][0][r] = 0.f;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float4 xb = make_float4(p2[ct][4 * g], p2[ct][4 * g + 1], p2[ct][4 * g + 2], p2[ct][4 * g + 3]);
-            float4 w0 = W3[(8 * ct + 2 * g + h) * 64 + l31];
-            float4 w1 = W3[(8 * ct + 2 * g + h) * 64 + 32 + l31];
-            mfma4(acc3[0], w0, xb);
-            mfma4(acc3[1], w1, xb);
+            const float4 xb[1] = {make_float4(p2[ct][4 * g], p2[ct][4 * g + 1], p2[ct][4 * g + 2], p2[ct][4 * g + 3])};
+            const float4 w[2] = {W3[(8 * ct + 2 * g + h) * 64 + l31], W3[(8 * ct + 2 * g + h) * 64 + 32 + l31]};
+            mfma_block<2, 1>(acc3, w, xb);
         }
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float4 b = ld4(a.b3 + ot * 32 + 8 * g + 4 * h), s = ld4(a.s3 + ot * 32 + 8 * g + 4 * h),
-                   t = ld4(a.t3 + ot * 32 + 8 * g + 4 * h);
+            const int ch = ot * 32 + 8 * g + 4 * h;
+            float4 b = ld4(&sPar[3][ch]), s = ld4(&sPar[4][ch]), t = ld4(&sPar[5][ch]);
             float4 o;
-            o.x = lrelu02(acc3[ot][4 * g + 0] + b.x) * s.x + t.x;
-            o.y = lrelu02(acc3[ot][4 * g + 1] + b.y) * s.y + t.y;
-            o.z = lrelu02(acc3[ot][4 * g + 2] + b.z) * s.z + t.z;
-            o.w = lrelu02(acc3[ot][4 * g + 3] + b.w) * s.w + t.w;
+            o.x = lrelu02(acc3[ot][0][4 * g + 0] + b.x) * s.x + t.x;
+            o.y = lrelu02(acc3[ot][0][4 * g + 1] + b.y) * s.y + t.y;
+            o.z = lrelu02(acc3[ot][0][4 * g + 2] + b.z) * s.z + t.z;
+            o.w = lrelu02(acc3[ot][0][4 * g + 3] + b.w) * s.w + t.w;
             st4(a.X3 + ((int64_t)(fo * 16 + ot * 8 + 2 * g + h) * a.Mc + m0 + l31) * 4, o);
         }
 }

@@ -28,6 +28,16 @@ struct GemmArgs {
 };
 hipError_t sdfa_launch_gemm(const GemmArgs &a, hipStream_t s);
 
+// ---- PCA expansion of the dgrad head, both bases fused (pca.hip) ---------------------------------
+struct PcaArgs {
+    const float *coef;               // K4 [288/4][Nc]: rows 0..95 scale coefficients (85 real), 96..287 rotat (180 real)
+    const float *basis_s, *basis_r;  // K4 [96/4][ld_s], [192/4][ld_r]
+    const float *mean_s, *mean_r;    // [cols_s], [cols_r]
+    float *out;                      // [N][out_dim] row-major, triangle-interleaved [s0..s5 r0 r1 r2]
+    int64_t N, Nc, out_dim, ld_s, ld_r, cols_s, cols_r;
+};
+hipError_t sdfa_launch_pca_dgrad(const PcaArgs &a, hipStream_t s);
+
 // ---- front end -----------------------------------------------------------------------------
 struct FrontendConsts {      // device pointers, built once per sample rate
     const float *hamm;       // [win]
