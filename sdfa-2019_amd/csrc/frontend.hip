@@ -9,13 +9,16 @@
 //   delta / delta-delta (SG width 9) speech_anime/datasets/get_features.py:199-207
 //   (T,F,C) interleave               get_features.py:210-215, sliding_window.py:462
 //
-// One 256-thread workgroup per animation frame.  The zero-padded, pre-emphasised window is
+// One 512-thread workgroup per animation frame (8 waves = 2 per SIMD; the 150 KB of LDS allow one workgroup per CU,
+// so the second wave per SIMD is what hides LDS latency).  The zero-padded, pre-emphasised window is
 // staged once in LDS (coalesced HBM read of sliding*4 bytes); each wave then transforms PAIRS
 // of STFT columns as one complex radix-4 Stockham FFT (column t in the real part, t+1 in the
 // imaginary part) with twiddles and the Hamming window resident in LDS, untangles the two
 // spectra, gathers the sparse mel rows (CSR, ~449 non-zeros, only bins below 3.6 kHz are ever
 // needed) and writes log-mel into an LDS image from which the 9-tap delta filters and the
 // interleaved (T,F,C) store run.  HBM traffic per frame: the window read + 98,304 bytes written.
+// A wave's FFT lives in its own LDS buffer, so the stages are separated by wavefront-scope fences only (LDS executes a
+// wave's instructions in order); the workgroup meets at two barriers: window staged, mel image complete.
 #include "common.h"
 #include "kernels.h"
 
@@ -25,8 +28,11 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 
+constexpr int FE_WAVES = 8, FE_THREADS = 64 * FE_WAVES;
+#define WAVE_SYNC() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
 template <int WIN>
-__global__ __launch_bounds__(256) void frontend_kernel(FrontendConsts c, const float *__restrict__ pcm,
+__global__ __launch_bounds__(FE_THREADS) void frontend_kernel(FrontendConsts c, const float *__restrict__ pcm,
                                                        const int64_t *__restrict__ clip_off,
                                                        const int64_t *__restrict__ clip_len,
                                                        const int32_t *__restrict__ frame_clip,
@@ -34,11 +40,10 @@ __global__ __launch_bounds__(256) void frontend_kernel(FrontendConsts c, const f
     constexpr int HOP = WIN / 8, SLIDING = HOP * 63 + WIN, NB = 256, NR4 = WIN / 256;   // radix-4 butterflies per lane
     constexpr bool HAS_R2 = (WIN == 512);
     __shared__ float sY[SLIDING];
-    __shared__ float2 sFft[4][WIN];
+    __shared__ float2 sFft[FE_WAVES][WIN];
     __shared__ float2 sTw[WIN];
     __shared__ float sHamm[WIN];
-    __shared__ float sPow[4][2][NB];
-    __shared__ float sMel[64][129];
+    __shared__ float sMel[64][128];   // lanes walk the band index in every access: no padding needed
     __shared__ int sPtr[132];
     __shared__ int sBin[512];
     __shared__ float sW[512];
@@ -48,11 +53,11 @@ __global__ __launch_bounds__(256) void frontend_kernel(FrontendConsts c, const f
     const int clip = frame_clip[frame];
     const int64_t off = clip_off[clip], len = clip_len[clip], s0 = frame_start[frame];
 
-    for (int i = tid; i < WIN; i += 256) { sTw[i] = c.twiddle[i]; sHamm[i] = c.hamm[i]; }
-    for (int i = tid; i < 129; i += 256) sPtr[i] = c.mel_ptr[i];
-    for (int i = tid; i < c.nnz; i += 256) { sBin[i] = c.mel_bin[i]; sW[i] = c.mel_w[i]; }
+    for (int i = tid; i < WIN; i += FE_THREADS) { sTw[i] = c.twiddle[i]; sHamm[i] = c.hamm[i]; }
+    for (int i = tid; i < 129; i += FE_THREADS) sPtr[i] = c.mel_ptr[i];
+    for (int i = tid; i < c.nnz; i += FE_THREADS) { sBin[i] = c.mel_bin[i]; sW[i] = c.mel_w[i]; }
     // window cut, zero pad, pre-emphasis (fp32, one rounding per op as numpy does)
-    for (int i = tid; i < SLIDING; i += 256) {
+    for (int i = tid; i < SLIDING; i += FE_THREADS) {
         const int64_t g = s0 + i;
         float x = (g >= 0 && g < len) ? pcm[off + g] : 0.f;
         float xm = (i > 0 && g - 1 >= 0 && g - 1 < len) ? pcm[off + g - 1] : 0.f;
@@ -69,8 +74,9 @@ __global__ __launch_bounds__(256) void frontend_kernel(FrontendConsts c, const f
     const int odd = (int)(hop_base & 1);
     const int njobs = 32 + odd;                                              // 32 pairs, or solo + 31 pairs + solo
     float2 *buf = sFft[wave];
-    for (int it = 0; it < 9; ++it) {             // 36 job slots over 4 waves: every wave hits every block barrier
-        const int job = it * 4 + wave;
+    float *pw0 = reinterpret_cast<float *>(buf), *pw1 = pw0 + NB;   // power spectra of the two columns (bins < 256) reuse the wave's buffer
+    for (int it = 0; it < (36 + FE_WAVES - 1) / FE_WAVES; ++it) {   // up to 33 jobs over the waves
+        const int job = it * FE_WAVES + wave;
         const bool live = job < njobs;
         int t0 = 2 * job - odd, t1 = t0 + 1;                                 // columns in the real / imaginary part
         if (!live) { t0 = 0; t1 = 1; }                                       // idle slot: harmless recomputation, results dropped
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(256) void frontend_kernel(FrontendConsts c, const f
                         v[b][r] = (r == 0) ? x : cmul(x, sTw[(tstep * r) & (WIN - 1)]);
                     }
                 }
-                __syncthreads();   // every read of this stage done before any write
+                WAVE_SYNC()   // every read of this stage done before any write
             }
 #pragma unroll
             for (int b = 0; b < NR4; ++b) {
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(256) void frontend_kernel(FrontendConsts c, const f
                 buf[j0 + 2 * Ns] = csub(a0, a2);
                 buf[j0 + 3 * Ns] = csub(a1, a3);
             }
-            __syncthreads();
+            WAVE_SYNC()
             Ns *= 4;
         }
         if (HAS_R2) {   // WIN = 512 = 4^4 * 2: final radix-2 stage, Ns = 256
@@ -128,24 +134,30 @@ __global__ __launch_bounds__(256) void frontend_kernel(FrontendConsts c, const f
                 u[b][0] = buf[j];
                 u[b][1] = cmul(buf[j + WIN / 2], sTw[j]);
             }
-            __syncthreads();
+            WAVE_SYNC()
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const int j = lane + 64 * b;
                 buf[j] = cadd(u[b][0], u[b][1]);
                 buf[j + WIN / 2] = csub(u[b][0], u[b][1]);
             }
-            __syncthreads();
+            WAVE_SYNC()
         }
-        // ---- untangle the two real spectra, power
-        for (int k = lane; k < c.nbins_used; k += 64) {
+        // ---- untangle the two real spectra, power (bins in registers first: the power arrays reuse the FFT buffer)
+        float p0[4], p1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = lane + 64 * i;
             float2 zk = buf[k], zn = buf[(WIN - k) & (WIN - 1)];
             float ar = 0.5f * (zk.x + zn.x), ai = 0.5f * (zk.y - zn.y);     // A = (Z[k] + conj Z[N-k]) / 2
             float br = 0.5f * (zk.y + zn.y), bi = -0.5f * (zk.x - zn.x);    // B = (Z[k] - conj Z[N-k]) / (2i)
-            sPow[wave][0][k] = __fadd_rn(__fmul_rn(ar, ar), __fmul_rn(ai, ai));
-            sPow[wave][1][k] = __fadd_rn(__fmul_rn(br, br), __fmul_rn(bi, bi));
+            p0[i] = __fadd_rn(__fmul_rn(ar, ar), __fmul_rn(ai, ai));
+            p1[i] = __fadd_rn(__fmul_rn(br, br), __fmul_rn(bi, bi));
         }
-        __syncthreads();
+        WAVE_SYNC()
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { pw0[lane + 64 * i] = p0[i]; pw1[lane + 64 * i] = p1[i]; }
+        WAVE_SYNC()
         // ---- sparse mel gather, dB, normalise, clamp
 #pragma unroll
         for (int col = 0; col < 2; ++col)
@@ -153,19 +165,21 @@ __global__ __launch_bounds__(256) void frontend_kernel(FrontendConsts c, const f
             for (int bb = 0; bb < 2; ++bb) {
                 const int band = lane + 64 * bb;
                 float m = 0.f;
-                for (int e = sPtr[band]; e < sPtr[band + 1]; ++e) m += sW[e] * sPow[wave][col][sBin[e]];
+                const float *pw = col ? pw1 : pw0;
+                for (int e = sPtr[band]; e < sPtr[band + 1]; ++e) m += sW[e] * pw[sBin[e]];
                 float db = __fmul_rn(10.0f, log10f(fmaxf(m, 1.1920929e-07f)));
                 float nv = __fdiv_rn(__fadd_rn(__fsub_rn(db, 20.0f), 80.0f), 80.0f);
                 const int tt = col ? t1 : t0;
                 if (live && tt >= 0 && tt <= 63) sMel[tt][band] = fminf(fmaxf(nv, 0.f), 1.f);
             }
-        __syncthreads();
+        WAVE_SYNC()
     }
+    __syncthreads();   // mel image complete
     // ---- Savitzky-Golay deltas (edges replicate the first / last interior value) + (T,F,C) store
     const float c2[9] = {28.f / 462.f, 7.f / 462.f, -8.f / 462.f, -17.f / 462.f, -20.f / 462.f,
                          -17.f / 462.f, -8.f / 462.f, 7.f / 462.f, 28.f / 462.f};
     float *dst = out + frame * (64 * 128 * 3);
-    for (int idx = tid; idx < 64 * 128; idx += 256) {
+    for (int idx = tid; idx < 64 * 128; idx += FE_THREADS) {
         const int t = idx >> 7, f = idx & 127;
         const int tc = t < 4 ? 4 : (t > 59 ? 59 : t);
         float d1 = 0.f, d2 = 0.f;
@@ -189,10 +203,10 @@ hipError_t sdfa_launch_frontend(const FrontendConsts &c, const float *pcm, const
     if (n_frames <= 0) return hipSuccess;
     if (c.nnz > 512 || c.nbins_used > 256) return hipErrorInvalidValue;
     if (c.win == 1024)
-        hipLaunchKernelGGL(frontend_kernel<1024>, dim3((unsigned)n_frames), dim3(256), 0, s, c, pcm, clip_off, clip_len,
+        hipLaunchKernelGGL(frontend_kernel<1024>, dim3((unsigned)n_frames), dim3(FE_THREADS), 0, s, c, pcm, clip_off, clip_len,
                            frame_clip, frame_start, audio_feat);
     else if (c.win == 512)
-        hipLaunchKernelGGL(frontend_kernel<512>, dim3((unsigned)n_frames), dim3(256), 0, s, c, pcm, clip_off, clip_len,
+        hipLaunchKernelGGL(frontend_kernel<512>, dim3((unsigned)n_frames), dim3(FE_THREADS), 0, s, c, pcm, clip_off, clip_len,
                            frame_clip, frame_start, audio_feat);
     else
         return hipErrorInvalidValue;
