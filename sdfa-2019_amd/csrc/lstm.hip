@@ -417,41 +417,52 @@ __global__ __launch_bounds__(512, 2) void time_lstm_kernel(TimeLstmArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) c[j][r] = 0.f;
 
+    // The accumulators start every step from the input projection GX (the GEMM's output).  Those 32 quads per lane
+    // are requested one step AHEAD, quad by quad, as the cell update releases the registers -- requested at the top of
+    // the step they would put an HBM round trip in front of every step's first MFMA (all 8 waves wait in lock-step).
+    f32x16 acc[4][NT];
+#define TL_GX(t_, gt, g, j) GX[(int64_t)(dir * 256 + wave * 32 + (gt) * 8 + 2 * (g) + h) * a.Mc + (int64_t)(t_) * a.Nc + n0 + l31 + (j) * 32]
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const float4 v = TL_GX(dir ? 63 : 0, gt, g, j);
+                acc[gt][j][4 * g + 0] = v.x; acc[gt][j][4 * g + 1] = v.y; acc[gt][j][4 * g + 2] = v.z; acc[gt][j][4 * g + 3] = v.w;
+            }
+
     for (int s = 0; s < 64; ++s) {
         const int t = dir ? 63 - s : s;
+        const int tn = dir ? t - 1 : t + 1;
         const int64_t mcol = (int64_t)t * a.Nc + n0 + l31;
         const float4 *sHc = sHt + (size_t)(s & 1) * 64 * BT;
         float4 *sHn = sHt + (size_t)((s & 1) ^ 1) * 64 * BT;
 
-        f32x16 acc[4][NT];
-#pragma unroll
-        for (int gt = 0; gt < 4; ++gt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    float4 v = GX[(int64_t)(dir * 256 + wave * 32 + gt * 8 + 2 * g + h) * a.Mc + mcol + j * 32];
-                    acc[gt][j][4 * g + 0] = v.x; acc[gt][j][4 * g + 1] = v.y;
-                    acc[gt][j][4 * g + 2] = v.z; acc[gt][j][4 * g + 3] = v.w;
-                }
         if (s > 0) {
+            // recurrent weights one k-block ahead, two alternating register sets, branch-free (see freq_lstm_kernel)
             const float4 *__restrict__ wp = Ww + h * 1024;
-            float4 wn0 = wp[0], wn1 = wp[32], wn2 = wp[64], wn3 = wp[96];
-#pragma unroll 2
-            for (int kb = 0; kb < 32; ++kb) {
-                const float4 w0 = wn0, w1 = wn1, w2 = wn2, w3 = wn3;
-                if (kb + 1 < 32) {
-                    const float4 *__restrict__ wq = wp + (kb + 1) * 2048;
-                    wn0 = wq[0]; wn1 = wq[32]; wn2 = wq[64]; wn3 = wq[96];
-                }
-                const int kq = 2 * kb + h;
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const float4 bj = sHc[kq * BT + j * 32 + l31];
-                    mfma4(acc[0][j], w0, bj); mfma4(acc[1][j], w1, bj);
-                    mfma4(acc[2][j], w2, bj); mfma4(acc[3][j], w3, bj);
-                }
+            float4 wa[4], wb[4];
+#define TL_LOAD(kb, W) { const float4 *__restrict__ wq = wp + (kb) * 2048; W[0] = wq[0]; W[1] = wq[32]; W[2] = wq[64]; W[3] = wq[96]; }
+#define TL_MFMA(kb, W)                                                                    \
+    {                                                                                     \
+        float4 bq[NT];                                                                    \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) bq[j] = sHc[(2 * (kb) + h) * BT + j * 32 + l31]; \
+        mfma_block<4, NT>(acc, W, bq);                                                    \
+    }
+            TL_LOAD(0, wa)
+#pragma unroll 1
+            for (int kb = 0; kb < 32; kb += 2) {
+                TL_LOAD(kb + 1, wb)
+                __builtin_amdgcn_sched_barrier(0);
+                TL_MFMA(kb, wa)
+                const int kn = kb + 2 < 32 ? kb + 2 : 0;
+                TL_LOAD(kn, wa)
+                __builtin_amdgcn_sched_barrier(0);
+                TL_MFMA(kb + 1, wb)
             }
+#undef TL_LOAD
+#undef TL_MFMA
         }
 #pragma unroll
         for (int j = 0; j < NT; ++j)
@@ -462,9 +473,17 @@ __global__ __launch_bounds__(512, 2) void time_lstm_kernel(TimeLstmArgs a) {
                 const int hq_idx = 8 * wave + 2 * g + h;
                 sHn[hq_idx * BT + j * 32 + l31] = hq;
                 H[(int64_t)(dir * 64 + hq_idx) * a.Mc + mcol + j * 32] = hq;
+                if (s + 1 < 64) {   // this quad's gate registers are free: request the next step's input projection into them
+#pragma unroll
+                    for (int gt = 0; gt < 4; ++gt) {
+                        const float4 v = TL_GX(tn, gt, g, j);
+                        acc[gt][j][4 * g + 0] = v.x; acc[gt][j][4 * g + 1] = v.y; acc[gt][j][4 * g + 2] = v.z; acc[gt][j][4 * g + 3] = v.w;
+                    }
+                }
             }
         __syncthreads();   // h_s complete in sHn before anyone reads it; sHc free for step s+1's writes
     }
+#undef TL_GX
 }
 
 }  // namespace
