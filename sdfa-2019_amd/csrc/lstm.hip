@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256, WGS) void freq_lstm_kernel(FreqLstmArgs a) {
         const int f = dir ? 31 - s : s;
         const int cur = s & 1;
         LSTAMP(q0)
+        if (s + 1 < 32) { XLOAD(dir ? 30 - s : s + 1) }   // next x_f tile: in flight during the whole step, staged after the cell update
 
         f32x16 acc[4][NJ];
 #pragma unroll
@@ -140,10 +141,13 @@ __global__ __launch_bounds__(256, WGS) void freq_lstm_kernel(FreqLstmArgs a) {
         const float4 *bsrc = (kb) < 8 ? &sX[cur][2 * (kb) + h][0] : &sH[2 * ((kb) - 8) + h][0];              \
         _Pragma("unroll") for (int j = 0; j < NJ; ++j) B[j] = bsrc[j * 32 + l31];                            \
     }
+        // (gate-tile-major order: the component-major mfma_block order needs 8 more registers here, which spills)
 #define FL_MFMA(W0, W1, W2, W3, B)                                                \
     {                                                                             \
-        const float4 wq4[4] = {W0, W1, W2, W3};                                   \
-        mfma_block<4, NJ>(acc, wq4, B);                                           \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) mfma4(acc[0][j], W0, B[j]); \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) mfma4(acc[1][j], W1, B[j]); \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) mfma4(acc[2][j], W2, B[j]); \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) mfma4(acc[3][j], W3, B[j]); \
     }
         FL_LOAD(0, wa0, wa1, wa2, wa3, ba)
         LSTAMP(q1)
@@ -171,7 +175,6 @@ __global__ __launch_bounds__(256, WGS) void freq_lstm_kernel(FreqLstmArgs a) {
         }
 #undef FL_LOAD
 #undef FL_MFMA
-        if (s + 1 < 32) { XLOAD(dir ? 30 - s : s + 1) }   // next x_f tile: in flight during the cell update, staged after it
         LSTAMP(q2)
         __syncthreads();   // every wave has finished reading sH / sX[cur]
         LSTAMP(q3)
