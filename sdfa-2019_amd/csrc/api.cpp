@@ -717,7 +717,6 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
             sa.prev = sh + 16; sa.shift = sa.prev + Nc;
             sa.owner = sa.shift + Nc; sa.flag = sa.owner + Mc; sa.uid = sa.flag + Mc;
             sa.col_src = sa.uid + Mc; sa.col_to_u = sa.col_src + Mc; sa.tile_sum = sa.col_to_u + Mc;
-            if (getenv("SDFA_DEBUG")) fprintf(stderr, "[sdfa] share: ws=%p SH=%lld sh=%p N=%lld Nc=%lld hop=%d\n", (void *)ws, (long long)w.SH, (void *)sh, (long long)N, (long long)Nc, hop);
             pf.begin("share_map"); HIP_TRY(sdfa_launch_share_map(sa, s)); pf.end();
             d_ulimit = sa.counts + 1; col_to_u = sa.col_to_u;
             ca.col_src = sa.col_src; ca.col_limit = d_ulimit;
@@ -859,7 +858,6 @@ int64_t sdfa_debug_distinct_columns(const sdfa_model *m, int64_t n_frames, const
     int64_t counts[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(counts, (const float *)d_workspace + w.SH, sizeof counts, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    if (getenv("SDFA_DEBUG")) fprintf(stderr, "[sdfa] distinct: ws=%p SH=%lld counts=%lld %lld\n", d_workspace, (long long)w.SH, (long long)counts[0], (long long)counts[1]);
     return counts[0];
 }
 

@@ -489,13 +489,11 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs a) {
 
 template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
 hipError_t launch_big(const GemmArgs &a, hipStream_t s) {
-    static bool attr_set = false;
     const size_t lds = 2 * 2 * KQ * 256 * sizeof(float4);   // 128 KiB
-    if (!attr_set) {
+    {   // per launch: cheap, and correct for every device / thread the library is used from
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_big_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const int64_t nblk = (a.Ppad / 256) * (a.Qpad / 256);
     hipLaunchKernelGGL((gemm_big_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>), dim3((unsigned)nblk), dim3(512), lds, s, a);

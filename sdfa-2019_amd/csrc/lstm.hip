@@ -529,13 +529,11 @@ hipError_t sdfa_launch_freq_lstm(const FreqLstmArgs &a, hipStream_t s) {
 
 template <int NT>
 static hipError_t launch_time(const TimeLstmArgs &a, hipStream_t s) {
-    static bool attr_set = false;
     const size_t lds = 2 * 64 * 32 * NT * sizeof(float4);   // 128 KiB (NT 2) / 64 KiB (NT 1)
-    if (!attr_set) {
+    {   // per launch: cheap, and correct for every device / thread the library is used from
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(time_lstm_kernel<NT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(time_lstm_kernel<NT>, dim3((unsigned)(a.Nc / (32 * NT) * 2)), dim3(512), lds, s, a);
     return hipGetLastError();
