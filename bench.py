@@ -28,7 +28,7 @@ sys.path.insert(0, os.path.join(ROOT, "sdfa-2019_amd"))
 
 FLOP_FREQ_LSTM_PER_FRAME = 64 * 32 * 2 * 512 * (64 + 128) * 2      # 268.4 + 536.9 MFLOP
 FLOP_MODEL_PER_FRAME = 1.514e9
-FRONTEND_BYTES_PER_FRAME = 4 * 16000 / 60 + 64 * 128 * 3 * 4         # new PCM + feature write = 99.4 KB
+FRONTEND_BYTES_PER_FRAME = 4 * 16000 / 60 + 64 * 128 * 3 * 4         # new PCM + feature write = 99.4 KB (at 16 kHz; 8 kHz: 98.8 KB)
 PEAK_FP32_MFMA_TFLOPS = 157.3                                        # MI355X_MICROARCH.md chip table
 PEAK_HBM_GBPS = 8000.0
 
@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-column-sharing", action="store_true", help="skip the second, column-sharing measurement")
+    ap.add_argument("--head", choices=["dgrad", "offsets"], default="dgrad", help="offsets = BASELINE configs[4] (VOCASET-style vertex offsets)")
+    ap.add_argument("--ragged-seconds", default=None, metavar="LO,HI",
+                    help="clip lengths uniform in [LO, HI] s instead of --seconds (a VOCASET-like stream of sentences)")
     ap.add_argument("--precision", choices=["fp32", "bf16_attention", "bf16x3", "bf16"], default="fp32",
                     help="matrix instruction of the headline run (fp32 = the reference's arithmetic; the others are BASELINE configs[3] modes)")
     ap.add_argument("--no-mixed-precision", action="store_true", help="skip the extra split-bf16 (configs[3]) measurement")
@@ -120,26 +123,34 @@ def main():
     for kv in a.opt:
         k, v = kv.split("=")
         _lib.check(_lib.lib.sdfa_debug_set_option(k.encode(), int(v)))
-    sr, L = a.sample_rate, int(a.seconds * a.sample_rate)
-    sd = synth.make_state_dict("dgrad", 1234)
+    sr = a.sample_rate
+    sd = synth.make_state_dict(a.head, 1234)
     eng = Engine(sd, device=dev, max_frames=a.chunk, precision=a.precision)
 
     # ---- this rank's clips: global clip ids [rank*C, (rank+1)*C), PCM resident in HBM before timing
     C = a.clips_per_gpu
-    starts, ts = frame_index(L, sr)
-    F_clip = len(starts)
-    F = C * F_clip
-    pcm = torch.from_numpy(np.concatenate([synth.make_pcm(rank * C + c, L) for c in range(C)])).to(dev)
-    clip_off = torch.arange(C, dtype=torch.int64, device=dev) * L
-    clip_len = torch.full((C,), L, dtype=torch.int64, device=dev)
-    frame_clip = torch.arange(C, dtype=torch.int32, device=dev).repeat_interleave(F_clip)
-    frame_start = torch.from_numpy(np.tile(starts, C)).to(dev)
+    if a.ragged_seconds:
+        lo, hi = (float(x) for x in a.ragged_seconds.split(","))
+        rs = np.random.RandomState(4242 + rank)
+        lengths = [int(rs.uniform(lo, hi) * sr) for _ in range(C)]
+    else:
+        lengths = [int(a.seconds * sr)] * C
+    tables = {L: frame_index(L, sr)[0] for L in set(lengths)}
+    counts = [len(tables[L]) for L in lengths]
+    F = int(sum(counts))
+    pcm = torch.from_numpy(np.concatenate([synth.make_pcm(rank * C + c, L) for c, L in enumerate(lengths)])).to(dev)
+    clip_len = torch.tensor(lengths, dtype=torch.int64, device=dev)
+    clip_off = torch.cumsum(clip_len, 0) - clip_len
+    frame_clip = torch.repeat_interleave(torch.arange(C, dtype=torch.int32, device=dev), torch.tensor(counts, device=dev))
+    frame_start = torch.from_numpy(np.concatenate([tables[L] for L in lengths])).to(dev)
     spk = torch.full((F,), 2, dtype=torch.int64, device=dev)          # speaker "m1"
     feat = torch.empty((F, 64, 128, 3), dtype=torch.float32, device=dev)
     width = eng.out_dim if a.gather != "coef" else eng.coef_dim
     gatherer = None
+    all_counts = sdist.frame_counts_all(F) if (world > 1 and a.ragged_seconds) else [F] * world
+    F_all = int(sum(all_counts))
     if world > 1 and a.gather != "none":
-        gatherer = sdist.FrameGatherer([F] * world, width, torch.float32, dev, a.chunk)
+        gatherer = sdist.FrameGatherer(all_counts, width, torch.float32, dev, a.chunk)
     out = torch.empty((F, eng.out_dim), dtype=torch.float32, device=dev)
 
     hop = int(0.008 * sr)
@@ -206,7 +217,7 @@ def main():
     stages["frontend"] = fe_ms
 
     if rank == 0:
-        frames_total = F * world * a.steps
+        frames_total = F_all * a.steps
         value = frames_total / dt
         lstm_ms_per_launch = stages["freq_lstm"] / n_chunks
         flop_per_launch = FLOP_FREQ_LSTM_PER_FRAME * (F / n_chunks)
@@ -218,8 +229,10 @@ def main():
             "vs_baseline": None, "dtype": {"fp32": "f32", "bf16_attention": "f32 (attention projections bf16)",
                                            "bf16x3": "split-bf16 x3 (fp32 accumulate)", "bf16": "bf16 (fp32 accumulate)"}[a.precision],
             "data": "synthetic",
-            "config": {"workload": f"batch={C} x {a.seconds:g} s@{sr} Hz synthetic PCM per GPU -> dgrad (BASELINE configs[1])",
-                       "clips_per_gpu": C, "frames_per_gpu": F, "head": "dgrad", "chunk_frames": a.chunk,
+            "config": {"workload": (f"batch={C} x {a.seconds:g} s@{sr} Hz synthetic PCM per GPU -> {a.head} (BASELINE configs[1])"
+                                    if not a.ragged_seconds else
+                                    f"stream of {C} sentences, {a.ragged_seconds} s@{sr} Hz synthetic PCM per GPU -> {a.head} (BASELINE configs[4] rehearsal)"),
+                       "clips_per_gpu": C, "frames_per_gpu": F, "head": a.head, "chunk_frames": a.chunk,
                        "gather": a.gather if world > 1 else "none (1 GPU)", "weights": "synthetic seed 1234"},
             "roofline": {"kernel": "freq_lstm_kernel", "bound": "mfma", "achieved": round(achieved, 2),
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -239,7 +252,7 @@ def main():
                 "note": "outputs BITWISE identical to the headline run; the per-column stages (conv, freq-LSTM, projection) are "
                         "evaluated once per DISTINCT column (SURVEY App. B legal redundancy); reported next to, not as, "
                         "the headline value",
-                "value": round(F * world * a.steps / dt_s, 1), "unit": "frames/s", "ms_per_step": round(dt_s / a.steps * 1e3, 3),
+                "value": round(F_all * a.steps / dt_s, 1), "unit": "frames/s", "ms_per_step": round(dt_s / a.steps * 1e3, 3),
                 "distinct_column_fraction_last_chunk": round(distinct / (64.0 * last), 4),
                 "stage_ms_per_step": {k: round(v, 3) for k, v in st_s.items()}}
         if mixed is not None:
@@ -248,9 +261,9 @@ def main():
                 "note": "BASELINE configs[3]: same workload with the frequency LSTM and every GEMM on split-bf16 MFMA (operands as "
                         "hi+lo bf16, three v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate/state/activations; front end, conv "
                         "stack, BiLSTM recurrences, softmax fp32); NOT the headline, which stays exact fp32",
-                "mode": "bf16x3", "value": round(F * world * a.steps / dt_m, 1), "unit": "frames/s",
+                "mode": "bf16x3", "value": round(F_all * a.steps / dt_m, 1), "unit": "frames/s",
                 "ms_per_step": round(dt_m / a.steps * 1e3, 3),
-                "with_column_sharing": None if dt_ms is None else round(F * world * a.steps / dt_ms, 1),
+                "with_column_sharing": None if dt_ms is None else round(F_all * a.steps / dt_ms, 1),
                 "stage_ms_per_step": {k: round(v, 3) for k, v in st_m.items()}}
         if world == 1 and not a.no_cpu_baseline:
             cb, gpu_err = cpu_baseline(sr, a.cpu_sample_seconds, eng, sd)
