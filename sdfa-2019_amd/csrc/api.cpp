@@ -827,8 +827,9 @@ int sdfa_regress_forward(const sdfa_model *m, const float *d_z, const int64_t *d
         if (d_out) {
             // PCA expansion: out[n][o] = sum_k coef[k][n] * basis[k][o] + means[o]   (rows = frames)
             pf.begin("pca");
-            if (m->pca_n == 2 && stage_terms(m, STAGE_REGRESSOR) == 0 && !g_sdfa_pca_unfused) {
-                // dgrad head, fp32: both bases in one kernel so that every output line is written once, whole (pca.hip)
+            if (m->pca_n == 2 && !g_sdfa_pca_unfused) {
+                // dgrad head: both bases in one fp32 kernel (all precision modes) so that every output line is written
+                // once, whole (pca.hip)
                 PcaArgs pa{};
                 pa.coef = coef; pa.basis_s = m->pca_q[0]; pa.basis_r = m->pca_q[1]; pa.mean_s = m->pca_bias[0]; pa.mean_r = m->pca_bias[1];
                 pa.out = d_out + f0 * m->out_dim; pa.N = N; pa.Nc = Nc; pa.out_dim = m->out_dim;
