@@ -132,6 +132,7 @@ struct sdfa_model {
     const void *fl_wb = nullptr;   // frequency-LSTM weights as bf16 hi/lo planes (mixed-precision modes)
     int precision = SDFA_PREC_FP32;
     const float *gx_w[2], *tl_w[2];
+    const void *tl_wb[2] = {nullptr, nullptr};   // BiLSTM recurrent weights as bf16 hi/lo planes (mixed-precision modes)
     const float *kp_w, *qc_w, *qp_w, *at_v, *at_b;
     struct Fc { const float *w, *b, *cw; int K, P, Ppad, Pstore; int act; };
     Fc trunk, br[2][3], off[3];
@@ -220,6 +221,22 @@ void pack_freq_lstm_bf16(uint16_t *dst, const float *cat, const int *perm) {
                 const uint16_t lo = bf16_rne_bits(x - bf16_bits_to_float(hi));
                 dst[((size_t)O * 512 + p) * 8 + e] = hi;
                 dst[((size_t)(24 + O) * 512 + p) * 8 + e] = lo;
+            }
+}
+
+// Recurrent weights of one BiLSTM direction for time_lstm_bf16_kernel: [plane hi | lo][32 octets][1024 gate rows][8] bf16,
+// the K axis (256 hidden units) in the accumulator-row order of the kernel (same octet rule as above).
+void pack_rec_bf16(uint16_t *dst, const float *whh, const int *perm) {
+    for (int o = 0; o < 32; ++o)
+        for (int p = 0; p < 1024; ++p)
+            for (int e = 0; e < 8; ++e) {
+                const int w = o >> 2, q = (o >> 1) & 1, hh = o & 1;
+                const int k = 32 * w + 16 * q + 4 * hh + (e & 3) + 8 * (e >> 2);
+                const float x = whh[(size_t)perm[p] * 256 + k];
+                const uint16_t hi = bf16_rne_bits(x);
+                const uint16_t lo = bf16_rne_bits(x - bf16_bits_to_float(hi));
+                dst[((size_t)o * 1024 + p) * 8 + e] = hi;
+                dst[((size_t)(32 + o) * 1024 + p) * 8 + e] = lo;
             }
 }
 
@@ -417,9 +434,10 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
         memcpy(&pk.buf[o_fpb], b->data(), 256 * 4);
     }
     // ---- time BiLSTM (bias=False): input projections as one 2048-row GEMM per layer, recurrent weights K4
-    size_t o_gx[2], o_tl[2];
+    size_t o_gx[2], o_tl[2], o_tlb[2];
     {
         const auto perm = gate_perm(256);
+        for (int l = 0; l < 2; ++l) o_tlb[l] = pk.add((size_t)2 * 2 * 32 * 1024 * 8 / 2);   // bf16 planes, two per float slot
         const char *suf[2] = {"", "_reverse"};
         for (int l = 0; l < 2; ++l) {
             const int Kin = l == 0 ? 256 : 512;
@@ -431,6 +449,7 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
                 if (!wih || !whh) return SDFA_ESTATE;
                 for (int p = 0; p < 1024; ++p) memcpy(&both[((size_t)d * 1024 + p) * Kin], &(*wih)[(size_t)perm[p] * Kin], Kin * 4);
                 size_t o = pack_k4(pk, whh->data(), 1024, 256, 256, 0, 256, 1024, perm.data());
+                pack_rec_bf16(reinterpret_cast<uint16_t *>(&pk.buf[o_tlb[l]]) + (size_t)d * 2 * 32 * 1024 * 8, whh->data(), perm.data());
                 if (d == 0) first = o;
                 else if (o != first + (size_t)64 * 1024 * 4) return fail(SDFA_ESTATE, "internal: time-lstm weights not contiguous");
             }
@@ -513,7 +532,7 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
     m->w3 = d + o_conv[2][0]; m->b3 = d + o_conv[2][1]; m->s3 = d + o_conv[2][2]; m->t3 = d + o_conv[2][3];
     m->fl_wb = d + o_flwb;
     m->fl_w = d + o_flw; m->fl_b = d + o_flb; m->fp_w = d + o_fpw; m->fp_b = d + o_fpb;
-    for (int l = 0; l < 2; ++l) { m->gx_w[l] = d + o_gx[l]; m->tl_w[l] = d + o_tl[l]; }
+    for (int l = 0; l < 2; ++l) { m->gx_w[l] = d + o_gx[l]; m->tl_w[l] = d + o_tl[l]; m->tl_wb[l] = d + o_tlb[l]; }
     m->kp_w = d + o_kp; m->qc_w = d + o_qc; m->qp_w = d + o_qp; m->at_v = d + o_v; m->at_b = d + o_b;
     auto bind = [&](sdfa_model::Fc &fc, size_t o[3]) {
         fc.w = d + o[0]; fc.b = d + o[1]; fc.cw = o[2] == (size_t)-1 ? nullptr : d + o[2];
@@ -548,12 +567,12 @@ Ws layout(int64_t Nc, bool keep) {
     int64_t o = 0;
     auto take = [&](int64_t n) { int64_t r = o; o += round_up(n, 64); return r; };
     if (keep) {   // debug: nothing aliased, taps stay valid after the forward
-        w.P1 = take(2048 * Mc); w.X3 = take(2048 * Mc); w.HF = take(8192 * Mc); w.Z = take(256 * Mc);
+        w.P1 = take(2048 * Mc); w.X3 = take(2048 * Mc); w.HF = take((int64_t)HF_SLAB_ROWS * 4 * Mc); w.Z = take(256 * Mc);
         w.GX = take(2048 * Mc); w.H0 = take(512 * Mc); w.H1 = take(512 * Mc); w.KP = take(128 * Mc);
     } else {
         const int64_t A = take(2048 * Mc);   // P1, later GX
         const int64_t B = take(2048 * Mc);   // X3, later Z | H0 | H1 | KP
-        w.HF = take(8192 * Mc);
+        w.HF = take((int64_t)HF_SLAB_ROWS * 4 * Mc);
         w.P1 = A; w.GX = A;
         w.X3 = B; w.Z = B; w.H0 = B + 256 * Mc; w.H1 = B + 768 * Mc; w.KP = B + 1280 * Mc;
     }
@@ -651,8 +670,8 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
                         int64_t workspace_bytes, void *stream);
 
 // Mixed-precision modes (BASELINE configs[3]).  Which MFMA each stage runs on: 0 = fp32, 1 = bf16 operands,
-// 3 = split-bf16 (hi/lo operands, three MFMAs per product).  The conv stack, the BiLSTM recurrences, softmax/context and
-// every accumulation, bias and activation stay fp32 in all modes.
+// 3 = split-bf16 (hi/lo operands, three MFMAs per product).  The conv stack, the fused dgrad PCA expansion, softmax/context
+// and every accumulation, cell state, bias and activation stay fp32 in all modes.
 enum { STAGE_BODY = 0, STAGE_ATTENTION = 1, STAGE_REGRESSOR = 2 };
 static int stage_terms(const sdfa_model *m, int stage) {
     switch (m->precision) {
@@ -730,7 +749,7 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
         GemmArgs g{};   // FreqLstm._proj: Linear(8192 -> 256) + bias
         g.P = m->fp_w; g.Q = ws + w.HF; g.D = ws + w.Z; g.bias = m->fp_b;
         g.ldp = 256; g.ldq = Mc; g.ldd = Mc; g.Ppad = 256; g.Qpad = Mc; g.Pstore = 256; g.Qreal = Mc;
-        g.K = 8192; g.seg_k = 8192; g.act = ACT_NONE; g.out_mode = OUT_K4; g.q_tile_major = 1;
+        g.K = 8192; g.seg_k = 8192; g.act = ACT_NONE; g.out_mode = OUT_K4; g.q_tile_major = 1; g.q_slab_rows = HF_SLAB_ROWS;
         g.terms = stage_terms(m, STAGE_BODY);
         if (share) { g.D = ws + w.ZU; g.q_limit = d_ulimit; }
         pf.begin("freq_proj"); HIP_TRY(sdfa_launch_gemm(g, s)); pf.end();
@@ -748,7 +767,7 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
             gi.K = l == 0 ? 256 : 512; gi.seg_k = gi.K; gi.act = ACT_NONE; gi.out_mode = OUT_K4;
             gi.terms = stage_terms(m, STAGE_BODY);
             pf.begin(gxn[l]); HIP_TRY(sdfa_launch_gemm(gi, s)); pf.end();
-            TimeLstmArgs ta{ws + w.GX, m->tl_w[l], hout[l], Nc, Mc};
+            TimeLstmArgs ta{ws + w.GX, m->tl_w[l], hout[l], Nc, Mc, m->tl_wb[l], stage_terms(m, STAGE_BODY)};
             pf.begin(lsn[l]); HIP_TRY(sdfa_launch_time_lstm(ta, s)); pf.end();
             xin = hout[l];
         }

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void gemm_k4_kernel(GemmArgs a) {
     // tile-major Q (frequency-LSTM hidden states): a column block of 128 is one contiguous [K/4][128] slab
     const int64_t qrow = a.q_tile_major ? 128 : a.ldq;               // float4 elements between consecutive k-quads
     const float4 *Pn = P + p0;
-    const float4 *Qn = a.q_tile_major ? Q + (q0 >> 7) * (int64_t)nkq_total * 128 : Q + q0;
+    const float4 *Qn = a.q_tile_major ? Q + (q0 >> 7) * (int64_t)a.q_slab_rows * 128 : Q + q0;
     int kin_n = 0;
     const unsigned boffP = (unsigned)(((tid >> 7) * a.ldp + (tid & 127)) * 16);
     const unsigned boffQ = (unsigned)(((tid >> 7) * qrow + (tid & 127)) * 16);
@@ -349,8 +349,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
         rp[it][0] = P[(int64_t)gkq * a.ldp + p0 + c];                                             \
         rp[it][1] = P[(int64_t)(gkq + 1) * a.ldp + p0 + c];                                       \
         if (a.q_tile_major) {                                                                     \
-            rq[it][0] = Q[((q0 >> 7) * (int64_t)(a.K / 4) + gkq) * 128 + c];                      \
-            rq[it][1] = Q[((q0 >> 7) * (int64_t)(a.K / 4) + gkq + 1) * 128 + c];                  \
+            rq[it][0] = Q[((q0 >> 7) * (int64_t)a.q_slab_rows + gkq) * 128 + c];                      \
+            rq[it][1] = Q[((q0 >> 7) * (int64_t)a.q_slab_rows + gkq + 1) * 128 + c];                  \
         } else {                                                                                  \
             rq[it][0] = Q[(int64_t)kin * a.ldq + (int64_t)seg * a.seg_col + q0 + c];              \
             rq[it][1] = Q[(int64_t)(kin + 1) * a.ldq + (int64_t)seg * a.seg_col + q0 + c];        \
@@ -411,6 +411,136 @@ hipError_t launch_bf16(const GemmArgs &a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16-MFMA GEMM, 256 x 256 tile (mixed-precision modes, P and Q multiples of 256): with the matrix work cut 5-16x the
+// 128 x 128 kernel above is bound by its operand stream (32 FLOP per staged byte: the 8192-deep frequency projection
+// took 44 ms in every mode); this tile stages half the bytes per FLOP.  8 waves (2 x 4, each 128 x 64 = 4 x 2 MFMA
+// tiles), operands split into bf16 planes while they are staged, 128 KiB of LDS, one workgroup per CU.
+// ------------------------------------------------------------------------------------------------
+template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND, int TERMS>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_big_kernel(GemmArgs a) {
+    constexpr bool LO = TERMS > 1;
+    constexpr int BT = 256, NPL = LO ? 2 : 1;
+    extern __shared__ bf16x8 sBb[];                        // [2 bufs][P | Q][NPL planes][4 octets][256]
+    auto SPL = [&](int buf, int pq, int plane) { return sBb + ((size_t)((buf * 2 + pq) * NPL + plane) * 4) * BT; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave >> 2, wq = wave & 3, l31 = lane & 31, h = lane >> 5;
+    const int64_t ntp = a.Ppad / BT, bid = blockIdx.x;
+    const int64_t p0 = (bid % ntp) * BT, q0 = (bid / ntp) * BT;
+    if (a.q_limit && q0 >= *a.q_limit) return;
+
+    const float4 *__restrict__ P = reinterpret_cast<const float4 *>(a.P);
+    const float4 *__restrict__ Q = reinterpret_cast<const float4 *>(a.Q);
+    const int nkq_total = a.K / 4, seg_kq = a.seg_k / 4, nstage = a.K / 32;
+    // staging: item it = 0, 1 of a thread is (octet g = 2*it + (tid >> 8), column c = tid & 255): K4 quads 2g and 2g+1.
+    // Uniform running bases + loop-invariant thread byte offsets, as in gemm_k4_kernel.
+    const int c = tid & 255, g0 = tid >> 8;
+    const int64_t qrow = a.q_tile_major ? 128 : a.ldq;
+    const float4 *Pn = P + p0;
+#ifdef SDFA_GEMM_SAMESLAB   /* timing experiment only: every workgroup streams the SAME column block (cache-resident) */
+    const float4 *Qn = a.q_tile_major ? Q : Q + q0;
+#else
+    const float4 *Qn = a.q_tile_major ? Q + (q0 >> 7) * (int64_t)a.q_slab_rows * 128 : Q + q0;
+#endif
+    int kin_n = 0;
+    const unsigned boffP = (unsigned)((2 * g0 * a.ldp + c) * 16);
+    const unsigned boffQ = a.q_tile_major ? (unsigned)((((int64_t)(c >> 7) * a.q_slab_rows + 2 * g0) * 128 + (c & 127)) * 16)
+                                          : (unsigned)((2 * g0 * qrow + c) * 16);
+    float4 rp[2][2], rq[2][2];   // [item][quad of the octet]
+#ifdef SDFA_GEMM_SAMEP   /* timing experiment only: every stage re-reads the first weight rows */
+#define BB_PSTEP
+#else
+#define BB_PSTEP Pn += KQ * a.ldp;
+#endif
+#define BB_GLOAD()                                                                                              \
+    {                                                                                                           \
+        _Pragma("unroll") for (int it = 0; it < 2; ++it)                                                        \
+            _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                     \
+                rp[it][e] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Pn + (4 * it + e) * a.ldp) + boffP); \
+                rq[it][e] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Qn + (4 * it + e) * qrow) + boffQ);  \
+            }                                                                                                   \
+        BB_PSTEP                                                                                                \
+        kin_n += KQ;                                                                                            \
+        if (kin_n == seg_kq) { kin_n = 0; Qn += a.seg_col - (int64_t)(seg_kq - KQ) * qrow; }                    \
+        else Qn += KQ * qrow;                                                                                   \
+    }
+#define BB_LSTORE(buf)                                                                                          \
+    _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                                          \
+        const int g = 2 * it + g0;                                                                              \
+        bf16x8 hi, lo;                                                                                          \
+        split8(rp[it][0], rp[it][1], hi, lo); SPL(buf, 0, 0)[g * BT + c] = hi; if (LO) SPL(buf, 0, NPL - 1)[g * BT + c] = lo; \
+        split8(rq[it][0], rq[it][1], hi, lo); SPL(buf, 1, 0)[g * BT + c] = hi; if (LO) SPL(buf, 1, NPL - 1)[g * BT + c] = lo; \
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    BB_GLOAD()
+    BB_LSTORE(0)
+    __syncthreads();
+    for (int st = 0; st < nstage; ++st) {
+        const int buf = st & 1;
+        const bool reload = st + 1 < nstage;
+        if (reload) { BB_GLOAD() }
+#ifdef SDFA_GEMM_LOADONLY   /* timing experiment only: the operand stream without LDS staging and matrix work */
+        acc[0][0][0] += rp[0][0].x + rp[0][1].y + rp[1][0].z + rp[1][1].w + rq[0][0].x + rq[0][1].y + rq[1][0].z + rq[1][1].w;
+        continue;
+#endif
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {   // two k-steps of 16
+            bf16x8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ah[i] = SPL(buf, 0, 0)[(2 * m + h) * BT + wp * 128 + i * 32 + l31];
+                if (LO) al[i] = SPL(buf, 0, NPL - 1)[(2 * m + h) * BT + wp * 128 + i * 32 + l31];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bh[j] = SPL(buf, 1, 0)[(2 * m + h) * BT + wq * 64 + j * 32 + l31];
+                if (LO) bl[j] = SPL(buf, 1, NPL - 1)[(2 * m + h) * BT + wq * 64 + j * 32 + l31];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (LO) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (reload) { BB_LSTORE(buf ^ 1) }
+        __syncthreads();
+    }
+#undef BB_GLOAD
+#undef BB_LSTORE
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            store_tile<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, acc[i][j], p0 + wp * 128 + i * 32, q0 + wq * 64 + j * 32 + l31, h);
+}
+
+template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND, int TERMS>
+hipError_t launch_bf16_big(const GemmArgs &a, hipStream_t s) {
+    const size_t lds = (size_t)2 * 2 * (TERMS > 1 ? 2 : 1) * 4 * 256 * sizeof(bf16x8);   // 128 KiB (split) / 64 KiB
+    {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16_big_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, TERMS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const int64_t nblk = (a.Ppad / 256) * (a.Qpad / 256);
+    hipLaunchKernelGGL((gemm_bf16_big_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, TERMS>), dim3((unsigned)nblk), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // 256 x 256 tile, 8 waves (2 x 4, each 128 x 64 = 4 x 2 MFMA tiles), 128 KiB LDS, one workgroup per CU.
 // Half the staged bytes per FLOP of the 128 x 128 tile: the 128-tile kernel's time did not move when its MFMA work
 // was cut 5x (split-bf16 experiment) -- it is bound by the global->LDS staging stream -- so the big GEMMs
@@ -432,22 +562,50 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs a) {
     auto SP = [&](int buf) { return sBig + (size_t)buf * 2 * KQ * BT; };
     auto SQ = [&](int buf) { return sBig + (size_t)buf * 2 * KQ * BT + KQ * BT; };
 
-    float4 rp0, rp1, rp2, rp3, rq0, rq1, rq2, rq3;
-#define BG_GLOAD1(st, i, RP, RQ)                                                             \
-    {                                                                                        \
-        const int idx = (i)*512 + tid, kq = idx >> 8, c = idx & 255, gkq = (st)*KQ + kq;     \
-        RP = P[(int64_t)gkq * a.ldp + p0 + c];                                               \
-        const int seg = gkq / seg_kq, kin = gkq - seg * seg_kq;                              \
-        RQ = Q[(int64_t)kin * a.ldq + (int64_t)seg * a.seg_col + q0 + c];                    \
+    // staging loads: uniform running bases + one loop-invariant byte offset per thread (see gemm_k4_kernel); item i of a
+    // thread is k-quad 2i + (tid >> 8), column tid & 255
+    const int c = tid & 255, kq0 = tid >> 8;
+    const int64_t qrow = a.q_tile_major ? 128 : a.ldq;
+    const float4 *Pn = P + p0;
+    const float4 *Qn = a.q_tile_major ? Q + (q0 >> 7) * (int64_t)a.q_slab_rows * 128 : Q + q0;
+    int kin_n = 0;
+    const unsigned boffP = (unsigned)((kq0 * a.ldp + c) * 16);
+    const unsigned boffQ = a.q_tile_major ? (unsigned)((((int64_t)(c >> 7) * a.q_slab_rows + kq0) * 128 + (c & 127)) * 16)
+                                          : (unsigned)((kq0 * qrow + c) * 16);
+    // register staging two tiles ahead in two alternating sets (A: ra/rb, B: rc/rd), as in gemm_k4_kernel
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, rc0, rc1, rc2, rc3, rd0, rd1, rd2, rd3;
+#define BG_GLOAD1(i, RP, RQ)                                                                            \
+    {                                                                                                   \
+        RP = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Pn + (i) * 2 * a.ldp) + boffP); \
+        RQ = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Qn + (i) * 2 * qrow) + boffQ);  \
     }
-#define BG_GLOAD(st) BG_GLOAD1(st, 0, rp0, rq0) BG_GLOAD1(st, 1, rp1, rq1) BG_GLOAD1(st, 2, rp2, rq2) BG_GLOAD1(st, 3, rp3, rq3)
+#define BG_ADVANCE()                                                                                    \
+    {                                                                                                   \
+        Pn += KQ * a.ldp;                                                                               \
+        kin_n += KQ;                                                                                    \
+        if (kin_n == seg_kq) { kin_n = 0; Qn += a.seg_col - (int64_t)(seg_kq - KQ) * qrow; }            \
+        else Qn += KQ * qrow;                                                                           \
+    }
+#define BG_GLOAD_A() BG_GLOAD1(0, ra0, rb0) BG_GLOAD1(1, ra1, rb1) BG_GLOAD1(2, ra2, rb2) BG_GLOAD1(3, ra3, rb3) BG_ADVANCE()
+#define BG_GLOAD_B() BG_GLOAD1(0, rc0, rd0) BG_GLOAD1(1, rc1, rd1) BG_GLOAD1(2, rc2, rd2) BG_GLOAD1(3, rc3, rd3) BG_ADVANCE()
 #define BG_LSTORE1(buf, i, RP, RQ)                                     \
     {                                                                  \
         const int idx = (i)*512 + tid;                                 \
         SP(buf)[idx] = RP;                                             \
         SQ(buf)[idx] = RQ;                                             \
     }
-#define BG_LSTORE(buf) BG_LSTORE1(buf, 0, rp0, rq0) BG_LSTORE1(buf, 1, rp1, rq1) BG_LSTORE1(buf, 2, rp2, rq2) BG_LSTORE1(buf, 3, rp3, rq3)
+#define BG_LSTORE_A(buf) BG_LSTORE1(buf, 0, ra0, rb0) BG_LSTORE1(buf, 1, ra1, rb1) BG_LSTORE1(buf, 2, ra2, rb2) BG_LSTORE1(buf, 3, ra3, rb3)
+#define BG_LSTORE_B(buf) BG_LSTORE1(buf, 0, rc0, rd0) BG_LSTORE1(buf, 1, rc1, rd1) BG_LSTORE1(buf, 2, rc2, rd2) BG_LSTORE1(buf, 3, rc3, rd3)
+#define BG_COMPUTE(buf)                                                                                 \
+    {                                                                                                   \
+        const float4 *sp = SP(buf), *sq = SQ(buf);                                                      \
+        _Pragma("unroll") for (int kb = 0; kb < KQ / 2; ++kb) {                                         \
+            float4 fa[4], fb[2];                                                                        \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[i] = sp[(2 * kb + h) * BT + wp * 128 + i * 32 + l31]; \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) fb[j] = sq[(2 * kb + h) * BT + wq * 64 + j * 32 + l31];  \
+            mfma_block<4, 2>(acc, fa, fb);                                                              \
+        }                                                                                               \
+    }
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -457,29 +615,26 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    BG_GLOAD(0)
-    BG_LSTORE(0)
+    BG_GLOAD_A()
+    BG_LSTORE_A(0)
+    if (nstage > 1) { BG_GLOAD_A() }
     __syncthreads();
-    for (int st = 0; st < nstage; ++st) {
-        const int buf = st & 1;
-        const bool reload = st + 1 < nstage;
-        if (reload) { BG_GLOAD(st + 1) }
-        const float4 *sp = SP(buf), *sq = SQ(buf);
-#pragma unroll
-        for (int kb = 0; kb < KQ / 2; ++kb) {
-            float4 fa[4], fb[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = sp[(2 * kb + h) * BT + wp * 128 + i * 32 + l31];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = sq[(2 * kb + h) * BT + wq * 64 + j * 32 + l31];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { mfma4(acc[i][0], fa[i], fb[0]); mfma4(acc[i][1], fa[i], fb[1]); }
-        }
-        if (reload) { BG_LSTORE(buf ^ 1) }
+    int st = 0;
+    for (; st + 1 < nstage; st += 2) {
+        if (st + 2 < nstage) { BG_GLOAD_B() }     // even stage: LDS buffer 0 = tile st, set A = tile st+1
+        BG_COMPUTE(0)
+        BG_LSTORE_A(1)
+        __syncthreads();
+        if (st + 3 < nstage) { BG_GLOAD_A() }     // odd stage: LDS buffer 1 = tile st+1, set B = tile st+2
+        BG_COMPUTE(1)
+        if (st + 2 < nstage) { BG_LSTORE_B(0) }
         __syncthreads();
     }
-#undef BG_GLOAD
-#undef BG_LSTORE
+    if (st < nstage) { BG_COMPUTE(0) }            // odd stage count: the last tile is already in LDS buffer 0
+#undef BG_GLOAD1
+#undef BG_ADVANCE
+#undef BG_COMPUTE
+
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -532,7 +687,7 @@ __global__ __launch_bounds__(384) void gemm_pc_kernel(GemmArgs a) {
                 __builtin_amdgcn_global_load_lds(                                                                  \
                     (const void __attribute__((address_space(1))) *)(P + (int64_t)gkq * a.ldp + p0 + c0 + lane),   \
                     (void __attribute__((address_space(3))) *)(&sP[buf][kq][c0]), 16, 0, 0);                       \
-                const float4 *qsrc = a.q_tile_major ? Q + ((q0 >> 7) * (int64_t)nkq_total + gkq) * 128 + c0 + lane \
+                const float4 *qsrc = a.q_tile_major ? Q + ((q0 >> 7) * (int64_t)a.q_slab_rows + gkq) * 128 + c0 + lane \
                                                     : Q + (int64_t)kin * a.ldq + (int64_t)seg * a.seg_col + q0 + c0 + lane; \
                 __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)qsrc,             \
                                                  (void __attribute__((address_space(3))) *)(&sQ[buf][kq][c0]), 16, 0, 0); \
@@ -596,15 +751,22 @@ int g_sdfa_gemm_variant = 0;   // 0 = LDS-tiled (default), 1/2 = register-direct
 
 template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
 hipError_t launch_any(const GemmArgs &a, hipStream_t s) {
-    if (a.terms == 1) return launch_bf16<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 1>(a, s);   // mixed-precision modes
-    if (a.terms == 3) return launch_bf16<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 3>(a, s);
+    if (a.terms) {   // mixed-precision modes
+        const bool big = a.Ppad % 256 == 0 && a.Qpad % 256 == 0 && g_sdfa_gemm_variant != 7;
+        if (a.terms == 1) return big ? launch_bf16_big<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 1>(a, s) : launch_bf16<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 1>(a, s);
+        return big ? launch_bf16_big<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 3>(a, s) : launch_bf16<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 3>(a, s);
+    }
     if (g_sdfa_gemm_variant == 4 && !a.q_tile_major) return launch_bf16<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 3>(a, s);
     if (g_sdfa_gemm_variant == 6) return launch_pc<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
+    // 256 x 256 tile: on request (gemm_variant 5), and by default for the 8192-deep frequency projection, whose operand
+    // stream (2 MB of hidden states per frame) is what the 128 x 128 tile waits for (40.3 vs 41.7 ms); the L2-resident
+    // projections are faster on the small tile (two independent workgroups per CU)
+    if ((g_sdfa_gemm_variant == 5 || (a.q_tile_major && g_sdfa_gemm_variant == 0)) && a.Ppad % 256 == 0 && a.Qpad % 256 == 0)
+        return launch_big<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
     if (a.q_tile_major) return launch<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);   // only the LDS-tiled kernels read that layout
     if (g_sdfa_gemm_variant == 1 && a.Ppad % 128 == 0) return launch_direct<4, OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
     if (g_sdfa_gemm_variant == 2 && a.Ppad % 64 == 0) return launch_direct<2, OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
     if (g_sdfa_gemm_variant == 3) return launch<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, true>(a, s);
-    if (g_sdfa_gemm_variant == 5 && a.Ppad % 256 == 0 && a.Qpad % 256 == 0) return launch_big<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
     return launch<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
 }
 
@@ -620,7 +782,7 @@ hipError_t sdfa_launch_gemm(const GemmArgs &a, hipStream_t s) {
         if (a.act == ACT_LRELU && bp) return launch_any<OUT_K4, ACT_LRELU, true, false, true>(a, s);
         return hipErrorInvalidValue;
     }
-    if (a.act == ACT_NONE) return bp ? launch<OUT_K4, ACT_NONE, true, false, false>(a, s)
+    if (a.act == ACT_NONE) return bp ? launch_any<OUT_K4, ACT_NONE, true, false, false>(a, s)
                                      : launch_any<OUT_K4, ACT_NONE, false, false, false>(a, s);
     if (a.act == ACT_TANH && bp) return launch_any<OUT_K4, ACT_TANH, true, false, false>(a, s);
     if (a.act == ACT_LRELU && bp) return launch_any<OUT_K4, ACT_LRELU, true, false, false>(a, s);

@@ -4,6 +4,15 @@
 #include <stdint.h>
 
 enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_TANH = 2 };
+
+// Frequency-LSTM hidden states are stored tile-major: float4[column block of 128][HF_SLAB_ROWS][128], of which the
+// first 8192/4 = 2048 rows of a slab are used.  The pad rows keep the slab stride off a power of two: every workgroup
+// of the projection GEMM streams its own slab front to back at about the same pace, and with a 4 MiB stride all of
+// them would sit on the same HBM channels at the same time.
+#ifndef SDFA_HF_PAD
+#define SDFA_HF_PAD 0
+#endif
+constexpr int HF_SLAB_ROWS = 2048 + SDFA_HF_PAD;
 enum { OUT_K4 = 0, OUT_ROW = 1 };
 
 struct GemmArgs {
@@ -22,7 +31,8 @@ struct GemmArgs {
     int64_t seg_col;     // Q column offset between segments
     int act, out_mode, bias_on_q;
     int terms;                // 0 = fp32 MFMA; 1 = operands rounded to bf16; 3 = split-bf16, three bf16 MFMAs per product
-    int q_tile_major;         // Q is stored tile-major: float4[column block of 128][K/4][128] (the freq-LSTM hidden states)
+    int q_tile_major;         // Q is stored tile-major: float4[column block of 128][q_slab_rows >= K/4][128] (the freq-LSTM hidden states)
+    int q_slab_rows;
     const int64_t *q_limit;   // device scalar: tiles whose first column is >= *q_limit exit at once (null = no limit)
     int col_group, col_stride, col_off;   // OUT_ROW only: column q is stored at (q / group) * stride + off + q % group (group 0 = identity)
 };
@@ -88,6 +98,8 @@ struct TimeLstmArgs {
     const float *W;      // per direction: K4 [256/4][1024][4]
     float *H;            // K4 [512/4][Mc]   rows dir*256 + j
     int64_t Nc, Mc;
+    const void *Wb;      // mixed-precision modes: per direction bf16x8 [hi | lo][32 octets][1024 rows] (lstm.hip)
+    int terms;           // 0 = fp32 MFMA; 1 = bf16; 3 = split-bf16
 };
 hipError_t sdfa_launch_time_lstm(const TimeLstmArgs &a, hipStream_t s);
 

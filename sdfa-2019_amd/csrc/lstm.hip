@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, WGS) void freq_lstm_kernel(FreqLstmArgs a) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) HF[((m0 >> 7) * (int64_t)2048 + (f * 64 + dir * 32 + 8 * wave + 2 * g + h)) * 128 + (m0 & 127) + j * 32 + l31] = hq[j][g];
+                for (int g = 0; g < 4; ++g) HF[((m0 >> 7) * (int64_t)HF_SLAB_ROWS + (f * 64 + dir * 32 + 8 * wave + 2 * g + h)) * 128 + (m0 & 127) + j * 32 + l31] = hq[j][g];
             LSTAMP(e3)
             s_math += e1 - q3; s_lds += e2 - e1;
         }
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256, WGS) void freq_lstm_kernel(FreqLstmArgs a) {
                 lstm_cell_quad(acc[0][j], acc[1][j], acc[2][j], acc[3][j], c[j], g, hq);
                 const int hq_idx = 8 * wave + 2 * g + h;
                 sH[hq_idx][j * 32 + l31] = hq;
-                HF[((m0 >> 7) * (int64_t)2048 + (f * 64 + dir * 32 + hq_idx)) * 128 + (m0 & 127) + j * 32 + l31] = hq;
+                HF[((m0 >> 7) * (int64_t)HF_SLAB_ROWS + (f * 64 + dir * 32 + hq_idx)) * 128 + (m0 & 127) + j * 32 + l31] = hq;
             }
         if (s + 1 < 32) { XSTORE(cur ^ 1) }
 #endif
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_bf16_kernel(FreqLstmArgs a) 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 lstm_cell_quad(acc[0][j], acc[1][j], acc[2][j], acc[3][j], c[j], g, hq[g]);
-                HF[((m0 >> 7) * (int64_t)2048 + (f * 64 + dir * 32 + 8 * wave + 2 * g + h)) * 128 + (m0 & 127) + j * 32 + l31] = hq[g];
+                HF[((m0 >> 7) * (int64_t)HF_SLAB_ROWS + (f * 64 + dir * 32 + 8 * wave + 2 * g + h)) * 128 + (m0 & 127) + j * 32 + l31] = hq[g];
             }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -489,6 +489,117 @@ __global__ __launch_bounds__(512, 2) void time_lstm_kernel(TimeLstmArgs a) {
 #undef TL_GX
 }
 
+// ------------------------------------------------------------------------------ time LSTM on bf16 MFMA
+// Mixed-precision modes: the BiLSTM recurrence h_{t-1} * W_hh^T on v_mfma_f32_32x32x16_bf16 (TERMS 1 or 3, see
+// freq_lstm_bf16_kernel); input projection (from the GEMM), accumulation, cell state and gate math stay fp32.
+// h lives in LDS as bf16x8 octets, split by the lane that produced it: octet 4w + 2q + h holds hidden units
+// 32w+16q+4h+{0..3} and 32w+16q+8+4h+{0..3}; the host packs W_hh's K axis in that order (api.cpp: pack_rec_bf16).
+template <int NT, int TERMS>
+__global__ __launch_bounds__(512, 2) void time_lstm_bf16_kernel(TimeLstmArgs a) {
+    constexpr bool LO = TERMS > 1;
+    constexpr int NPL = LO ? 2 : 1, BT = 32 * NT;
+    extern __shared__ bf16x8 sHb[];   // [2 buffers][NPL planes][32 octets][BT sequences]
+    auto SH = [&](int buf, int plane) { return sHb + ((size_t)(buf * NPL + plane) * 32) * BT; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // 8 waves: hidden block of 32
+    const int l31 = lane & 31, h = lane >> 5;
+    const int dir = blockIdx.x & 1;
+    const int64_t n0 = (int64_t)(blockIdx.x >> 1) * BT;
+
+    const float4 *__restrict__ GX = reinterpret_cast<const float4 *>(a.GX);
+    // per direction: [plane hi | lo][32 octets][1024 gate rows]
+    const bf16x8 *__restrict__ Wh = reinterpret_cast<const bf16x8 *>(a.Wb) + (size_t)dir * 2 * 32 * 1024 + wave * 128 + l31;
+    const bf16x8 *__restrict__ Wl = Wh + 32 * 1024;
+    float4 *__restrict__ H = reinterpret_cast<float4 *>(a.H);
+
+    f32x16 c[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[j][r] = 0.f;
+
+    f32x16 acc[4][NT];
+#define TB_GX(t_, gt, g, j) GX[(int64_t)(dir * 256 + wave * 32 + (gt) * 8 + 2 * (g) + h) * a.Mc + (int64_t)(t_) * a.Nc + n0 + l31 + (j) * 32]
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const float4 v = TB_GX(dir ? 63 : 0, gt, g, j);
+                acc[gt][j][4 * g + 0] = v.x; acc[gt][j][4 * g + 1] = v.y; acc[gt][j][4 * g + 2] = v.z; acc[gt][j][4 * g + 3] = v.w;
+            }
+
+    for (int s = 0; s < 64; ++s) {
+        const int t = dir ? 63 - s : s;
+        const int tn = dir ? t - 1 : t + 1;
+        const int64_t mcol = (int64_t)t * a.Nc + n0 + l31;
+        const int cur = s & 1;
+
+        if (s > 0) {
+            bf16x8 whn[4];
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt) whn[gt] = Wh[h * 1024 + gt * 32];
+#pragma unroll 1
+            for (int ks = 0; ks < 16; ++ks) {
+                bf16x8 wh[4], wl[4], bh[NT], bl[NT];
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt) {
+                    wh[gt] = whn[gt];
+                    if (LO) wl[gt] = Wl[(2 * ks + h) * 1024 + gt * 32];
+                }
+                const int kn = ks + 1 < 16 ? ks + 1 : 0;      // branch-free: the last request is dropped
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt) whn[gt] = Wh[(2 * kn + h) * 1024 + gt * 32];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    bh[j] = SH(cur, 0)[(2 * ks + h) * BT + j * 32 + l31];
+                    if (LO) bl[j] = SH(cur, NPL - 1)[(2 * ks + h) * BT + j * 32 + l31];
+                }
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[gt][j] = MFMA_BF16(wh[gt], bh[j], acc[gt][j]);
+                if (LO) {
+#pragma unroll
+                    for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) acc[gt][j] = MFMA_BF16(wh[gt], bl[j], acc[gt][j]);
+#pragma unroll
+                    for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) acc[gt][j] = MFMA_BF16(wl[gt], bh[j], acc[gt][j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float4 hq[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                lstm_cell_quad(acc[0][j], acc[1][j], acc[2][j], acc[3][j], c[j], g, hq[g]);
+                H[(int64_t)(dir * 64 + 8 * wave + 2 * g + h) * a.Mc + mcol + j * 32] = hq[g];
+                if (s + 1 < 64) {   // this quad's gate registers are free: request the next step's input projection into them
+#pragma unroll
+                    for (int gt = 0; gt < 4; ++gt) {
+                        const float4 v = TB_GX(tn, gt, g, j);
+                        acc[gt][j][4 * g + 0] = v.x; acc[gt][j][4 * g + 1] = v.y; acc[gt][j][4 * g + 2] = v.z; acc[gt][j][4 * g + 3] = v.w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                bf16x8 hi, lo;
+                split_octet(hq[2 * q], hq[2 * q + 1], hi, lo);
+                SH(cur ^ 1, 0)[(4 * wave + 2 * q + h) * BT + j * 32 + l31] = hi;
+                if (LO) SH(cur ^ 1, NPL - 1)[(4 * wave + 2 * q + h) * BT + j * 32 + l31] = lo;
+            }
+        }
+        __syncthreads();   // h_s complete in the other buffer before anyone reads it; this one free for step s+1's writes
+    }
+#undef TB_GX
+}
+
 }  // namespace
 
 #ifdef SDFA_STAMPS
@@ -539,7 +650,25 @@ static hipError_t launch_time(const TimeLstmArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
+template <int NT, int TERMS>
+static hipError_t launch_time_bf16(const TimeLstmArgs &a, hipStream_t s) {
+    const size_t lds = (size_t)2 * (TERMS > 1 ? 2 : 1) * 32 * 32 * NT * sizeof(bf16x8);   // 128 KiB (NT 2, split) ... 32 KiB
+    {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(time_lstm_bf16_kernel<NT, TERMS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((time_lstm_bf16_kernel<NT, TERMS>), dim3((unsigned)(a.Nc / (32 * NT) * 2)), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
 hipError_t sdfa_launch_time_lstm(const TimeLstmArgs &a, hipStream_t s) {
     // 64-frame tiles while they fill the 256 CUs (one 8-wave workgroup per CU); otherwise 32-frame tiles
-    return (a.Nc / 64) * 2 >= 256 ? launch_time<2>(a, s) : launch_time<1>(a, s);
+    const bool big = (a.Nc / 64) * 2 >= 256;
+    if (a.terms) {
+        if (!a.Wb) return hipErrorInvalidValue;
+        if (a.terms == 1) return big ? launch_time_bf16<2, 1>(a, s) : launch_time_bf16<1, 1>(a, s);
+        return big ? launch_time_bf16<2, 3>(a, s) : launch_time_bf16<1, 3>(a, s);
+    }
+    return big ? launch_time<2>(a, s) : launch_time<1>(a, s);
 }
