@@ -192,7 +192,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    STAGES = ("conv1", "conv23", "freq_lstm", "freq_proj", "gx0", "lstm0", "gx1", "lstm1", "attn_proj", "attn", "mlp", "pca")
+    STAGES = ("conv23", "freq_lstm", "freq_proj", "gx0", "lstm0", "gx1", "lstm1", "attn_proj", "attn", "mlp", "pca")
 
     def timed(share):
         """W warm-up steps, then EXACTLY K timed steps between barrier + synchronize fences; max over ranks."""

@@ -627,10 +627,12 @@ int64_t sdfa_workspace_bytes(const sdfa_model *m, int64_t max_frames) {
 extern int g_sdfa_gemm_variant;
 int g_sdfa_freq_lstm_shape = 0;
 int g_sdfa_pca_unfused = 0;
+int g_sdfa_conv_unfused = 0;
 int sdfa_debug_set_option(const char *name, int value) {
     if (name && !strcmp(name, "gemm_variant")) { g_sdfa_gemm_variant = value; return SDFA_OK; }
     if (name && !strcmp(name, "freq_lstm_shape")) { g_sdfa_freq_lstm_shape = value; return SDFA_OK; }
     if (name && !strcmp(name, "pca_unfused")) { g_sdfa_pca_unfused = value; return SDFA_OK; }
+    if (name && !strcmp(name, "conv_unfused")) { g_sdfa_conv_unfused = value; return SDFA_OK; }
     return fail(SDFA_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }
 
@@ -740,8 +742,12 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
             d_ulimit = sa.counts + 1; col_to_u = sa.col_to_u;
             ca.col_src = sa.col_src; ca.col_limit = d_ulimit;
         }
-        pf.begin("conv1"); HIP_TRY(sdfa_launch_conv1(ca, s)); pf.end();
-        pf.begin("conv23"); HIP_TRY(sdfa_launch_conv23(ca, s)); pf.end();
+        if (m->keep || g_sdfa_conv_unfused) {   // the debug taps read pool1
+            pf.begin("conv1"); HIP_TRY(sdfa_launch_conv1(ca, s)); pf.end();
+            pf.begin("conv23"); HIP_TRY(sdfa_launch_conv23(ca, s)); pf.end();
+        } else {
+            pf.begin("conv23"); HIP_TRY(sdfa_launch_conv123(ca, s)); pf.end();
+        }
 
         FreqLstmArgs fa{ws + w.X3, m->fl_w, m->fl_b, ws + w.HF, Mc, d_ulimit, m->fl_wb, stage_terms(m, STAGE_BODY)};
         pf.begin("freq_lstm"); HIP_TRY(sdfa_launch_freq_lstm(fa, s)); pf.end();

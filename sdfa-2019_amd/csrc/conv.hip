@@ -190,10 +190,159 @@ __global__ __launch_bounds__(256, 2) void conv23_kernel(ConvArgs a) {
         }
 }
 
+// ------------------------------------------------- conv1 + pool + conv2 + pool + conv3 in one kernel
+// conv23_kernel reads 10 pool1 rows (8 + a halo of 2) per workgroup: 1.25 x 512 KB per frame in, after conv1_pool_kernel
+// wrote the same 512 KB out -- an HBM round trip of 1.1 MB per frame for 4.7 MFLOP of work.  Here the workgroup builds
+// its 10 pool1 rows itself from the 22 frequency rows x 3 channels of audio_feat they depend on (66 contiguous floats
+// per column; conv1 is recomputed 1.25 x), straight into the LDS image conv2 multiplies from.  Same arithmetic, same
+// order per output element as the two-kernel path (which stays, for the debug taps): bitwise identical results.
+__global__ __launch_bounds__(256, 2) void conv123_kernel(ConvArgs a) {
+    __shared__ float4 sP1[80][32];   // 10 pool1 rows x 32 ci as 80 k-quads
+    __shared__ float sIn[68][33];    // input rows k = (f - f_lo) * 3 + c, f_lo = 16 fc - 3; +1 column against bank conflicts
+    __shared__ float sPar[6][64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int fc = blockIdx.x & 7;                       // chunk of 4 pooled rows
+    const int64_t m0 = (int64_t)(blockIdx.x >> 3) * 32;
+    if (a.col_limit && m0 >= *a.col_limit) return;
+    const int64_t t = m0 / a.Nc, n0 = m0 % a.Nc;
+
+    // ---- input slice: audio_feat row (n, t) is 384 contiguous floats (f*3 + c); this workgroup needs 66 of them
+    const int k_lo = (16 * fc - 3) * 3;
+    {   // thread -> (column tid >> 3, nine consecutive k starting at 9 * (tid & 7)): 8 x 9 = 72 >= 68 rows, no divisions
+        const int col = tid >> 3, kb0 = (tid & 7) * 9;
+        const int64_t n = n0 + col;
+        int64_t row = n < a.N ? n * 64 + t : -1;
+        if (a.col_src) row = a.col_src[m0 + col];
+        const float *src = a.audio_feat + (row >= 0 ? row : 0) * 384 + k_lo;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int k = kb0 + i, gk = k_lo + k;
+            if (k < 68) sIn[k][col] = (row >= 0 && k < 66 && gk >= 0 && gk < 384) ? src[k] : 0.f;
+        }
+    }
+    if (tid < 64) {
+        sPar[0][tid] = a.b2[tid]; sPar[1][tid] = a.s2[tid]; sPar[2][tid] = a.t2[tid];
+        sPar[3][tid] = a.b3[tid]; sPar[4][tid] = a.s3[tid]; sPar[5][tid] = a.t3[tid];
+    }
+    const float4 *__restrict__ W2 = reinterpret_cast<const float4 *>(a.w2) + h * 64 + l31;
+    const float4 *__restrict__ W3 = reinterpret_cast<const float4 *>(a.w3);
+    float4 wa[2] = {W2[0], W2[32]}, wb[2];
+    __syncthreads();
+
+    // ---- conv1 + LeakyReLU + BN + pool: pool1 row j of the slice (global row 8 fc - 1 + j), rows j = wave, wave+4, wave+8
+    {
+        float w1[5];
+#pragma unroll
+        for (int s = 0; s < 5; ++s) w1[s] = a.w1[(s * 2 + h) * 32 + l31];
+        for (int j = wave; j < 10; j += 4) {
+            const int f1 = 8 * fc - 1 + j;
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+                const float b0 = sIn[6 * j + 2 * s + h][l31];
+                const float b1 = sIn[6 * j + 3 + 2 * s + h][l31];
+                acc0 = MFMA(SDFA_OP(w1[s]), SDFA_OP(b0), acc0);
+                acc1 = MFMA(SDFA_OP(w1[s]), SDFA_OP(b1), acc1);
+            }
+            const bool valid = f1 >= 0 && f1 < 64;       // rows -1 and 64 are conv2's zero padding
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 b = ld4(a.b1 + 8 * g + 4 * h), sc = ld4(a.s1 + 8 * g + 4 * h), sh = ld4(a.t1 + 8 * g + 4 * h);
+                const float bq[4] = {b.x, b.y, b.z, b.w}, sq[4] = {sc.x, sc.y, sc.z, sc.w}, tq[4] = {sh.x, sh.y, sh.z, sh.w};
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v0 = lrelu02(acc0[4 * g + e] + bq[e]) * sq[e] + tq[e];
+                    const float v1 = lrelu02(acc1[4 * g + e] + bq[e]) * sq[e] + tq[e];
+                    o[e] = valid ? fmaxf(v0, v1) : 0.f;
+                }
+                sP1[j * 8 + 2 * g + h][l31] = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- conv2 + pool + conv3: identical to conv23_kernel from here on
+    const int fo = fc * 4 + wave;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll 1
+    for (int kb = 0; kb < 12; kb += 2) {
+        wb[0] = W2[(kb + 1) * 128]; wb[1] = W2[(kb + 1) * 128 + 32];
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const float4 x[2] = {sP1[16 * wave + 2 * kb + h][l31], sP1[16 * wave + 8 + 2 * kb + h][l31]};
+            mfma_block<2, 2>(acc, wa, x);
+        }
+        const int kn = kb + 2 < 12 ? kb + 2 : 0;
+        wa[0] = W2[kn * 128]; wa[1] = W2[kn * 128 + 32];
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const float4 x[2] = {sP1[16 * wave + 2 * (kb + 1) + h][l31], sP1[16 * wave + 8 + 2 * (kb + 1) + h][l31]};
+            mfma_block<2, 2>(acc, wb, x);
+        }
+    }
+    f32x16 p2[2];
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ch = ot * 32 + 8 * g + 4 * h;
+            float4 b = ld4(&sPar[0][ch]), sc = ld4(&sPar[1][ch]), sh = ld4(&sPar[2][ch]);
+            const float bq[4] = {b.x, b.y, b.z, b.w}, sq[4] = {sc.x, sc.y, sc.z, sc.w}, tq[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v0 = lrelu02(acc[ot][0][4 * g + e] + bq[e]) * sq[e] + tq[e];
+                float v1 = lrelu02(acc[ot][1][4 * g + e] + bq[e]) * sq[e] + tq[e];
+                p2[ot][4 * g + e] = fmaxf(v0, v1);
+            }
+        }
+    f32x16 acc3[2][1];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc3[j][0][r] = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 xb[1] = {make_float4(p2[ct][4 * g], p2[ct][4 * g + 1], p2[ct][4 * g + 2], p2[ct][4 * g + 3])};
+            const float4 w[2] = {W3[(8 * ct + 2 * g + h) * 64 + l31], W3[(8 * ct + 2 * g + h) * 64 + 32 + l31]};
+            mfma_block<2, 1>(acc3, w, xb);
+        }
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ch = ot * 32 + 8 * g + 4 * h;
+            float4 b = ld4(&sPar[3][ch]), sc = ld4(&sPar[4][ch]), sh = ld4(&sPar[5][ch]);
+            float4 o;
+            o.x = lrelu02(acc3[ot][0][4 * g + 0] + b.x) * sc.x + sh.x;
+            o.y = lrelu02(acc3[ot][0][4 * g + 1] + b.y) * sc.y + sh.y;
+            o.z = lrelu02(acc3[ot][0][4 * g + 2] + b.z) * sc.z + sh.z;
+            o.w = lrelu02(acc3[ot][0][4 * g + 3] + b.w) * sc.w + sh.w;
+            st4(a.X3 + ((int64_t)(fo * 16 + ot * 8 + 2 * g + h) * a.Mc + m0 + l31) * 4, o);
+        }
+}
+
 }  // namespace
 
 hipError_t sdfa_launch_conv1(const ConvArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(conv1_pool_kernel, dim3((unsigned)(a.Mc / 32)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t sdfa_launch_conv123(const ConvArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(conv123_kernel, dim3((unsigned)(a.Mc / 32 * 8)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

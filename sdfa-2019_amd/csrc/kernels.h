@@ -79,6 +79,7 @@ struct ConvArgs {
 };
 hipError_t sdfa_launch_conv1(const ConvArgs &a, hipStream_t s);
 hipError_t sdfa_launch_conv23(const ConvArgs &a, hipStream_t s);
+hipError_t sdfa_launch_conv123(const ConvArgs &a, hipStream_t s);   // conv1_pool + conv23 fused (P1 is not written)
 
 // ---- LSTM recurrences ----------------------------------------------------------------------
 struct FreqLstmArgs {

@@ -227,6 +227,20 @@ def test_error_paths(eng, synth_sd):
         Engine(bad)
 
 
+def test_fused_conv_stack_is_bitwise_the_two_kernel_path(eng, synth_sd, golden):
+    """conv123_kernel (product) vs conv1_pool + conv23 (kept for the debug taps, used by `eng`): same arithmetic per
+    element, so z must be identical bit for bit -- on a ragged batch that leaves a partial column tile."""
+    clips = [synth.make_pcm(0, 32000), synth.make_pcm(5, 9088 + 777, "speechlike")]
+    feat, _, _ = eng.mel_frontend(clips, 16000)
+    z0, a0 = eng.encoder(feat)                           # debug_keep engine: two kernels
+    fused = Engine(synth_sd["dgrad"])
+    z1, a1 = fused.encoder(feat)
+    assert torch.equal(z0, z1) and torch.equal(a0, a1)
+    fc, fs, hop = eng.last_frame_table
+    z2, _ = fused.encoder(feat, frame_clip=fc, frame_start=fs, hop=hop)      # and through the column-sharing indirection
+    assert torch.equal(z0, z2)
+
+
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
 def test_gemm_variants_agree(eng, golden, variant):
     """The alternative GEMM data paths (register-direct MT 4 / MT 2, LDS-DMA, split-bf16 x3, 256-tile,
