@@ -8,13 +8,16 @@
 // every 128-byte line of the 7.3 GB output is then written twice, partially, by different kernels -- a
 // read-modify-write at the memory side, 7.9 ms per 20,352 frames for 2.7 ms of matrix work.  Here one workgroup owns
 // 128 frames x 32 triangles and computes BOTH parts (per wave: 32 frames; 6 scale tiles + 3 rotat tiles of 32x32), so
-// all stores to a line leave the same wave within a microsecond and merge in that XCD's L2 into full-line writes.
+// a wave owns complete output rows: it transposes them through LDS and writes 1,152 contiguous bytes per frame with
+// 16-byte stores.
 // Operands come straight from global memory as K4 quads (register-direct, no LDS): the coefficient quads of the wave's
-// 32 frames and the basis quads of its columns, requested one k-block ahead in two alternating register sets.  The four
+// 32 frames and the basis quads of its columns, requested two k-blocks ahead in three rotating register sets.  The four
 // waves of a workgroup read the same basis slab (L1 hits); frame blocks of one triangle block are dispatched together,
 // so the slab (147 KB) stays in L2.
 #include "common.h"
 #include "kernels.h"
+
+#define WAVE_LDS_FENCE() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
 namespace {
 
@@ -22,7 +25,9 @@ template <int NT>   // NT column tiles of 32: 6 for the scale basis (group 6), 3
 __device__ __forceinline__ void pca_part(const float4 *__restrict__ coef, int64_t ldc, const float4 *__restrict__ basis, int64_t ldb,
                                          int nkb, int h, f32x16 (&acc)[1][NT]) {
     // lane: A row = frame (coef already offset to this lane's frame), B column = basis already offset to tile 0's column
-    float4 a0[1], b0[NT], a1[1], b1[NT];
+    // requests run TWO k-blocks ahead in three rotating register sets: the rotat part has only 12 MFMAs (768 cycles) per
+    // k-block, less than an L2 round trip
+    float4 a0[1], b0[NT], a1[1], b1[NT], a2[1], b2[NT];
 #define PCA_LOAD(kb, A, B)                                                    \
     {                                                                         \
         const int64_t kq = 2 * (kb) + h;                                      \
@@ -30,43 +35,41 @@ __device__ __forceinline__ void pca_part(const float4 *__restrict__ coef, int64_
         _Pragma("unroll") for (int t = 0; t < NT; ++t) B[t] = basis[kq * ldb + 32 * t]; \
     }
     PCA_LOAD(0, a0, b0)
+    PCA_LOAD(1, a1, b1)
 #pragma unroll 1
-    for (int kb = 0; kb < nkb; kb += 2) {      // nkb is even (12 or 24)
-        PCA_LOAD(kb + 1, a1, b1)
+    for (int kb = 0; kb < nkb; kb += 3) {      // nkb is a multiple of 3 (12 or 24); late requests wrap to k-block 0 and are dropped
+        PCA_LOAD(kb + 2 < nkb ? kb + 2 : 0, a2, b2)
         __builtin_amdgcn_sched_barrier(0);
         mfma_block<1, NT>(acc, a0, b0);
-        const int kn = kb + 2 < nkb ? kb + 2 : 0;   // branch-free; the last request is dropped
-        PCA_LOAD(kn, a0, b0)
+        PCA_LOAD(kb + 3 < nkb ? kb + 3 : 0, a0, b0)
         __builtin_amdgcn_sched_barrier(0);
         mfma_block<1, NT>(acc, a1, b1);
+        PCA_LOAD(kb + 4 < nkb ? kb + 4 : 0, a1, b1)
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block<1, NT>(acc, a2, b2);
     }
 #undef PCA_LOAD
 }
 
+constexpr int PCA_ROW = 292;   // floats per staged row: 288 used; 4 * 292 mod 32 = 16 keeps the two lane halves on different LDS banks
+
+// accumulator rows 8g + 4h + e of pass g -> LDS rows 4h + e, triangle-interleaved columns; + mean
 template <int NT, int GROUP, int OFF>
-__device__ __forceinline__ void pca_store(const PcaArgs &a, const f32x16 (&acc)[1][NT], const float *__restrict__ mean, int64_t col0,
-                                          int64_t cols, int64_t frame0, int h, int l31) {
+__device__ __forceinline__ void pca_stage(float *__restrict__ sRow, const f32x16 (&acc)[1][NT], const float *__restrict__ mean,
+                                          int64_t col0, int64_t cols, int g, int h, int l31) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int64_t q = col0 + 32 * t + l31;
-        if (q >= cols) continue;
-        const float m = mean[q];
-        const int64_t o = (q / GROUP) * 9 + OFF + q % GROUP;
+        const int ql = 32 * t + l31;                       // column inside this workgroup's slice of the basis
+        const int64_t q = col0 + ql;
+        const float m = q < cols ? mean[q] : 0.f;
+        const int o = (ql / GROUP) * 9 + OFF + ql % GROUP; // position inside the 288-float row segment
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int64_t n = frame0 + 8 * g + 4 * h + e;
-#ifdef SDFA_PCA_NOSTORE   /* timing experiment only: matrix work without the output stream */
-                if (n < a.N && acc[0][t][4 * g + e] == 12345.678f) a.out[n * a.out_dim + o] = m;
-#else
-                if (n < a.N) a.out[n * a.out_dim + o] = acc[0][t][4 * g + e] + m;
-#endif
-            }
+        for (int e = 0; e < 4; ++e) sRow[(4 * h + e) * PCA_ROW + o] = acc[0][t][4 * g + e] + m;
     }
 }
 
 __global__ __launch_bounds__(256, 2) void pca_dgrad_kernel(PcaArgs a) {
+    __shared__ float sOut[4][8 * PCA_ROW];                // per wave: 8 output rows x 288 floats, staged for 16-byte stores
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int64_t nfb = a.Nc / 128;                       // frame blocks: fastest-varying, so a basis slab is reused from L2
@@ -75,25 +78,35 @@ __global__ __launch_bounds__(256, 2) void pca_dgrad_kernel(PcaArgs a) {
     if (frame0 >= a.N) return;
 
     const float4 *__restrict__ coef = reinterpret_cast<const float4 *>(a.coef) + frame0 + l31;   // K4 [288/4][Nc]: scale rows 0..95, rotat 96..287
-    {
-        f32x16 acc[1][6];
+    f32x16 accs[1][6], accr[1][3];
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+    for (int t = 0; t < 6; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][t][r] = 0.f;
-        const int64_t col0 = tb * 192;
-        pca_part<6>(coef, a.Nc, reinterpret_cast<const float4 *>(a.basis_s) + col0 + l31, a.ld_s, 12, h, acc);
-        pca_store<6, 6, 0>(a, acc, a.mean_s, col0, a.cols_s, frame0, h, l31);
-    }
-    {
-        f32x16 acc[1][3];
+        for (int r = 0; r < 16; ++r) accs[0][t][r] = 0.f;
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][t][r] = 0.f;
-        const int64_t col0 = tb * 96;
-        pca_part<3>(coef + 24 * a.Nc, a.Nc, reinterpret_cast<const float4 *>(a.basis_r) + col0 + l31, a.ld_r, 24, h, acc);
-        pca_store<3, 3, 6>(a, acc, a.mean_r, col0, a.cols_r, frame0, h, l31);
+        for (int r = 0; r < 16; ++r) accr[0][t][r] = 0.f;
+    pca_part<6>(coef, a.Nc, reinterpret_cast<const float4 *>(a.basis_s) + tb * 192 + l31, a.ld_s, 12, h, accs);
+    pca_part<3>(coef + 24 * a.Nc, a.Nc, reinterpret_cast<const float4 *>(a.basis_r) + tb * 96 + l31, a.ld_r, 24, h, accr);
+
+    // epilogue: four passes of 8 frames; the wave transposes its (8 x 288) block through LDS and writes whole rows with
+    // 16-byte stores (1,152 contiguous bytes per frame) instead of 4-byte stores strided 6-of-9 / 3-of-9
+    float *sRow = sOut[wave];
+    const int64_t ocol0 = tb * 288, orow_valid = a.out_dim - ocol0;     // floats of this triangle block that exist (216 in the last one)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {            // unrolled: g indexes accumulator registers
+        pca_stage<6, 6, 0>(sRow, accs, a.mean_s, tb * 192, a.cols_s, g, h, l31);
+        pca_stage<3, 3, 6>(sRow, accr, a.mean_r, tb * 96, a.cols_r, g, h, l31);
+        WAVE_LDS_FENCE()
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int idx = i * 64 + lane, r = idx / 72, c4 = idx % 72;     // row-local mapping r = 4h' + e  <->  frame 8g + 4h' + e
+            const int64_t n = frame0 + 8 * g + r;
+            if (n < a.N && 4 * c4 < orow_valid)
+                *reinterpret_cast<float4 *>(a.out + n * a.out_dim + ocol0 + 4 * c4) = *reinterpret_cast<const float4 *>(sRow + r * PCA_ROW + 4 * c4);
+        }
+        WAVE_LDS_FENCE()
     }
 }
 
