@@ -178,20 +178,26 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(FrontendConsts c, 
     // ---- Savitzky-Golay deltas (edges replicate the first / last interior value) + (T,F,C) store
     const float c2[9] = {28.f / 462.f, 7.f / 462.f, -8.f / 462.f, -17.f / 462.f, -20.f / 462.f,
                          -17.f / 462.f, -8.f / 462.f, 7.f / 462.f, 28.f / 462.f};
-    float *dst = out + frame * (64 * 128 * 3);
-    for (int idx = tid; idx < 64 * 128; idx += FE_THREADS) {
-        const int t = idx >> 7, f = idx & 127;
+    // a thread takes 4 consecutive frequency bins of one time step: 12 output floats = three 16-byte stores
+    float4 *dst = reinterpret_cast<float4 *>(out + frame * (64 * 128 * 3));
+    for (int i4 = tid; i4 < 64 * 128 / 4; i4 += FE_THREADS) {
+        const int t = i4 >> 5, f0 = (i4 & 31) * 4;
         const int tc = t < 4 ? 4 : (t > 59 ? 59 : t);
-        float d1 = 0.f, d2 = 0.f;
+        float m[4], d1[4], d2[4];
 #pragma unroll
-        for (int j = -4; j <= 4; ++j) {
-            const float mv = sMel[tc + j][f];
-            d1 += (float)j * (1.0f / 60.0f) * mv;
-            d2 += c2[j + 4] * mv;
+        for (int q = 0; q < 4; ++q) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = -4; j <= 4; ++j) {
+                const float mv = sMel[tc + j][f0 + q];
+                s1 += (float)j * (1.0f / 60.0f) * mv;
+                s2 += c2[j + 4] * mv;
+            }
+            m[q] = sMel[t][f0 + q]; d1[q] = s1; d2[q] = s2;
         }
-        dst[idx * 3 + 0] = sMel[t][f];
-        dst[idx * 3 + 1] = d1;
-        dst[idx * 3 + 2] = d2;
+        dst[i4 * 3 + 0] = make_float4(m[0], d1[0], d2[0], m[1]);
+        dst[i4 * 3 + 1] = make_float4(d1[1], d2[1], m[2], d1[2]);
+        dst[i4 * 3 + 2] = make_float4(d2[2], m[3], d1[3], d2[3]);
     }
 }
 
