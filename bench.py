@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--head", choices=["dgrad", "offsets"], default="dgrad", help="offsets = BASELINE configs[4] (VOCASET-style vertex offsets)")
     ap.add_argument("--ragged-seconds", default=None, metavar="LO,HI",
                     help="clip lengths uniform in [LO, HI] s instead of --seconds (a VOCASET-like stream of sentences)")
+    ap.add_argument("--frontend", choices=["gather", "direct"], default="gather",
+                    help="gather = each distinct STFT column once + per-frame gather (sdfa_mel_frontend_gather); direct = one FFT per window column")
     ap.add_argument("--precision", choices=["fp32", "bf16_attention", "bf16x3", "bf16"], default="fp32",
                     help="matrix instruction of the headline run (fp32 = the reference's arithmetic; the others are BASELINE configs[3] modes)")
     ap.add_argument("--no-mixed-precision", action="store_true", help="skip the extra split-bf16 (configs[3]) measurement")
@@ -174,7 +176,7 @@ def main():
     hop = int(0.008 * sr)
 
     def step(share=False):
-        eng.mel_frontend_device(pcm, clip_off, clip_len, frame_clip, frame_start, sr, out=feat)
+        eng.mel_frontend_device(pcm, clip_off, clip_len, frame_clip, frame_start, sr, out=feat, gather=(a.frontend == "gather"))
         for ci, f0 in enumerate(range(0, F, a.chunk)):
             f1 = min(F, f0 + a.chunk)
             if share:
@@ -229,7 +231,7 @@ def main():
         mixed = (dt_m, st_m, dt_ms)
     # front end: timed separately (same stream, HIP events), outside the headline region
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record(); eng.mel_frontend_device(pcm, clip_off, clip_len, frame_clip, frame_start, sr, out=feat); ev1.record()
+    ev0.record(); eng.mel_frontend_device(pcm, clip_off, clip_len, frame_clip, frame_start, sr, out=feat, gather=(a.frontend == "gather")); ev1.record()
     torch.cuda.synchronize()
     fe_ms = ev0.elapsed_time(ev1)
     stages["frontend"] = fe_ms

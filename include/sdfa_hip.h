@@ -86,6 +86,19 @@ int sdfa_mel_frontend(const float *d_pcm, const int64_t *d_clip_off, const int64
                       int32_t n_clips, const int32_t *d_frame_clip, const int64_t *d_frame_start,
                       int64_t n_frames, int sample_rate, float *d_audio_feat, void *stream);
 
+/* The same features through the "spectral gather" form: windows of one clip whose starts differ by whole hops contain
+ * the same STFT columns (only window column 0 is special: misc.py:17), so each DISTINCT column is transformed once
+ * (26 instead of 64 per frame at 60 fps / hop 8 ms) into a mel table, and every frame is then gathered from its 64
+ * table rows (delta filters + (T,F,C) store).  Same arguments as sdfa_mel_frontend plus scratch memory of
+ * sdfa_frontend_workspace_bytes(n_frames) bytes.  Results agree with sdfa_mel_frontend to float rounding (a column is
+ * transformed alone, as a half-size complex FFT, instead of sharing a complex FFT with its neighbour): a column's features
+ * depend on its samples only -- not on the batch it is in -- and are bit-identical in every frame that contains it. */
+int64_t sdfa_frontend_workspace_bytes(int64_t max_frames);
+int sdfa_mel_frontend_gather(const float *d_pcm, const int64_t *d_clip_off, const int64_t *d_clip_len,
+                             int32_t n_clips, const int32_t *d_frame_clip, const int64_t *d_frame_start,
+                             int64_t n_frames, int sample_rate, float *d_audio_feat, void *d_workspace,
+                             int64_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Model weights.  Tensors are given by the reference's state_dict names with the `_model.`
  * prefix stripped, AFTER weight-norm has been folded

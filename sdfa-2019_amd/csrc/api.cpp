@@ -327,6 +327,71 @@ int sdfa_mel_frontend(const float *d_pcm, const int64_t *d_clip_off, const int64
 }
 
 // ------------------------------------------------------------------------------------------------
+// "spectral gather" form of the front end (frontend.hip): share map over mel columns -> FFT + mel of the distinct
+// columns -> per-frame gather.  Scratch: the map (ints) followed by the mel table (128 floats per column, sized for the
+// case that nothing is shared).
+namespace {
+struct FeWs { int64_t Nc, Mc, map_ints, table_off, total; };
+FeWs fe_layout(int64_t n_frames) {
+    FeWs w;
+    w.Nc = round_up(n_frames, 128); w.Mc = 64 * w.Nc;
+    w.map_ints = round_up(16 + 2 * w.Nc + 5 * w.Mc + w.Mc / 1024 + 2, 64);
+    w.table_off = w.map_ints * 4;
+    w.total = w.table_off + w.Mc * 128 * 4;
+    return w;
+}
+}  // namespace
+
+int64_t sdfa_frontend_workspace_bytes(int64_t max_frames) {
+    if (max_frames <= 0) return fail(SDFA_EINVAL, "frontend_workspace_bytes: bad argument");
+    return fe_layout(max_frames).total;
+}
+
+int sdfa_mel_frontend_gather(const float *d_pcm, const int64_t *d_clip_off, const int64_t *d_clip_len, int32_t n_clips,
+                             const int32_t *d_frame_clip, const int64_t *d_frame_start, int64_t n_frames, int sample_rate,
+                             float *d_audio_feat, void *d_workspace, int64_t workspace_bytes, void *stream) {
+    if (n_frames == 0) return SDFA_OK;
+    if (!d_pcm || !d_clip_off || !d_clip_len || !d_frame_clip || !d_frame_start || !d_audio_feat || !d_workspace || n_clips <= 0 || n_frames < 0)
+        return fail(SDFA_EINVAL, "mel_frontend_gather: null pointer or bad count");
+    if (((uintptr_t)d_workspace | (uintptr_t)d_audio_feat) & 15) return fail(SDFA_EINVAL, "mel_frontend_gather: pointers must be 16-byte aligned");
+    const FeWs w = fe_layout(n_frames);
+    if (workspace_bytes < w.total)
+        return fail(SDFA_ENOSPACE, "mel_frontend_gather: workspace of %lld bytes, %lld needed for %lld frames", (long long)workspace_bytes,
+                    (long long)w.total, (long long)n_frames);
+    if (w.Mc >= (int64_t)1 << 31) return fail(SDFA_EINVAL, "mel_frontend_gather: too many frames in one call");
+    FrontendConsts c;
+    {
+        std::lock_guard<std::mutex> lk(g_fe_mu);
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        auto key = sample_rate * 64 + dev;
+        auto it = g_fe.find(key);
+        if (it == g_fe.end()) {
+            FrontendCache fc;
+            int rc = build_frontend(sample_rate, fc);
+            if (rc) return rc;
+            it = g_fe.emplace(key, fc).first;
+        }
+        c = it->second.c;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    int32_t *sh = reinterpret_cast<int32_t *>(d_workspace);
+    ShareArgs sa{};
+    sa.frame_clip = d_frame_clip; sa.frame_start = d_frame_start; sa.hop = c.hop;
+    sa.t_lo = 1; sa.t_hi = 63;          // every window column but the first (raw first sample) is a function of (clip, position)
+    sa.N = n_frames; sa.Nc = w.Nc; sa.Mc = w.Mc;
+    sa.counts = reinterpret_cast<int64_t *>(sh);
+    sa.prev = sh + 16; sa.shift = sa.prev + w.Nc;
+    sa.owner = sa.shift + w.Nc; sa.flag = sa.owner + w.Mc; sa.uid = sa.flag + w.Mc;
+    sa.col_src = sa.uid + w.Mc; sa.col_to_u = sa.col_src + w.Mc; sa.tile_sum = sa.col_to_u + w.Mc;
+    HIP_TRY(sdfa_launch_share_map(sa, s));
+    float *table = reinterpret_cast<float *>(reinterpret_cast<char *>(d_workspace) + w.table_off);
+    HIP_TRY(sdfa_launch_mel_columns(c, d_pcm, d_clip_off, d_clip_len, d_frame_clip, d_frame_start, sa.col_src, sa.counts, table, s));
+    HIP_TRY(sdfa_launch_gather_features(table, sa.col_to_u, n_frames, w.Nc, d_audio_feat, s));
+    return SDFA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 sdfa_model *sdfa_model_create(int head) {
     if (head != SDFA_HEAD_DGRAD && head != SDFA_HEAD_OFFSETS) { fail(SDFA_EINVAL, "unknown head %d", head); return nullptr; }
     auto *m = new sdfa_model();
@@ -733,6 +798,7 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
             int32_t *sh = reinterpret_cast<int32_t *>(ws + w.SH);
             ShareArgs sa{};
             sa.frame_clip = d_frame_clip + f0; sa.frame_start = d_frame_start + f0; sa.hop = hop;
+            sa.t_lo = 6; sa.t_hi = 58;      // feature columns: see share.hip
             sa.N = N; sa.Nc = Nc; sa.Mc = Mc;
             sa.counts = reinterpret_cast<int64_t *>(sh);           // 16 ints reserved
             sa.prev = sh + 16; sa.shift = sa.prev + Nc;

@@ -31,70 +31,16 @@ __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(
 constexpr int FE_WAVES = 8, FE_THREADS = 64 * FE_WAVES;
 #define WAVE_SYNC() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
+// One wave: complex FFT of a column pair (stage-0 butterfly inputs in v: column A in .x, column B in .y), untangled power
+// spectra, sparse mel gather, dB, normalise, clamp.  Returns mel[col][bb] for band = lane + 64 * bb.  Everything stays in
+// the wave's own LDS buffer `buf`, so only wavefront-scope fences separate the stages.
 template <int WIN>
-__global__ __launch_bounds__(FE_THREADS) void frontend_kernel(FrontendConsts c, const float *__restrict__ pcm,
-                                                       const int64_t *__restrict__ clip_off,
-                                                       const int64_t *__restrict__ clip_len,
-                                                       const int32_t *__restrict__ frame_clip,
-                                                       const int64_t *__restrict__ frame_start, float *__restrict__ out) {
-    constexpr int HOP = WIN / 8, SLIDING = HOP * 63 + WIN, NB = 256, NR4 = WIN / 256;   // radix-4 butterflies per lane
+__device__ __forceinline__ void fft_pair_to_mel(float2 (&v)[WIN / 256][4], float2 *buf, const float2 *sTw, const int *sPtr, const int *sBin,
+                                                const float *sW, int lane, float (&mel)[2][2]) {
+    constexpr int NB = 256, NR4 = WIN / 256;
     constexpr bool HAS_R2 = (WIN == 512);
-    __shared__ float sY[SLIDING];
-    __shared__ float2 sFft[FE_WAVES][WIN];
-    __shared__ float2 sTw[WIN];
-    __shared__ float sHamm[WIN];
-    __shared__ float sMel[64][128];   // lanes walk the band index in every access: no padding needed
-    __shared__ int sPtr[132];
-    __shared__ int sBin[512];
-    __shared__ float sW[512];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t frame = blockIdx.x;
-    const int clip = frame_clip[frame];
-    const int64_t off = clip_off[clip], len = clip_len[clip], s0 = frame_start[frame];
-
-    for (int i = tid; i < WIN; i += FE_THREADS) { sTw[i] = c.twiddle[i]; sHamm[i] = c.hamm[i]; }
-    for (int i = tid; i < 129; i += FE_THREADS) sPtr[i] = c.mel_ptr[i];
-    for (int i = tid; i < c.nnz; i += FE_THREADS) { sBin[i] = c.mel_bin[i]; sW[i] = c.mel_w[i]; }
-    // window cut, zero pad, pre-emphasis (fp32, one rounding per op as numpy does)
-    for (int i = tid; i < SLIDING; i += FE_THREADS) {
-        const int64_t g = s0 + i;
-        float x = (g >= 0 && g < len) ? pcm[off + g] : 0.f;
-        float xm = (i > 0 && g - 1 >= 0 && g - 1 < len) ? pcm[off + g - 1] : 0.f;
-        sY[i] = (i == 0) ? x : __fsub_rn(x, __fmul_rn(0.65f, xm));
-    }
-    __syncthreads();
-
-    // STFT columns are transformed in PAIRS (one complex FFT = two real columns).  The pairing follows the ABSOLUTE
-    // hop index of a column, floor(start / hop) + t, not its position in the window: two frames of one clip that
-    // contain the same column (starts a whole number of hops apart) then give it the same partner, so their mel
-    // values -- and every interior feature column -- are bit-identical, which is what makes column sharing
-    // (share.hip) exact.  With an odd base the first and last column have no partner and run alone.
-    const int64_t hop_base = (s0 >= 0 ? s0 : s0 - (HOP - 1)) / HOP;         // floor division
-    const int odd = (int)(hop_base & 1);
-    const int njobs = 32 + odd;                                              // 32 pairs, or solo + 31 pairs + solo
-    float2 *buf = sFft[wave];
-    float *pw0 = reinterpret_cast<float *>(buf), *pw1 = pw0 + NB;   // power spectra of the two columns (bins < 256) reuse the wave's buffer
-    for (int it = 0; it < (36 + FE_WAVES - 1) / FE_WAVES; ++it) {   // up to 33 jobs over the waves
-        const int job = it * FE_WAVES + wave;
-        const bool live = job < njobs;
-        int t0 = 2 * job - odd, t1 = t0 + 1;                                 // columns in the real / imaginary part
-        if (!live) { t0 = 0; t1 = 1; }                                       // idle slot: harmless recomputation, results dropped
-        const bool has0 = t0 >= 0, has1 = t1 <= 63;
-        const float *ya = sY + (has0 ? t0 : 0) * HOP, *yb = sY + (has1 ? t1 : 63) * HOP;
-        const float ga = has0 ? 1.f : 0.f, gb = has1 ? 1.f : 0.f;
-        float2 v[NR4][4];
-        // ---- stage 0 (Ns = 1) straight from the windowed signal
-#pragma unroll
-        for (int b = 0; b < NR4; ++b) {
-            const int j = lane + 64 * b;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int nidx = j + r * (WIN / 4);
-                const float w = sHamm[nidx];
-                v[b][r] = make_float2(ga * (w * ya[nidx]), gb * (w * yb[nidx]));
-            }
-        }
+    float *pw0 = reinterpret_cast<float *>(buf), *pw1 = pw0 + NB;   // power spectra of the two columns (bins < 256) reuse the buffer
+    {
         int Ns = 1;
 #pragma unroll
         for (int stage = 0; stage < (HAS_R2 ? 4 : 5); ++stage) {
@@ -169,10 +115,167 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(FrontendConsts c, 
                 for (int e = sPtr[band]; e < sPtr[band + 1]; ++e) m += sW[e] * pw[sBin[e]];
                 float db = __fmul_rn(10.0f, log10f(fmaxf(m, 1.1920929e-07f)));
                 float nv = __fdiv_rn(__fadd_rn(__fsub_rn(db, 20.0f), 80.0f), 80.0f);
-                const int tt = col ? t1 : t0;
-                if (live && tt >= 0 && tt <= 63) sMel[tt][band] = fminf(fmaxf(nv, 0.f), 1.f);
+                mel[col][bb] = fminf(fmaxf(nv, 0.f), 1.f);
             }
         WAVE_SYNC()
+    }
+}
+
+// One wave, ONE real column: the WIN-point real FFT as a complex FFT of M = WIN/2 points on z[n] = y[2n] + i y[2n+1],
+// then X[k] = E[k] + W_WIN^k O[k] with E, O the even / odd half spectra recovered from Z[k] and conj Z[M-k].  No second
+// column shares the transform, so the result is a function of the column's samples alone -- whichever batch, chunk or
+// neighbour it is computed with.  v: stage-0 butterfly inputs (.x = even sample, .y = odd sample, windowed).
+template <int WIN>
+__device__ __forceinline__ void fft_real_to_mel(float2 (&v)[WIN / 512][4], float2 *buf, const float2 *sTw, const int *sPtr, const int *sBin,
+                                                const float *sW, int lane, float (&mel)[2]) {
+    constexpr int M = WIN / 2, NR4 = M / 256;
+    constexpr bool HAS_R2 = (M == 512);            // 512 = 4^4 * 2, 256 = 4^4
+    float *pw = reinterpret_cast<float *>(buf);    // power spectrum (bins < 256) reuses the buffer
+    int Ns = 1;
+#pragma unroll
+    for (int stage = 0; stage < 4; ++stage) {
+        if (stage > 0) {
+#pragma unroll
+            for (int b = 0; b < NR4; ++b) {
+                const int j = lane + 64 * b, k = j & (Ns - 1);
+                const int tstep = k * (M / (4 * Ns));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float2 x = buf[j + r * (M / 4)];
+                    v[b][r] = (r == 0) ? x : cmul(x, sTw[2 * ((tstep * r) & (M - 1))]);     // W_M^m = W_WIN^(2m)
+                }
+            }
+            WAVE_SYNC()
+        }
+#pragma unroll
+        for (int b = 0; b < NR4; ++b) {
+            const int j = lane + 64 * b, k = j & (Ns - 1);
+            const int j0 = (j - k) * 4 + k;
+            float2 a0 = cadd(v[b][0], v[b][2]), a1 = csub(v[b][0], v[b][2]);
+            float2 a2 = cadd(v[b][1], v[b][3]), d = csub(v[b][1], v[b][3]);
+            float2 a3 = make_float2(d.y, -d.x);   // (-i) * d
+            buf[j0] = cadd(a0, a2);
+            buf[j0 + Ns] = cadd(a1, a3);
+            buf[j0 + 2 * Ns] = csub(a0, a2);
+            buf[j0 + 3 * Ns] = csub(a1, a3);
+        }
+        WAVE_SYNC()
+        Ns *= 4;
+    }
+    if (HAS_R2) {   // final radix-2 stage, Ns = 256
+        float2 u[4][2];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = lane + 64 * b;
+            u[b][0] = buf[j];
+            u[b][1] = cmul(buf[j + M / 2], sTw[2 * j]);
+        }
+        WAVE_SYNC()
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = lane + 64 * b;
+            buf[j] = cadd(u[b][0], u[b][1]);
+            buf[j + M / 2] = csub(u[b][0], u[b][1]);
+        }
+        WAVE_SYNC()
+    }
+    float p[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = lane + 64 * i;                                       // bins 0..255 (only those below 3.6 kHz are used)
+        const float2 zk = buf[k & (M - 1)], zn = buf[(M - k) & (M - 1)];
+        const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));     // E = (Z[k] + conj Z[M-k]) / 2
+        const float2 o = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));    // O = (Z[k] - conj Z[M-k]) / (2i)
+        const float2 x = cadd(e, cmul(o, sTw[k]));                                    // X[k] = E + W_WIN^k O
+        p[i] = __fadd_rn(__fmul_rn(x.x, x.x), __fmul_rn(x.y, x.y));
+    }
+    WAVE_SYNC()
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pw[lane + 64 * i] = p[i];
+    WAVE_SYNC()
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+        const int band = lane + 64 * bb;
+        float m = 0.f;
+        for (int e = sPtr[band]; e < sPtr[band + 1]; ++e) m += sW[e] * pw[sBin[e]];
+        float db = __fmul_rn(10.0f, log10f(fmaxf(m, 1.1920929e-07f)));
+        float nv = __fdiv_rn(__fadd_rn(__fsub_rn(db, 20.0f), 80.0f), 80.0f);
+        mel[bb] = fminf(fmaxf(nv, 0.f), 1.f);
+    }
+    WAVE_SYNC()
+}
+
+template <int WIN>
+__global__ __launch_bounds__(FE_THREADS) void frontend_kernel(FrontendConsts c, const float *__restrict__ pcm,
+                                                       const int64_t *__restrict__ clip_off,
+                                                       const int64_t *__restrict__ clip_len,
+                                                       const int32_t *__restrict__ frame_clip,
+                                                       const int64_t *__restrict__ frame_start, float *__restrict__ out) {
+    constexpr int HOP = WIN / 8, SLIDING = HOP * 63 + WIN, NR4 = WIN / 256;   // radix-4 butterflies per lane
+    __shared__ float sY[SLIDING];
+    __shared__ float2 sFft[FE_WAVES][WIN];
+    __shared__ float2 sTw[WIN];
+    __shared__ float sHamm[WIN];
+    __shared__ float sMel[64][128];   // lanes walk the band index in every access: no padding needed
+    __shared__ int sPtr[132];
+    __shared__ int sBin[512];
+    __shared__ float sW[512];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t frame = blockIdx.x;
+    const int clip = frame_clip[frame];
+    const int64_t off = clip_off[clip], len = clip_len[clip], s0 = frame_start[frame];
+
+    for (int i = tid; i < WIN; i += FE_THREADS) { sTw[i] = c.twiddle[i]; sHamm[i] = c.hamm[i]; }
+    for (int i = tid; i < 129; i += FE_THREADS) sPtr[i] = c.mel_ptr[i];
+    for (int i = tid; i < c.nnz; i += FE_THREADS) { sBin[i] = c.mel_bin[i]; sW[i] = c.mel_w[i]; }
+    // window cut, zero pad, pre-emphasis (fp32, one rounding per op as numpy does)
+    for (int i = tid; i < SLIDING; i += FE_THREADS) {
+        const int64_t g = s0 + i;
+        float x = (g >= 0 && g < len) ? pcm[off + g] : 0.f;
+        float xm = (i > 0 && g - 1 >= 0 && g - 1 < len) ? pcm[off + g - 1] : 0.f;
+        sY[i] = (i == 0) ? x : __fsub_rn(x, __fmul_rn(0.65f, xm));
+    }
+    __syncthreads();
+
+    // STFT columns are transformed in PAIRS (one complex FFT = two real columns).  The pairing follows the ABSOLUTE
+    // hop index of a column, floor(start / hop) + t, not its position in the window: two frames of one clip that
+    // contain the same column (starts a whole number of hops apart) then give it the same partner, so their mel
+    // values -- and every interior feature column -- are bit-identical, which is what makes column sharing
+    // (share.hip) exact.  With an odd base the first and last column have no partner and run alone.
+    const int64_t hop_base = (s0 >= 0 ? s0 : s0 - (HOP - 1)) / HOP;         // floor division
+    const int odd = (int)(hop_base & 1);
+    const int njobs = 32 + odd;                                              // 32 pairs, or solo + 31 pairs + solo
+    float2 *buf = sFft[wave];
+    for (int it = 0; it < (36 + FE_WAVES - 1) / FE_WAVES; ++it) {   // up to 33 jobs over the waves
+        const int job = it * FE_WAVES + wave;
+        const bool live = job < njobs;
+        int t0 = 2 * job - odd, t1 = t0 + 1;                                 // columns in the real / imaginary part
+        if (!live) { t0 = 0; t1 = 1; }                                       // idle slot: harmless recomputation, results dropped
+        const bool has0 = t0 >= 0, has1 = t1 <= 63;
+        const float *ya = sY + (has0 ? t0 : 0) * HOP, *yb = sY + (has1 ? t1 : 63) * HOP;
+        const float ga = has0 ? 1.f : 0.f, gb = has1 ? 1.f : 0.f;
+        float2 v[NR4][4];
+        // ---- stage 0 (Ns = 1) straight from the windowed signal
+#pragma unroll
+        for (int b = 0; b < NR4; ++b) {
+            const int j = lane + 64 * b;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nidx = j + r * (WIN / 4);
+                const float w = sHamm[nidx];
+                v[b][r] = make_float2(ga * (w * ya[nidx]), gb * (w * yb[nidx]));
+            }
+        }
+        float mel[2][2];
+        fft_pair_to_mel<WIN>(v, buf, sTw, sPtr, sBin, sW, lane, mel);
+#pragma unroll
+        for (int col = 0; col < 2; ++col)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const int tt = col ? t1 : t0;
+                if (live && tt >= 0 && tt <= 63) sMel[tt][lane + 64 * bb] = mel[col][bb];
+            }
     }
     __syncthreads();   // mel image complete
     // ---- Savitzky-Golay deltas (edges replicate the first / last interior value) + (T,F,C) store
@@ -181,6 +284,103 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(FrontendConsts c, 
     // a thread takes 4 consecutive frequency bins of one time step: 12 output floats = three 16-byte stores
     float4 *dst = reinterpret_cast<float4 *>(out + frame * (64 * 128 * 3));
     for (int i4 = tid; i4 < 64 * 128 / 4; i4 += FE_THREADS) {
+        const int t = i4 >> 5, f0 = (i4 & 31) * 4;
+        const int tc = t < 4 ? 4 : (t > 59 ? 59 : t);
+        float m[4], d1[4], d2[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = -4; j <= 4; ++j) {
+                const float mv = sMel[tc + j][f0 + q];
+                s1 += (float)j * (1.0f / 60.0f) * mv;
+                s2 += c2[j + 4] * mv;
+            }
+            m[q] = sMel[t][f0 + q]; d1[q] = s1; d2[q] = s2;
+        }
+        dst[i4 * 3 + 0] = make_float4(m[0], d1[0], d2[0], m[1]);
+        dst[i4 * 3 + 1] = make_float4(d1[1], d2[1], m[2], d1[2]);
+        dst[i4 * 3 + 2] = make_float4(d2[2], m[3], d1[3], d2[3]);
+    }
+}
+
+// ----------------------------------------------------------------------------- "spectral gather" form
+// Windows of one clip whose starts differ by whole hops contain the same STFT columns (at 60 fps / 16 kHz every 12th
+// frame, 25 hops apart): only window column 0 is special (its first sample is not pre-emphasised, misc.py:17).  The share
+// map (share.hip, t in 1..63) lists every DISTINCT column once -- 26 new ones per frame instead of 64 -- and
+//   mel_columns_kernel      transforms those (one column per wave as a half-size complex FFT, samples read straight from
+//                           the clip with the pre-emphasis applied on the fly) into a mel table  float[distinct][128];
+//   gather_features_kernel  builds each frame from its 64 table rows: mel image in LDS, delta filters, (T,F,C) store --
+//                           32 KB read (mostly L2) + 98 KB written per frame: the HBM-bound scan SURVEY 8(d) describes.
+constexpr int MC_WAVES = 8;
+
+template <int WIN>
+__global__ __launch_bounds__(64 * MC_WAVES) void mel_columns_kernel(FrontendConsts c, const float *__restrict__ pcm,
+                                                                    const int64_t *__restrict__ clip_off, const int64_t *__restrict__ clip_len,
+                                                                    const int32_t *__restrict__ frame_clip, const int64_t *__restrict__ frame_start,
+                                                                    const int32_t *__restrict__ col_src, const int64_t *__restrict__ n_distinct,
+                                                                    float *__restrict__ mel_table) {
+    constexpr int HOP = WIN / 8, M = WIN / 2, NR4 = M / 256;
+    __shared__ float2 sFft[MC_WAVES][M];
+    __shared__ float2 sTw[WIN];
+    __shared__ float sHamm[WIN];
+    __shared__ int sPtr[132];
+    __shared__ int sBin[512];
+    __shared__ float sW[512];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < WIN; i += 64 * MC_WAVES) { sTw[i] = c.twiddle[i]; sHamm[i] = c.hamm[i]; }
+    for (int i = tid; i < 129; i += 64 * MC_WAVES) sPtr[i] = c.mel_ptr[i];
+    for (int i = tid; i < c.nnz; i += 64 * MC_WAVES) { sBin[i] = c.mel_bin[i]; sW[i] = c.mel_w[i]; }
+    __syncthreads();
+
+    const int64_t nd = *n_distinct;
+    float2 *buf = sFft[wave];
+    for (int64_t u = (int64_t)blockIdx.x * MC_WAVES + wave; u < nd; u += (int64_t)gridDim.x * MC_WAVES) {
+        // (frame, window column) of this distinct column -> clip and absolute sample position
+        const int row = col_src[u], n = row >> 6, t = row & 63, clip = frame_clip[n];
+        const float *x = pcm + clip_off[clip];
+        const int64_t len = clip_len[clip], p = frame_start[n] + (int64_t)t * HOP;
+        const bool raw0 = t == 0;                 // a window's very first sample is not pre-emphasised (misc.py:17)
+        float2 v[NR4][4];
+#pragma unroll
+        for (int b = 0; b < NR4; ++b) {
+            const int j = lane + 64 * b;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 2 * (j + r * (M / 4));                       // even sample of z[j + r M/4]
+                const int64_t g = p + i;
+                // zero-padded clip; pre-emphasis with one rounding per op (misc.py:8-17)
+                const float xm = (g - 1 >= 0 && g - 1 < len) ? x[g - 1] : 0.f;
+                const float x0 = (g >= 0 && g < len) ? x[g] : 0.f;
+                const float x1 = (g + 1 >= 0 && g + 1 < len) ? x[g + 1] : 0.f;
+                const float y0 = (raw0 && i == 0) ? x0 : __fsub_rn(x0, __fmul_rn(0.65f, xm));
+                const float y1 = __fsub_rn(x1, __fmul_rn(0.65f, x0));
+                v[b][r] = make_float2(sHamm[i] * y0, sHamm[i + 1] * y1);
+            }
+        }
+        float mel[2];
+        fft_real_to_mel<WIN>(v, buf, sTw, sPtr, sBin, sW, lane, mel);
+        mel_table[u * 128 + lane] = mel[0];
+        mel_table[u * 128 + 64 + lane] = mel[1];
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_features_kernel(const float4 *__restrict__ mel_table, const int32_t *__restrict__ col_to_u,
+                                                              int64_t Nc, float *__restrict__ out) {
+    __shared__ float sMel[64][128];
+    const int tid = threadIdx.x;
+    const int64_t frame = blockIdx.x;
+    for (int i4 = tid; i4 < 64 * 32; i4 += 256) {
+        const int t = i4 >> 5, f4 = i4 & 31;
+        const int64_t u = col_to_u[(int64_t)t * Nc + frame];
+        *reinterpret_cast<float4 *>(&sMel[t][4 * f4]) = mel_table[u * 32 + f4];
+    }
+    __syncthreads();
+    // Savitzky-Golay deltas (edges replicate the first / last interior value) + (T,F,C) store: as in frontend_kernel
+    const float c2[9] = {28.f / 462.f, 7.f / 462.f, -8.f / 462.f, -17.f / 462.f, -20.f / 462.f,
+                         -17.f / 462.f, -8.f / 462.f, 7.f / 462.f, 28.f / 462.f};
+    float4 *dst = reinterpret_cast<float4 *>(out + frame * (64 * 128 * 3));
+    for (int i4 = tid; i4 < 64 * 128 / 4; i4 += 256) {
         const int t = i4 >> 5, f0 = (i4 & 31) * 4;
         const int tc = t < 4 ? 4 : (t > 59 ? 59 : t);
         float m[4], d1[4], d2[4];
@@ -216,5 +416,29 @@ hipError_t sdfa_launch_frontend(const FrontendConsts &c, const float *pcm, const
                            frame_clip, frame_start, audio_feat);
     else
         return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t sdfa_launch_mel_columns(const FrontendConsts &c, const float *pcm, const int64_t *clip_off, const int64_t *clip_len,
+                                   const int32_t *frame_clip, const int64_t *frame_start, const int32_t *col_src,
+                                   const int64_t *n_distinct, float *mel_table, hipStream_t s) {
+    if (c.nnz > 512 || c.nbins_used > 256) return hipErrorInvalidValue;
+    const unsigned grid = 256 * 6;      // persistent waves: each takes column pairs round-robin until the device-side count runs out
+    if (c.win == 1024)
+        hipLaunchKernelGGL(mel_columns_kernel<1024>, dim3(grid), dim3(64 * MC_WAVES), 0, s, c, pcm, clip_off, clip_len, frame_clip,
+                           frame_start, col_src, n_distinct, mel_table);
+    else if (c.win == 512)
+        hipLaunchKernelGGL(mel_columns_kernel<512>, dim3(grid), dim3(64 * MC_WAVES), 0, s, c, pcm, clip_off, clip_len, frame_clip,
+                           frame_start, col_src, n_distinct, mel_table);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t sdfa_launch_gather_features(const float *mel_table, const int32_t *col_to_u, int64_t n_frames, int64_t Nc,
+                                       float *audio_feat, hipStream_t s) {
+    if (n_frames <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_features_kernel, dim3((unsigned)n_frames), dim3(256), 0, s, reinterpret_cast<const float4 *>(mel_table),
+                       col_to_u, Nc, audio_feat);
     return hipGetLastError();
 }

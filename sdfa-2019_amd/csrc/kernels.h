@@ -60,6 +60,13 @@ struct FrontendConsts {      // device pointers, built once per sample rate
 hipError_t sdfa_launch_frontend(const FrontendConsts &c, const float *pcm, const int64_t *clip_off,
                                 const int64_t *clip_len, const int32_t *frame_clip, const int64_t *frame_start,
                                 int64_t n_frames, float *audio_feat, hipStream_t s);
+// "spectral gather" form: mel columns of the DISTINCT STFT columns (col_src / n_distinct from the share map with
+// t in 1..63), then one gather + delta + store pass per frame
+hipError_t sdfa_launch_mel_columns(const FrontendConsts &c, const float *pcm, const int64_t *clip_off, const int64_t *clip_len,
+                                   const int32_t *frame_clip, const int64_t *frame_start, const int32_t *col_src,
+                                   const int64_t *n_distinct, float *mel_table, hipStream_t s);
+hipError_t sdfa_launch_gather_features(const float *mel_table, const int32_t *col_to_u, int64_t n_frames, int64_t Nc,
+                                       float *audio_feat, hipStream_t s);
 
 // ---- conv stack ----------------------------------------------------------------------------
 struct ConvArgs {
@@ -131,6 +138,7 @@ struct ShareArgs {
     const int32_t *frame_clip;   // [N] clip id of each frame of the chunk
     const int64_t *frame_start;  // [N] window start sample inside its clip
     int hop;
+    int t_lo, t_hi;              // window columns t_lo..t_hi are shareable between hop-aligned frames of a clip
     int64_t N, Nc, Mc;
     int32_t *prev, *shift;       // [Nc]
     int32_t *owner, *flag, *uid; // [Mc]

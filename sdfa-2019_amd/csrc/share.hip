@@ -13,9 +13,9 @@
 
 namespace {
 
-constexpr int T_LO = 6, T_HI = 58;
+// [a.t_lo, a.t_hi]: 6..58 for feature columns (above); 1..63 for mel columns (frontend.hip: only window column 0 differs)
 
-// prev[n] = nearest earlier frame of the same clip whose start differs by d whole hops, 1 <= d <= T_HI - T_LO
+// prev[n] = nearest earlier frame of the same clip whose start differs by d whole hops, 1 <= d <= t_hi - t_lo
 __global__ void share_prev_kernel(ShareArgs a) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= a.Nc) return;
@@ -28,7 +28,7 @@ __global__ void share_prev_kernel(ShareArgs a) {
             if (a.frame_clip[q] != clip) break;
             const int64_t diff = s - a.frame_start[q];
             if (diff <= 0) break;
-            if (diff > (int64_t)(T_HI - T_LO) * a.hop) break;
+            if (diff > (int64_t)(a.t_hi - a.t_lo) * a.hop) break;
             if (diff % a.hop == 0) { prev = (int)q; shift = (int)(diff / a.hop); break; }
         }
     }
@@ -43,11 +43,11 @@ __global__ void share_owner_kernel(ShareArgs a) {
     int64_t n = m % a.Nc;
     int t = (int)(m / a.Nc);
     if (n >= a.N) { a.owner[m] = -1; a.flag[m] = 0; return; }     // padding frame: never computed
-    while (t >= T_LO && t <= T_HI) {
+    while (t >= a.t_lo && t <= a.t_hi) {
         const int p = a.prev[n];
         if (p < 0) break;
         const int tt = t + a.shift[n];
-        if (tt > T_HI) break;
+        if (tt > a.t_hi) break;
         n = p; t = tt;
     }
     const int64_t o = (int64_t)t * a.Nc + n;

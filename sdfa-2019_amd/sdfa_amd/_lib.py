@@ -24,6 +24,8 @@ SYMBOLS = {
     "sdfa_last_error": (C.c_char_p, []),
     "sdfa_frame_index": (_i64, [_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _i64]),
     "sdfa_mel_frontend": (C.c_int, [_p, _p, _p, _i32, _p, _p, _i64, C.c_int, _p, _p]),
+    "sdfa_frontend_workspace_bytes": (_i64, [_i64]),
+    "sdfa_mel_frontend_gather": (C.c_int, [_p, _p, _p, _i32, _p, _p, _i64, C.c_int, _p, _p, _i64, _p]),
     "sdfa_model_create": (_p, [C.c_int]),
     "sdfa_model_destroy": (None, [_p]),
     "sdfa_model_set_tensor": (C.c_int, [_p, C.c_char_p, _p, _i64]),

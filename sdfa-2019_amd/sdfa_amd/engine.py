@@ -49,7 +49,7 @@ class FrontendOnly:
         torch.cuda.set_device(self.device)
 
     # ------------------------------------------------------------------ front end
-    def mel_frontend(self, clips, sr):
+    def mel_frontend(self, clips, sr, gather=True):
         """clips: list of 1-D float32 arrays/tensors in [-1,1].  Returns (audio_feat (F_total,64,128,3) cuda,
         per-clip tslists, per-clip frame counts)."""
         offs, lens, fclip, fstart, tslists, counts = [], [], [], [], [], []
@@ -66,16 +66,29 @@ class FrontendOnly:
         d_len = torch.tensor(lens, dtype=torch.int64, device=dev)
         d_fc = torch.from_numpy(np.concatenate(fclip)).to(dev)
         d_fs = torch.from_numpy(np.concatenate(fstart)).to(dev)
-        feat = self.mel_frontend_device(pcm, d_off, d_len, d_fc, d_fs, sr)
+        feat = self.mel_frontend_device(pcm, d_off, d_len, d_fc, d_fs, sr, gather=gather)
         self.last_frame_table = (d_fc, d_fs, frame_geometry(sr)[1])      # (clip, start, hop) for encoder(share)
         return feat, tslists, counts
 
-    def mel_frontend_device(self, pcm, clip_off, clip_len, frame_clip, frame_start, sr, out=None):
+    def mel_frontend_device(self, pcm, clip_off, clip_len, frame_clip, frame_start, sr, out=None, gather=True):
+        """gather=True: the "spectral gather" form (each distinct STFT column transformed once, frames gathered from the
+        mel table; needs scratch memory); gather=False: one FFT per window column (sdfa_mel_frontend)."""
         F = int(frame_clip.numel())
         if out is None:
             out = torch.empty((F,) + FEAT_SHAPE, dtype=torch.float32, device=self.device)
-        check(lib.sdfa_mel_frontend(_ptr(pcm), _ptr(clip_off), _ptr(clip_len), int(clip_off.numel()), _ptr(frame_clip),
-                                    _ptr(frame_start), F, int(sr), _ptr(out), _stream()))
+        if F == 0:
+            return out
+        if gather:
+            need = check(lib.sdfa_frontend_workspace_bytes(F))
+            ws = getattr(self, "_fe_ws", None)
+            if ws is None or ws.numel() < need:
+                self._fe_ws = None
+                self._fe_ws = ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            check(lib.sdfa_mel_frontend_gather(_ptr(pcm), _ptr(clip_off), _ptr(clip_len), int(clip_off.numel()), _ptr(frame_clip),
+                                               _ptr(frame_start), F, int(sr), _ptr(out), _ptr(ws), ws.numel(), _stream()))
+        else:
+            check(lib.sdfa_mel_frontend(_ptr(pcm), _ptr(clip_off), _ptr(clip_len), int(clip_off.numel()), _ptr(frame_clip),
+                                        _ptr(frame_start), F, int(sr), _ptr(out), _stream()))
         return out
 
 

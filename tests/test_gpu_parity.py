@@ -227,6 +227,33 @@ def test_error_paths(eng, synth_sd):
         Engine(bad)
 
 
+def test_gather_front_end_matches_the_per_window_front_end(eng):
+    """sdfa_mel_frontend_gather (each distinct STFT column once, frames gathered from the mel table) against
+    sdfa_mel_frontend (one FFT per window column): same features to float rounding, on ragged clips that include an
+    all-zero clip, a clip of exactly one window and clips whose starts are not hop-aligned with each other."""
+    sr = 16000
+    clips = [synth.make_pcm(0, 2 * sr), np.zeros(12000, np.float32), synth.make_pcm(22, 9088), synth.make_pcm(21, 30011, "speechlike"),
+             synth.make_pcm(23, 20000, "sweep")]
+    a, ts_a, counts = eng.mel_frontend(clips, sr, gather=True)
+    b, ts_b, _ = eng.mel_frontend(clips, sr, gather=False)
+    assert ts_a == ts_b and a.shape == b.shape
+    # a column shares its complex FFT with another one; with a different partner the rounding noise it receives changes:
+    # a few 1e-6 on broadband clips, up to 1e-4 on the log-mel of near-silent bands of the sine sweep (same class as the
+    # sweep tolerance against the fp64-FFT oracle)
+    off = np.r_[0, np.cumsum(counts)]
+    d = (a - b).abs()
+    assert float(d[:off[4]].max()) <= 2e-5 and float(d[off[4]:].max()) <= 2e-4
+    n0 = counts[0]
+    assert not bool(a[n0:n0 + counts[1]].any())         # the zero clip stays exactly zero
+    # a column shared by two frames of a clip is bit-identical in both (frames 12 apart are 25 hops apart at 60 fps / 16 kHz)
+    assert torch.equal(a[20, 30:60, :, 0], a[32, 5:35, :, 0])
+    for srate in (8000,):
+        c8 = [synth.make_pcm(1, 2 * srate), synth.make_pcm(2, 4544 + 100, "speechlike")]
+        x, _, _ = eng.mel_frontend(c8, srate, gather=True)
+        y, _, _ = eng.mel_frontend(c8, srate, gather=False)
+        assert float((x - y).abs().max()) <= 2e-5
+
+
 def test_fused_conv_stack_is_bitwise_the_two_kernel_path(eng, synth_sd, golden):
     """conv123_kernel (product) vs conv1_pool + conv23 (kept for the debug taps, used by `eng`): same arithmetic per
     element, so z must be identical bit for bit -- on a ragged batch that leaves a partial column tile."""
