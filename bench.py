@@ -100,21 +100,27 @@ def cpu_baseline(sr, seconds, eng, state_dict, head):
         out, *_ = eng.forward(feat, torch.full((feat.shape[0],), 2, dtype=torch.int64))
         return float(np.abs(out.cpu().numpy() - ref).max()), bool(tslists[0] == list(ts))
 
-    return dict(value=round(frames / spent, 2), unit="frames/s", cores=int(cores), kind="port",
+    return dict(value=round(frames / spent, 2), unit="frames/s", cores=int(cores), nproc=int(os.cpu_count() or 0),
+                affinity_cpus=len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None, kind="port",
                 sample=f"{clips} clip(s) x {seconds:g} s @ {sr} Hz = {frames} frames in {spent:.1f} s; oracle/torch_oracle.py = the reference "
-                       f"path on torch {torch.__version__} CPU operators (fp32, batches of 100 frames), {cores} threads"), gpu_err
+                       f"path on torch {torch.__version__} CPU operators (fp32, batches of 100 frames); cores = the {cores} threads used "
+                       f"(fastest of a scan), nproc = logical CPUs the host exposes"), gpu_err
 
 
 def traffic_from_profile(frames_per_launch):
-    """HBM bytes per freq_lstm_kernel launch from the committed rocprofv3 PMC passes (profiles/r01_pmc: FETCH_SIZE and
-    WRITE_SIZE in KiB for a launch over 8192 frames), scaled to this run's frames per launch.  Counters cannot be
-    read inside the benchmark itself."""
+    """HBM bytes per freq_lstm_kernel launch from the newest committed rocprofv3 PMC passes (profiles/r*_pmc/
+    freq_lstm_traffic.json, written by profiles/pmc_summary.py: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950), scaled to this run's frames per launch.  Counters cannot be
+    read inside the benchmark itself.  Returns (traffic bytes, algorithmic bytes, source) or (None, None, None)."""
+    import glob
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc", "freq_lstm_traffic.json")) as f:
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc", "freq_lstm_traffic.json")))[-1]
+        with open(path) as f:
             t = json.load(f)
-        return round((t["fetch_kib"] + t["write_kib"]) * 1024.0 / t["frames"] * frames_per_launch)
+        k = frames_per_launch / t["frames"]
+        return round(t["traffic_bytes"] * k), round(t["algorithmic_bytes"] * k), os.path.relpath(path, ROOT)
     except Exception:
-        return None
+        return None, None, None
 
 
 def main():
@@ -164,6 +170,7 @@ def main():
     frame_clip = torch.repeat_interleave(torch.arange(C, dtype=torch.int32, device=dev), torch.tensor(counts, device=dev))
     frame_start = torch.from_numpy(np.concatenate([tables[L] for L in lengths])).to(dev)
     spk = torch.full((F,), 2, dtype=torch.int64, device=dev)          # speaker "m1"
+    eng.check_speaker_ids(spk)                                         # once, outside the timed region (a host sync)
     feat = torch.empty((F, 64, 128, 3), dtype=torch.float32, device=dev)
     width = eng.out_dim if a.gather != "coef" else eng.coef_dim
     gatherer = None
@@ -177,17 +184,16 @@ def main():
 
     def step(share=False):
         eng.mel_frontend_device(pcm, clip_off, clip_len, frame_clip, frame_start, sr, out=feat, gather=(a.frontend == "gather"))
-        for ci, f0 in enumerate(range(0, F, a.chunk)):
-            f1 = min(F, f0 + a.chunk)
+        def compute(f0, f1):
             if share:
                 z, _ = eng.encoder(feat[f0:f1], want_align=False, frame_clip=frame_clip[f0:f1], frame_start=frame_start[f0:f1], hop=hop)
             else:
                 z, _ = eng.encoder(feat[f0:f1], want_align=False)
-            coef, o = eng.regress(z, spk[f0:f1], want_coef=(a.gather == "coef"), out=out[f0:f1])
-            if gatherer is not None:
-                gatherer.gather_chunk(o if a.gather == "dgrad" else coef, ci)
-        if gatherer is not None:
-            gatherer.finish()
+            coef, o = eng.regress(z, spk[f0:f1], want_coef=(a.gather == "coef"), out=out[f0:f1], check_ids=False)
+            return o if a.gather == "dgrad" else coef
+
+        # every rank issues the SAME number of collectives, also when shards are ragged (sdfa_amd/dist.py: run_chunks)
+        sdist.run_chunks(F, a.chunk, gatherer, compute)
 
     def fence():
         if world > 1:
@@ -242,6 +248,7 @@ def main():
         lstm_ms_per_launch = stages["freq_lstm"] / n_chunks
         flop_per_launch = FLOP_FREQ_LSTM_PER_FRAME * (F / n_chunks)
         achieved = flop_per_launch / (lstm_ms_per_launch * 1e-3) / 1e12
+        traffic, traffic_alg, traffic_src = traffic_from_profile(F / n_chunks)
         res = {
             "metric": "animation frames/s/node (10 s@16 kHz clips); max|Δdgrad| vs CPU ref",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -256,8 +263,8 @@ def main():
                        "gather": a.gather if world > 1 else "none (1 GPU)", "weights": "synthetic seed 1234"},
             "roofline": {"kernel": "freq_lstm_kernel", "bound": "mfma", "achieved": round(achieved, 2),
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                         "traffic": traffic_from_profile(F / n_chunks), "launch_ms": round(lstm_ms_per_launch, 3),
-                         "flop_per_launch": flop_per_launch},
+                         "traffic": traffic, "traffic_algorithmic": traffic_alg, "traffic_source": traffic_src,
+                         "launch_ms": round(lstm_ms_per_launch, 3), "flop_per_launch": flop_per_launch},
             "model_tflops": round(value / world * FLOP_MODEL_PER_FRAME / 1e12, 2),
             "model_frac_of_fp32_mfma_peak": round(value / world * FLOP_MODEL_PER_FRAME / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
             "frontend": {"ms": round(fe_ms, 3), "frames_per_s": round(F / (fe_ms * 1e-3), 1),
@@ -293,7 +300,8 @@ def main():
                 if mixed is not None:
                     res["mixed_precision"]["max_abs_dgrad_err_vs_cpu_ref"] = gpu_err("bf16x3")[0]
             except Exception as e:      # the GPU measurement above stands on its own; say what went wrong with the CPU leg
-                res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": None, "kind": "port", "sample": f"failed: {e!r}"}
+                res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": None, "nproc": int(os.cpu_count() or 0), "kind": "port",
+                                       "sample": f"failed: {e!r}"}
             finally:
                 eng.set_precision(a.precision)
         print(json.dumps(res), flush=True)

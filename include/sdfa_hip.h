@@ -151,6 +151,7 @@ int64_t sdfa_workspace_bytes(const sdfa_model *m, int64_t max_frames);
  *   d_audio_feat  [n_frames][64][128][3] float32, contiguous
  *   d_z           out [n_frames][512]   attention context (z_audio)
  *   d_align       out [n_frames][64]    attention weights (align_dict["audio_encoder10"]); may be NULL
+ * Alignment: d_audio_feat, d_z and d_workspace 16 bytes, d_align 4 bytes (SDFA_EINVAL otherwise).
  * ---------------------------------------------------------------------------------------- */
 int sdfa_encoder_forward(const sdfa_model *m, const float *d_audio_feat, int64_t n_frames,
                          float *d_z, float *d_align, void *d_workspace, int64_t workspace_bytes,
@@ -179,6 +180,8 @@ int sdfa_encoder_forward_shared(const sdfa_model *m, const float *d_audio_feat, 
  *   d_speaker_id  [n_frames] int64, each in [0, 8)
  *   d_coef        out [n_frames][coef_dim]  PCA coefficients (scale then rotat); may be NULL
  *   d_out         out [n_frames][out_dim]   dgrad (9976 x [s0..s5 r0 r1 r2]) or offsets; may be NULL
+ * Alignment: d_z and d_workspace 16 bytes; d_out 16 bytes for the dgrad head (rows are written with 16-byte stores),
+ * 4 bytes for the offsets head; d_coef 4 bytes.  A misaligned pointer returns SDFA_EINVAL.
  * ---------------------------------------------------------------------------------------- */
 int sdfa_regress_forward(const sdfa_model *m, const float *d_z, const int64_t *d_speaker_id,
                          int64_t n_frames, float *d_coef, float *d_out, void *d_workspace,
@@ -187,7 +190,8 @@ int sdfa_regress_forward(const sdfa_model *m, const float *d_z, const int64_t *d
 /* Debug / parity taps: copy an intermediate activation of the LAST sdfa_encoder_forward call out of
  * the workspace in the reference's layout.  what: 0 = pool1 (n,32,64,64)  1 = conv3 (n,64,32,64)
  * 2 = freq-lstm (n,256,64)  3 = bilstm (n,64,512).  Used by tests only. */
-int sdfa_debug_set_option(const char *name, int value);     /* tuning switches for A/B runs, e.g. "gemm_variant" */
+int sdfa_debug_set_option(const char *name, int value);     /* tuning switches for A/B runs, e.g. "gemm_variant";
+                                                                THREAD-LOCAL: affects the calling thread's launches only */
 int sdfa_debug_keep_intermediates(sdfa_model *m, int on);   /* un-aliased workspace: call before sizing it */
 /* Number of distinct columns the LAST sdfa_encoder_forward_shared call evaluated for a chunk of n_frames frames
  * (synchronises the stream).  Tests / reporting only. */

@@ -2,14 +2,26 @@
 """Per-kernel, per-launch-shape table from the three separate rocprofv3 --pmc passes (MfmaUtil, FETCH_SIZE, WRITE_SIZE).
 
 Usage: python profiles/pmc_summary.py <dir with MfmaUtil_/FETCH_SIZE_/WRITE_SIZE_counter_collection.csv> [--traffic-json out.json]
-FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB on gfx950 (MI355X_MICROARCH.md, HBM section); the table shows
-them per launch.  --traffic-json writes the freq_lstm_kernel<false,..> figures of the 8192-frame launch, which
-bench.py scales to its frames per launch for `roofline.traffic`."""
+
+Counter handling follows MI355X_MICROARCH.md, section HBM:
+  * rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB on gfx950;
+  * FETCH_SIZE counts a 128-byte request as 64 bytes for wide (16 B per lane) streaming reads -- which is how every
+    kernel here reads its operands -- so the read column is DOUBLED ("read GB" = 2 x FETCH_SIZE);
+  * WRITE_SIZE is exact for 16-byte-per-lane streaming stores.
+Rows are keyed by (kernel symbol, grid size).  Collect the passes with `bench.py --no-column-sharing
+--no-mixed-precision`: a column-sharing run launches the SAME symbol and grid for the projection GEMMs but most of its
+workgroups exit at once (q_limit), and the two would be averaged into one row (the round-1 summary did that).
+
+--traffic-json writes the freq_lstm_kernel figures of the largest launch, which bench.py scales to its frames per launch
+for `roofline.traffic`.
+"""
 import collections
 import csv
 import json
 import os
 import sys
+
+FETCH_CORRECTION = 2.0      # MI355X_MICROARCH.md: "double it before comparing with a byte count"
 
 
 def load(path):
@@ -20,22 +32,37 @@ def load(path):
     return out
 
 
-d = sys.argv[1]
-M, F, W = (load(os.path.join(d, f"{c}_counter_collection.csv")) for c in ("MfmaUtil", "FETCH_SIZE", "WRITE_SIZE"))
-print(f"{'kernel':46s} {'grid':>10s} {'calls':>5s} {'MfmaUtil %':>10s} {'FETCH KiB':>12s} {'WRITE KiB':>12s}")
-for k in sorted(M, key=lambda k: -(sum(F.get(k, [0])) + sum(W.get(k, [0])))):
-    f, w, m = F.get(k, [0]), W.get(k, [0]), M[k]
-    if sum(f) + sum(w) < 1e5 or "at::" in k[0]:
-        continue
-    print(f"{k[0][:46]:46s} {k[1]:10d} {len(m):5d} {sum(m) / len(m):10.1f} {sum(f) / len(f):12.0f} {sum(w) / len(w):12.0f}")
-if "--traffic-json" in sys.argv:
-    key = next(k for k in M if k[0].startswith("freq_lstm_kernel<false") and k[1] == 8192 * 64 // 64 * 2 * 256)
-    fk, wk = sum(F[key]) / len(F[key]), sum(W[key]) / len(W[key])
-    alg = 8192 * (512 * 1024 + 2 * 1024 * 1024)
-    json.dump({"kernel": key[0], "frames": 8192, "fetch_kib": round(fk), "write_kib": round(wk),
-               "source": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r01_pmc/)",
-               "algorithmic_bytes": alg,
-               "note": f"algorithmic = conv3 activations read once (512 KiB/frame) + hidden states written once (2 MiB/frame) = "
-                       f"{alg / 1e9:.2f} GB; measured read {fk * 1024 / 1e9:.2f} GB + write {wk * 1024 / 1e9:.2f} GB "
-                       f"(the 0.77 MB of weights are served by L2)"},
-              open(sys.argv[sys.argv.index("--traffic-json") + 1], "w"), indent=1)
+def main():
+    d = sys.argv[1]
+    M, F, W = (load(os.path.join(d, f"{c}_counter_collection.csv")) for c in ("MfmaUtil", "FETCH_SIZE", "WRITE_SIZE"))
+    print(f"{'kernel':46s} {'grid':>10s} {'calls':>5s} {'MfmaUtil %':>10s} {'FETCH KiB raw':>14s} {'read GB (x2)':>13s} {'write GB':>10s}")
+    for k in sorted(M, key=lambda k: -(sum(F.get(k, [0])) + sum(W.get(k, [0])))):
+        f, w, m = F.get(k, [0]), W.get(k, [0]), M[k]
+        if sum(f) + sum(w) < 1e5 or "at::" in k[0]:
+            continue
+        fk, wk = sum(f) / len(f), sum(w) / len(w)
+        print(f"{k[0][:46]:46s} {k[1]:10d} {len(m):5d} {sum(m) / len(m):10.1f} {fk:14.0f} {fk * 1024 * FETCH_CORRECTION / 1e9:13.3f} {wk * 1024 / 1e9:10.3f}")
+    if "--traffic-json" in sys.argv:
+        key = max((k for k in M if k[0].startswith("freq_lstm_kernel<false")), key=lambda k: k[1])
+        frames = key[1] // 256 // 2          # grid = (frames * 64 columns / 64 per workgroup) * 2 directions * 256 threads
+        fk, wk = sum(F[key]) / len(F[key]), sum(W[key]) / len(W[key])
+        read_b, write_b = fk * 1024 * FETCH_CORRECTION, wk * 1024
+        alg_once = frames * (512 * 1024 + 2 * 1024 * 1024)
+        alg_two = frames * (2 * 512 * 1024 + 2 * 1024 * 1024)
+        json.dump({"kernel": key[0], "frames": frames, "fetch_kib_raw": round(fk), "write_kib": round(wk),
+                   "fetch_correction": FETCH_CORRECTION, "read_bytes": round(read_b), "write_bytes": round(write_b),
+                   "traffic_bytes": round(read_b + write_b),
+                   "source": f"separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes ({os.path.basename(os.path.normpath(d))}); FETCH_SIZE doubled per "
+                             "MI355X_MICROARCH.md (gfx950 tallies 128-byte read requests at 64 bytes)",
+                   "algorithmic_bytes": alg_once,
+                   "ratio_to_algorithmic": round((read_b + write_b) / alg_once, 4),
+                   "note": f"algorithmic = conv3 activations read once (512 KiB/frame) + hidden states written once (2 MiB/frame) = "
+                           f"{alg_once / 1e9:.2f} GB; measured read {read_b / 1e9:.2f} GB + write {write_b / 1e9:.2f} GB.  The forward and the "
+                           f"backward recurrence of a column tile each stream the tile's activations, in opposite row order, a "
+                           f"workgroup lifetime apart: read twice = {alg_two / 1e9:.2f} GB is what this kernel structure moves "
+                           f"(see DESIGN.md section 4)"},
+                  open(sys.argv[sys.argv.index("--traffic-json") + 1], "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

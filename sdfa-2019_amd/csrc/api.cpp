@@ -146,6 +146,7 @@ struct sdfa_model {
     // profiling
     struct Ev { std::string stage; hipEvent_t a, b; };
     mutable std::vector<Ev> events;
+    mutable std::mutex ev_mu;   // profiling appends events from const forward calls, possibly on several threads
 };
 
 namespace {
@@ -659,16 +660,20 @@ int64_t capacity(int64_t bytes, bool keep) {   // largest Nc (multiple of 128) w
 struct Prof {
     const sdfa_model *m;
     hipStream_t s;
+    hipEvent_t pending = nullptr;
     void begin(const char *stage) {
         if (!m->profile) return;
         sdfa_model::Ev e; e.stage = stage;
         (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b);
         (void)hipEventRecord(e.a, s);
+        pending = e.b;
+        std::lock_guard<std::mutex> lk(m->ev_mu);
         m->events.push_back(e);
     }
     void end() {
-        if (!m->profile) return;
-        (void)hipEventRecord(m->events.back().b, s);
+        if (!m->profile || !pending) return;
+        (void)hipEventRecord(pending, s);
+        pending = nullptr;
     }
 };
 
@@ -689,10 +694,12 @@ int64_t sdfa_workspace_bytes(const sdfa_model *m, int64_t max_frames) {
     return layout(round_up(max_frames, 128), m->keep).total * 4;
 }
 
-extern int g_sdfa_gemm_variant;
-int g_sdfa_freq_lstm_shape = 0;
-int g_sdfa_pca_unfused = 0;
-int g_sdfa_conv_unfused = 0;
+// A/B tuning switches: THREAD-LOCAL, so that a thread that flips one for an experiment cannot change what concurrent
+// callers on other threads launch (the header promises thread-safe concurrent use of the forward calls).
+extern thread_local int g_sdfa_gemm_variant;
+thread_local int g_sdfa_freq_lstm_shape = 0;
+thread_local int g_sdfa_pca_unfused = 0;
+thread_local int g_sdfa_conv_unfused = 0;
 int sdfa_debug_set_option(const char *name, int value) {
     if (name && !strcmp(name, "gemm_variant")) { g_sdfa_gemm_variant = value; return SDFA_OK; }
     if (name && !strcmp(name, "freq_lstm_shape")) { g_sdfa_freq_lstm_shape = value; return SDFA_OK; }
@@ -709,6 +716,7 @@ int sdfa_debug_keep_intermediates(sdfa_model *m, int on) {
 
 int sdfa_profile_enable(sdfa_model *m, int on) {
     if (!m) return fail(SDFA_EINVAL, "null model");
+    std::lock_guard<std::mutex> lk(m->ev_mu);
     m->profile = on != 0;
     for (auto &e : m->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     m->events.clear();
@@ -719,6 +727,7 @@ float sdfa_profile_ms(const sdfa_model *m, const char *stage) {
     if (!m || !stage) return (float)fail(SDFA_EINVAL, "profile_ms: bad argument");
     float total = 0.f;
     bool any = false;
+    std::lock_guard<std::mutex> lk(m->ev_mu);
     for (auto &e : m->events)
         if (e.stage == stage) {
             float ms = 0.f;
@@ -777,6 +786,7 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
     if (n_frames == 0) return SDFA_OK;
     if (!d_audio_feat || !d_z || !d_workspace || n_frames < 0) return fail(SDFA_EINVAL, "encoder_forward: bad argument");
     if (((uintptr_t)d_workspace | (uintptr_t)d_audio_feat | (uintptr_t)d_z) & 15) return fail(SDFA_EINVAL, "encoder_forward: pointers must be 16-byte aligned");
+    if ((uintptr_t)d_align & 3) return fail(SDFA_EINVAL, "encoder_forward: d_align must be 4-byte aligned");
     const int64_t cap = capacity(workspace_bytes, m->keep);
     if (cap < 128) return fail(SDFA_ENOSPACE, "encoder_forward: workspace of %lld bytes holds no 128-frame chunk", (long long)workspace_bytes);
     hipStream_t s = (hipStream_t)stream;
@@ -878,6 +888,9 @@ int sdfa_regress_forward(const sdfa_model *m, const float *d_z, const int64_t *d
     if (n_frames == 0) return SDFA_OK;
     if (!d_z || !d_speaker_id || !d_workspace || n_frames < 0) return fail(SDFA_EINVAL, "regress_forward: bad argument");
     if (((uintptr_t)d_workspace | (uintptr_t)d_z) & 15) return fail(SDFA_EINVAL, "regress_forward: pointers must be 16-byte aligned");
+    // the fused dgrad expansion writes whole rows with 16-byte stores (pca.hip); rows are 359,136 B apart, so the base decides
+    if (m->head == SDFA_HEAD_DGRAD && d_out && ((uintptr_t)d_out & 15)) return fail(SDFA_EINVAL, "regress_forward: d_out must be 16-byte aligned for the dgrad head");
+    if (((uintptr_t)d_out | (uintptr_t)d_coef) & 3) return fail(SDFA_EINVAL, "regress_forward: output pointers must be 4-byte aligned");
     const int64_t cap = capacity(workspace_bytes, m->keep);
     if (cap < 128) return fail(SDFA_ENOSPACE, "regress_forward: workspace too small");
     hipStream_t s = (hipStream_t)stream;

@@ -747,7 +747,7 @@ extern "C" int sdfa_debug_read_stamps(unsigned long long *out, int reset) {
 }
 #endif
 
-int g_sdfa_gemm_variant = 0;   // 0 = LDS-tiled (default), 1/2 = register-direct (MT 4 / 2), 3 = LDS-tiled fed by LDS-DMA (all fp32, within 2 % of each other); 4 = split-bf16 x3 (opt-in, not exact fp32)
+thread_local int g_sdfa_gemm_variant = 0;   // 0 = LDS-tiled (default), 1/2 = register-direct (MT 4 / 2), 3 = LDS-tiled fed by LDS-DMA (all fp32, within 2 % of each other); 4 = split-bf16 x3 (opt-in, not exact fp32)
 
 template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
 hipError_t launch_any(const GemmArgs &a, hipStream_t s) {

@@ -69,8 +69,10 @@ __global__ __launch_bounds__(256, WGS) void freq_lstm_kernel(FreqLstmArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    const int dir = blockIdx.x & 1;
-    const int64_t m0 = (int64_t)(blockIdx.x >> 1) * BT;
+    // block ids go round-robin over the 8 XCDs: the two directions of one column tile sit 8 ids apart, i.e. on the SAME
+    // XCD (same L2), and are dispatched in the same round
+    const int dir = (blockIdx.x >> 3) & 1;
+    const int64_t m0 = (int64_t)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) * BT;
     if (SHARED && m0 >= *a.col_limit) return;
 
     const float4 *__restrict__ X3 = reinterpret_cast<const float4 *>(a.X3);
@@ -271,8 +273,8 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_bf16_kernel(FreqLstmArgs a) 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    const int dir = blockIdx.x & 1;
-    const int64_t m0 = (int64_t)(blockIdx.x >> 1) * 64;
+    const int dir = (blockIdx.x >> 3) & 1;      // both directions of a column tile on one XCD (see freq_lstm_kernel)
+    const int64_t m0 = (int64_t)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) * 64;
     if (SHARED && m0 >= *a.col_limit) return;
 
     const float4 *__restrict__ X3 = reinterpret_cast<const float4 *>(a.X3);
@@ -610,7 +612,7 @@ extern "C" int sdfa_debug_read_lstm_stamps(unsigned long long *out, int reset) {
 }
 #endif
 
-extern int g_sdfa_freq_lstm_shape;   // api.cpp ("freq_lstm_shape" option): 0 = 64 columns x 2 workgroups/CU, 1 = 32 x 4, 2 = 32 x 3
+extern thread_local int g_sdfa_freq_lstm_shape;   // api.cpp ("freq_lstm_shape" option): 0 = 64 columns x 2 workgroups/CU, 1 = 32 x 4, 2 = 32 x 3
 
 template <bool SHARED>
 static hipError_t launch_freq(const FreqLstmArgs &a, hipStream_t s) {

@@ -31,6 +31,22 @@ def frame_counts_all(local_count, group=None):
     return [int(v.item()) for v in allc]
 
 
+def run_chunks(n_local, chunk, gatherer, compute):
+    """The per-step chunk loop of a rank: `compute(f0, f1)` produces this rank's output rows for its frames [f0, f1) and
+    the rows are handed to the gatherer chunk by chunk.  With a gatherer the loop runs over ITS chunk count -- the longest
+    shard's -- so that every rank issues the same number of collectives; a rank whose shard has ended joins the remaining
+    gathers with no rows of its own (ragged shards: different ranks hold different numbers of chunks)."""
+    n_local, chunk = int(n_local), int(chunk)
+    n = gatherer.n_chunks if gatherer is not None else (n_local + chunk - 1) // chunk
+    for ci in range(n):
+        f0, f1 = min(n_local, ci * chunk), min(n_local, (ci + 1) * chunk)
+        rows = compute(f0, f1) if f1 > f0 else None
+        if gatherer is not None:
+            gatherer.gather_chunk(rows, ci)
+    if gatherer is not None:
+        gatherer.finish()
+
+
 class FrameGatherer:
     """All-gather of per-frame rows, issued chunk by chunk so that the transfer of chunk i overlaps the
     compute of chunk i+1 (the collective is asynchronous on the process group's own stream).

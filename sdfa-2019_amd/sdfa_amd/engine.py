@@ -7,7 +7,7 @@ import torch
 
 from . import _lib
 from ._lib import lib, check
-from .weights import fold_state_dict, head_of
+from .weights import fold_state_dict, head_of, check_strict
 
 FPS = 60
 TS_DELTA_MS = 100
@@ -97,10 +97,12 @@ class Engine(FrontendOnly):
 
     PRECISIONS = {"fp32": 0, "bf16_attention": 1, "bf16x3": 2, "bf16": 3}      # include/sdfa_hip.h SDFA_PREC_*
 
-    def __init__(self, state_dict, device="cuda:0", max_frames=8192, debug_keep=False, precision="fp32"):
+    def __init__(self, state_dict, device="cuda:0", max_frames=8192, debug_keep=False, precision="fp32", strict=True):
         super().__init__(device)
         folded = fold_state_dict(state_dict)
         self.head = head_of(state_dict)
+        if strict:
+            check_strict(folded, self.head)
         self._m = lib.sdfa_model_create(_lib.HEAD_DGRAD if self.head == "dgrad" else _lib.HEAD_OFFSETS)
         if not self._m:
             raise _lib.SdfaError(-1, lib.sdfa_last_error().decode())
@@ -156,13 +158,25 @@ class Engine(FrontendOnly):
                                                   ws.numel(), _stream()))
         return z, align
 
-    def regress(self, z, speaker_id, want_coef=False, want_out=True, out=None):
+    @staticmethod
+    def check_speaker_ids(speaker_id):
+        """Raises what the reference's one_hot scatter_ raises for an id outside [0, 8) (saber/nn/functions.py:375-378).
+        The kernels take the ids as validated: call this (one aminmax, a host sync for a device tensor) on every id
+        tensor that reaches `regress`, or pass `check_ids=True` (the default)."""
+        if torch.is_tensor(speaker_id):
+            if speaker_id.numel() == 0:
+                return
+            lo, hi = (int(v) for v in torch.aminmax(speaker_id))
+        else:
+            lo = hi = int(speaker_id)
+        if lo < 0 or hi >= 8:
+            raise RuntimeError(f"index {hi if hi >= 8 else lo} is out of bounds for dimension 1 with size 8")
+
+    def regress(self, z, speaker_id, want_coef=False, want_out=True, out=None, check_ids=True):
         n = z.shape[0]
         z = z.contiguous()
-        if not speaker_id.is_cuda and speaker_id.numel():
-            lo, hi = int(speaker_id.min()), int(speaker_id.max())
-            if lo < 0 or hi >= 8:      # the reference's one_hot scatter_ raises on such an index (saber/nn/functions.py:375-378)
-                raise RuntimeError(f"index {hi if hi >= 8 else lo} is out of bounds for dimension 1 with size 8")
+        if check_ids:
+            self.check_speaker_ids(speaker_id)
         spk = speaker_id.to(device=self.device, dtype=torch.int64).contiguous()
         assert spk.numel() == n
         coef = torch.empty((n, self.coef_dim), dtype=torch.float32, device=self.device) if want_coef else None

@@ -50,6 +50,60 @@ def head_of(state):
     return "dgrad" if any("_scale_pca" in k for k in state) else "offsets"
 
 
+def expected_shapes(head):
+    """{folded tensor name: shape} of the chosen head -- SURVEY.md App. A.4 (speech_anime/config/model/{dgrad,offsets}.py).
+    This is what `load_state_dict(strict=True)` enforces in the reference (saber/trainer/manager/checkpoints.py:22-33)."""
+    e, o = "_audio_encoder._layers.", "_output_module."
+    t = {}
+    for idx, (co, ci, kf) in ((1, (32, 3, 3)), (3, (64, 32, 3)), (5, (64, 64, 1))):
+        t[f"{e}{idx}.weight"] = (co, ci, kf, 1)
+        t[f"{e}{idx}.bias"] = (co,)
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            t[f"{e}{idx}._ext_post_bn.{k}"] = (co,)
+    for suf in ("", "_reverse"):
+        t[f"{e}6._lstm.weight_ih_l0{suf}"] = (512, 64)
+        t[f"{e}6._lstm.weight_hh_l0{suf}"] = (512, 128)
+        t[f"{e}6._lstm.bias_ih_l0{suf}"] = (512,)
+        t[f"{e}6._lstm.bias_hh_l0{suf}"] = (512,)
+        t[f"{e}9.weight_ih_l0{suf}"] = (1024, 256)
+        t[f"{e}9.weight_hh_l0{suf}"] = (1024, 256)
+        t[f"{e}9.weight_ih_l1{suf}"] = (1024, 512)
+        t[f"{e}9.weight_hh_l1{suf}"] = (1024, 256)
+    t[f"{e}6._proj.weight"], t[f"{e}6._proj.bias"] = (256, 8192), (256,)
+    t[f"{e}10._conv_query.weight"] = (512, 512, 3)
+    t[f"{e}10.proj_key.weight"] = t[f"{e}10.proj_qry.weight"] = (128, 512)
+    t[f"{e}10.v.weight"], t[f"{e}10.b"] = (1, 128), (1, 1, 128)
+
+    def fc(key, p, k):
+        t[f"{o}{key}.weight"], t[f"{o}{key}.bias"] = (p, k), (p,)
+    fc("_layers.0", 512, 520)
+    if head == "dgrad":
+        for br, nco, rows in (("_scale", 85, 59856), ("_rotat", 180, 29928)):
+            fc(f"{br}_layers.0", 512, 520); fc(f"{br}_layers.1", 256, 512); fc(f"{br}_layers.2", nco, 256)
+            t[f"{o}{br}_pca.compT"], t[f"{o}{br}_pca.means"] = (rows, nco), (rows,)
+    else:
+        fc("_layers.1", 256, 512); fc("_layers.2", 59, 256)
+        t[f"{o}_pca.compT"], t[f"{o}_pca.means"] = (15069, 59), (15069,)
+    return t
+
+
+def check_strict(folded, head):
+    """Missing / unexpected keys and shape mismatches raise, with torch's load_state_dict wording."""
+    want = expected_shapes(head)
+    missing = sorted(k for k in want if k not in folded)
+    unexpected = sorted(k for k in folded if k not in want)
+    bad = [f"size mismatch for {k}: copying a param with shape {tuple(folded[k].shape)} from checkpoint, the shape in current model is {want[k]}."
+           for k in sorted(want) if k in folded and tuple(folded[k].shape) != tuple(want[k])]
+    msgs = []
+    if unexpected:
+        msgs.append("Unexpected key(s) in state_dict: " + ", ".join(f'"{k}"' for k in unexpected) + ".")
+    if missing:
+        msgs.append("Missing key(s) in state_dict: " + ", ".join(f'"{k}"' for k in missing) + ".")
+    msgs += bad
+    if msgs:
+        raise RuntimeError("Error(s) in loading state_dict for SpeechDrivenAnimation:\n\t" + "\n\t".join(msgs))
+
+
 def fold_state_dict(state):
     """{reference name: array} (weight_g/weight_v or plain weight) -> {name without '_model.': float32 array}."""
     out = {}

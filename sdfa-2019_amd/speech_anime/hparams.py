@@ -88,4 +88,34 @@ def configure(args):
     sr = hp["audio"]["sample_rate"]
     if sr not in (8000, 16000):
         raise ValueError(f"audio.sample_rate = {sr}: the MI355X front end supports 8000 and 16000 Hz")
+    check_compiled_in(hp)
     return _wrap(hp)
+
+
+# Front-end and frame-geometry values the kernels and sdfa_frame_index are built for (csrc/api.cpp build_frontend,
+# csrc/frontend.hip, sdfa_amd/engine.py).  A checkpoint's hparams.json that disagrees would run without error and give
+# wrong timestamps / features, so it is refused by name instead.
+_COMPILED_IN = {
+    "audio.mel.n_mels": 128, "audio.mel.win_size": 0.064, "audio.mel.hop_size": 0.008, "audio.mel.win_fn": "hamm",
+    "audio.mel.padding": False, "audio.mel.fmin": 50, "audio.mel.fmax": 3600, "audio.mel.ref_db": 20, "audio.mel.top_db": 80,
+    "audio.mel.normalize": True, "audio.mel.clip_normalized": True, "audio.mel.subtract_mean": False,
+    "audio.mel.preemphasis": 0.65, "audio.feature.name": "mel", "audio.feature.with_delta": True,
+    "audio.feature.sliding_window_frames": 64, "anime.fps": 60, "anime.feature.ts_delta": 100,
+    "model.speaker_embedding.using_onehot": True, "model.speaker_embedding.num_speakers": 8,
+}
+
+
+def check_compiled_in(hp):
+    for path, want in _COMPILED_IN.items():
+        node = hp
+        for k in path.split("."):
+            if not isinstance(node, dict) or k not in node:
+                node = None
+                break
+            node = node[k]
+        if node is None:
+            continue            # absent: the default (= compiled-in value) applies
+        same = (node == want) if isinstance(want, (str, bool)) else (isinstance(node, (int, float)) and abs(float(node) - float(want)) < 1e-9)
+        if not same:
+            raise ValueError(f"hparams.{path} = {node!r}: this build of the front end / frame geometry is compiled for {want!r}; "
+                             "a checkpoint trained with another value cannot be evaluated by it")

@@ -31,7 +31,7 @@ class SpeechDrivenAnimation:
         if head != want:
             raise RuntimeError(f"checkpoint holds a '{head}' output module but hparams.model.face_data_type = {self._face_type}")
         self._engine = Engine(state_dict, device=self.hp.get("device", "cuda:0") or "cuda:0",
-                              precision=self.hp.get("precision", "fp32") or "fp32")
+                              precision=self.hp.get("precision", "fp32") or "fp32", strict=strict)
         return self
 
     def eval(self):
@@ -148,6 +148,7 @@ class SaberSpeechDrivenAnimation:
         """`bs` is accepted for signature parity; frames are independent, so the engine batches by its own chunk size."""
         assert isinstance(speaker_id, (int, np.integer)), f"given index is {speaker_id}, {type(speaker_id)}"
         eng = self._model._engine
+        eng.check_speaker_ids(int(speaker_id))      # before any device work: ids >= num_speakers raise like one_hot's scatter_
         feat = feat_list if torch.is_tensor(feat_list) else torch.from_numpy(np.asarray(feat_list, np.float32))
         feat = feat.to(eng.device)
         n = feat.shape[0]

@@ -29,9 +29,11 @@ def _worker(rank, world, port, n_clips, frames_per_clip, width, chunk, q):
     local = torch.tensor(np.asarray(rows, np.float32).reshape(-1, width))
     counts = sd.frame_counts_all(local.shape[0])
     g = sd.FrameGatherer(counts, width, torch.float32, "cpu", chunk)
-    for i in range(g.n_chunks):
-        g.gather_chunk(local[i * chunk:(i + 1) * chunk], i)
-    g.finish()
+    calls = []
+    for step in range(2):       # two "steps" of bench.py's loop shape: a rank that skipped a collective would mispair here
+        g.buf.zero_()
+        sd.run_chunks(local.shape[0], chunk, g, lambda f0, f1: (calls.append((f0, f1)), local[f0:f1])[1])
+    assert all(f1 > f0 for f0, f1 in calls)
     out = g.gathered()
     per_rank = torch.cat(g.rows(1), 0)
     assert per_rank.shape[0] == counts[1]
@@ -40,7 +42,8 @@ def _worker(rank, world, port, n_clips, frames_per_clip, width, chunk, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("frames_per_clip", [[5, 5, 5, 5], [3, 9, 4, 1, 7]])
+# [9, 3]: rank 0 holds 3 chunks of 4 frames, rank 1 one -- different chunk counts per rank (the bench loop hung there)
+@pytest.mark.parametrize("frames_per_clip", [[5, 5, 5, 5], [3, 9, 4, 1, 7], [9, 3], [2, 11]])
 def test_sharded_gather_reassembles_clip_order(frames_per_clip):
     world, width, chunk = 2, 6, 4
     n_clips = len(frames_per_clip)
