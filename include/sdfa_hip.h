@@ -6,7 +6,9 @@
  * Every d_* pointer is DEVICE memory (hipMalloc'ed or owned by any allocator, e.g.
  * PyTorch's caching allocator); every h_* pointer is HOST memory.  `stream` is a
  * hipStream_t passed as void* (NULL = the default stream).  All device work is enqueued
- * on `stream` and the calls never synchronise.  Functions return 0 (or a non-negative
+ * on `stream` and the calls never synchronise (the constructors sdfa_model_finalize / sdfa_mesh_create* and the debug /
+ * profiling readers do).  A finalised model or mesh is read-only: the forward calls may be used concurrently from several
+ * threads on different streams with different workspaces.  Functions return 0 (or a non-negative
  * count) on success and a negative SDFA_E* code on failure; sdfa_last_error() returns
  * the message of the calling thread's last failure.
  *
@@ -212,7 +214,8 @@ float sdfa_profile_ms(const sdfa_model *m, const char *stage);
  * (deformation/cpp/src/pybind.cpp:13-33,101-117; deform_triangle_impl.hpp:8-140,215-310;
  * rotation/utils_rotation.cpp:33-49), called per video frame from speech_anime/viewer/frame.py:102-141.
  *
- * sdfa_mesh_create = set_target(verts, faces, cnsts, reg=1e-10) without triangle correspondences: builds the
+ * sdfa_mesh_create = set_target(verts, faces, cnsts, reg=1e-10) without triangle correspondences (with them:
+ * sdfa_mesh_create_corres below): builds the
  * per-triangle pseudo-inverse system over the free (un-constrained) vertices and factors it once (host, fp64).
  * sdfa_mesh_from_dgrad = get_mesh for n frames at once, constrained vertices pinned to their template positions
  * (what frame.py passes as vert_cnsts):
@@ -225,6 +228,67 @@ void       sdfa_mesh_destroy(sdfa_mesh *mesh);
 int64_t    sdfa_mesh_workspace_bytes(const sdfa_mesh *mesh, int64_t n_frames);
 int        sdfa_mesh_from_dgrad(const sdfa_mesh *mesh, const float *d_dgrad, int64_t n_frames, float *d_verts,
                                 void *d_workspace, int64_t workspace_bytes, void *stream);
+int64_t    sdfa_mesh_n_verts(const sdfa_mesh *mesh);
+int64_t    sdfa_mesh_n_src_tris(const sdfa_mesh *mesh);      /* 9-vectors per dgrad row */
+
+/* set_target WITH triangle correspondences -- retargeting to a template of another topology
+ * (evaluate.sh:28-41 `--mesh_tricorres`; speech_anime/viewer/frame.py:50-80 builds corr_count / corr_faces from the
+ * .tricorrs file; deform_triangle_impl.hpp:12-21,102,248-266).  Target triangle j contributes max(1, corr_count[j])
+ * equations; equation k takes the transform of SOURCE triangle corr_faces[k] (one filler entry per triangle with
+ * corr_count 0, whose equation is the identity).  h_corr_count NULL = no correspondences (then n_src_tris = n_tris).
+ *   h_corr_count [n_tris]   h_corr_faces [sum_j max(1, corr_count[j])], each < n_src_tris
+ *   n_src_tris   9-vectors per dgrad row handed to sdfa_mesh_from_dgrad* (9976 for the FLAME-topology model output) */
+sdfa_mesh *sdfa_mesh_create_corres(const float *h_verts, int64_t n_verts, const uint32_t *h_faces, int64_t n_tris,
+                                   const uint32_t *h_cnsts, int64_t n_cnsts, const uint32_t *h_corr_count,
+                                   const uint32_t *h_corr_faces, int64_t n_corr_faces, int64_t n_src_tris, double reg,
+                                   void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * NEXT ROW: frame-time resampling, saber.stream.seek
+ * (saber/data/stream/stream.py:20-46), called per video frame from speech_anime/model/model.py:204-212 with
+ * ts = i * 1000.0 / fps, i = 0 .. int(tslist[-1] * fps / 1000.0), right before frame_to_mesh.
+ *
+ * sdfa_seek_query_count: number of video frames of a clip whose last timestamp is last_timestamp_ms (host arithmetic).
+ * sdfa_seek_plan: for a batch of clips, one thread per query: float64 query time, binary search in the clip's
+ *   (ascending, int32 ms) timestamps, and the two float32 blend weights float32(a), float32(1 - a),
+ *   a = (t[m+1] - ts) / (t[m+1] - t[m]) in float64; before the first / after the last timestamp and on the last frame the
+ *   row is copied (src0 = src1, weights 1, 0).  Bit-exact.
+ *     d_tslist          concatenated timestamps of all clips (sdfa_frame_index)
+ *     d_clip_frame_off  [n_clips + 1] first animation frame (= row of the output matrix) of each clip
+ *     d_clip_query_off  [n_clips + 1] first query (video frame) of each clip; [n_clips] = n_queries
+ *     d_seek_src        out [n_queries][2] int64 global row indices    d_seek_w  out [n_queries][2] float32
+ * sdfa_seek_rows: out[q] = w0 * rows[src0] + w1 * rows[src1], three separately rounded float32 operations per element
+ *   (numpy's a * x + (1 - a) * y on float32 arrays) -- the rows evaluate() dumps as NNNNNN_dgrad.npy.
+ * sdfa_mesh_from_dgrad_seek: seek fused into the mesh solve -- every triangle's 9-vector is blended on the fly from the
+ *   two source rows (same three roundings), so the video-rate dgrad track is never materialised: d_dgrad stays the
+ *   animation-rate rows sdfa_regress_forward wrote, d_verts is [n_queries][n_verts][3].  Bit-identical to
+ *   sdfa_seek_rows followed by sdfa_mesh_from_dgrad.
+ * ---------------------------------------------------------------------------------------- */
+int64_t sdfa_seek_query_count(int32_t last_timestamp_ms, double fps);
+int     sdfa_seek_plan(const int32_t *d_tslist, const int64_t *d_clip_frame_off, const int64_t *d_clip_query_off,
+                       int32_t n_clips, double fps, int64_t n_queries, int64_t *d_seek_src, float *d_seek_w, void *stream);
+int     sdfa_seek_rows(const float *d_rows, int64_t row_width, const int64_t *d_seek_src, const float *d_seek_w,
+                       int64_t n_queries, float *d_out, void *stream);
+int     sdfa_mesh_from_dgrad_seek(const sdfa_mesh *mesh, const float *d_dgrad, const int64_t *d_seek_src,
+                                  const float *d_seek_w, int64_t n_queries, float *d_verts, void *d_workspace,
+                                  int64_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * NEXT ROW: audio ingest, sample-rate conversion.  Replaces
+ * librosa.resample(y, orig_sr, target_sr) [res_type "kaiser_best" -> resampy.resample] as the reference calls it at
+ * speech_anime/model/eval_utils.py:76-86 (file rate -> 44.1 kHz inside saber.audio.load, saber/data/audio/io.py:9-15,
+ * then 44.1 kHz -> hparams.audio.sample_rate).  Third-party arithmetic (librosa 0.8.0 / resampy 0.2.2, absent from the
+ * reference tree): restated from the published algorithm, PARITY UNPINNED (oracle/resample_oracle.py).
+ *   n_out = sdfa_resample_out_len(n_in, sr_orig, sr_new) = ceil(n_in * sr_new / sr_orig)   (librosa's fixed length)
+ *   d_workspace: sdfa_resample_workspace_bytes(...) bytes, 8-byte aligned.
+ * sdfa_resample uploads the per-sample time register from the host and SYNCHRONISES the stream once (ingest step).
+ * sdfa_resample_filter copies the half filter table (64 * 512 + 1 float64) to the host: tests compare it with scipy's.
+ * ---------------------------------------------------------------------------------------- */
+int64_t sdfa_resample_out_len(int64_t n_in, int sr_orig, int sr_new);
+int64_t sdfa_resample_workspace_bytes(int64_t n_in, int sr_orig, int sr_new);
+int     sdfa_resample_filter(double *h_half_window, int64_t cap);
+int     sdfa_resample(const float *d_in, int64_t n_in, int sr_orig, int sr_new, float *d_out, int64_t n_out,
+                      void *d_workspace, int64_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -8,25 +8,32 @@ import numpy as np
 
 
 class MeshOracle:
-    def __init__(self, verts, faces, cnsts, reg=1e-10):
+    def __init__(self, verts, faces, cnsts, reg=1e-10, corr_count=None, corr_faces=None):
         V = np.asarray(verts, np.float32).reshape(-1, 3)
         F = np.asarray(faces, np.int64).reshape(-1, 3)
         cn = np.asarray(cnsts, np.int64).reshape(-1)
         self.V, self.F, self.cn = V, F, cn
+        # triangle correspondences (:16-21,102): target triangle j contributes max(1, count[j]) equations
+        self.count = None if corr_count is None else np.asarray(corr_count, np.int64).reshape(-1)
+        self.corr_faces = None if corr_faces is None else np.asarray(corr_faces, np.int64).reshape(-1)
+        reps = np.ones(len(F), int) if self.count is None else np.maximum(1, self.count)
         free = np.setdiff1d(np.arange(len(V)), cn)
         col = -np.ones(len(V), int); col[free] = np.arange(len(free))
         ccol = -np.ones(len(V), int); ccol[cn] = np.arange(len(cn))
-        T = len(F)
-        A = np.zeros((3 * T, len(free))); Ar = np.zeros((3 * T, max(len(cn), 1)))
+        E = int(reps.sum())
+        A = np.zeros((3 * E, len(free))); Ar = np.zeros((3 * E, max(len(cn), 1)))
+        k = 0
         for j, (a, b, c) in enumerate(F):
             Va = np.stack([V[b] - V[a], V[c] - V[a]], 1).astype(np.float64)      # float32 subtraction, :96-97
             Q, R = np.linalg.qr(Va)                                              # :98-100
             U = np.linalg.inv(R) @ Q.T
-            for vi, coef in ((a, -U[0] - U[1]), (b, U[0]), (c, U[1])):           # :106-116
-                if col[vi] >= 0:
-                    A[3 * j:3 * j + 3, col[vi]] = coef
-                else:
-                    Ar[3 * j:3 * j + 3, ccol[vi]] = coef
+            for _ in range(reps[j]):                                             # :102-117
+                for vi, coef in ((a, -U[0] - U[1]), (b, U[0]), (c, U[1])):
+                    if col[vi] >= 0:
+                        A[3 * k:3 * k + 3, col[vi]] = coef
+                    else:
+                        Ar[3 * k:3 * k + 3, ccol[vi]] = coef
+                k += 1
         self.A, self.Ar, self.free = A, Ar, free
         self.AtA = A.T @ A + reg * np.eye(len(free))                             # :122-131
 
@@ -45,7 +52,17 @@ class MeshOracle:
 
     def get_mesh(self, dgrad):
         d = np.asarray(dgrad, np.float64).reshape(-1, 9)
-        M = np.concatenate([self.transform(x).T for x in d], 0)                  # transposed blocks, :243-247
+        if self.count is None:
+            M = np.concatenate([self.transform(x).T for x in d], 0)              # transposed blocks, :243-251
+        else:                                                                    # :252-267
+            blocks, fi = [], 0
+            for j in range(len(self.F)):
+                if self.count[j] > 0:
+                    for _ in range(self.count[j]):
+                        blocks.append(self.transform(d[self.corr_faces[fi]]).T); fi += 1
+                else:
+                    blocks.append(np.eye(3)); fi += 1
+            M = np.concatenate(blocks, 0)
         C = self.V[self.cn].astype(np.float64) if len(self.cn) else np.zeros((1, 3))
         rhs = self.A.T @ (M - self.Ar @ C)                                       # :282, :286
         X = np.linalg.solve(self.AtA, rhs)

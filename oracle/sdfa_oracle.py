@@ -336,3 +336,35 @@ def generate_animation(oracle, pcm, sr, speaker_id, batch=100):
         # reference's result is (F, 9976, 9) -- same bytes as (F, 89784).
         animes = animes.reshape(len(animes), -1, 9)
     return feats["tslist"], animes
+
+
+# ------------------------------------------------------------------------------------------------- next rows
+def seek(ts, timestamps, sequence):
+    """saber.stream.seek (saber/data/stream/stream.py:20-46) for ascending timestamps: the row at time `ts`, linearly
+    interpolated; rows are copied before the first / after the last timestamp and on the last frame."""
+    n = len(timestamps)
+    lo, hi = 0, n                       # :22-35 binary search for m with t[m] <= ts < t[m+1]
+    m = (lo + hi) // 2
+    while lo < hi:
+        m = (lo + hi) // 2
+        tm = timestamps[m]
+        tn = timestamps[m + 1] if m + 1 < n else ts + 1
+        if tm <= ts < tn:
+            break
+        if tm > ts:
+            hi = m
+        else:
+            lo = m + 1
+    if ts < timestamps[m] or ts > timestamps[-1] or m + 1 >= n:      # :37-42
+        return np.copy(sequence[m])
+    a = (timestamps[m + 1] - ts) / (timestamps[m + 1] - timestamps[m])   # :44-46 (python floats; float32 rows stay float32)
+    return a * sequence[m] + (1 - a) * sequence[m + 1]
+
+
+def seek_track(timestamps, sequence, fps, n_queries=None):
+    """The video-rate track evaluate() exports (speech_anime/model/model.py:204-212): query i at i * 1000.0 / fps,
+    i = 0 .. int(timestamps[-1] * fps / 1000.0)."""
+    if n_queries is None:
+        n_queries = int(timestamps[-1] * fps / 1000.0) + 1
+    ts = [int(t) for t in timestamps]
+    return np.stack([np.asarray(seek(i * 1000.0 / fps, ts, sequence)) for i in range(n_queries)])

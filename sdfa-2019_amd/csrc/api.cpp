@@ -984,17 +984,41 @@ int sdfa_debug_tap(const sdfa_model *m, int what, int64_t n_frames, float *d_dst
 // ================================================================================================
 struct sdfa_mesh {
     int n_verts = 0, n_tris = 0, n_free = 0, free_pad = 0;
+    int n_src_tris = 0;        // triangles per dgrad row (= n_tris unless triangle correspondences retarget another topology)
     void *blob = nullptr;
     const int *inc_ptr, *inc_tri, *vert_col;
-    const float *inc_coef, *tmpl, *inv_k4;
+    const float *inc_coef, *tmpl, *inv_k4, *reg_xt;
 };
 
 extern "C" {
 
 sdfa_mesh *sdfa_mesh_create(const float *h_verts, int64_t n_verts, const uint32_t *h_faces, int64_t n_tris,
                             const uint32_t *h_cnsts, int64_t n_cnsts, double reg, void *stream) {
-    if (!h_verts || !h_faces || n_verts <= 0 || n_tris <= 0 || n_cnsts < 0 || (n_cnsts && !h_cnsts)) {
+    return sdfa_mesh_create_corres(h_verts, n_verts, h_faces, n_tris, h_cnsts, n_cnsts, nullptr, nullptr, 0, n_tris, reg, stream);
+}
+
+sdfa_mesh *sdfa_mesh_create_corres(const float *h_verts, int64_t n_verts, const uint32_t *h_faces, int64_t n_tris,
+                                   const uint32_t *h_cnsts, int64_t n_cnsts, const uint32_t *h_corr_count,
+                                   const uint32_t *h_corr_faces, int64_t n_corr_faces, int64_t n_src_tris, double reg,
+                                   void *stream) {
+    if (!h_verts || !h_faces || n_verts <= 0 || n_tris <= 0 || n_cnsts < 0 || (n_cnsts && !h_cnsts) || n_src_tris <= 0) {
         fail(SDFA_EINVAL, "mesh_create: bad argument");
+        return nullptr;
+    }
+    // triangle correspondences (deform_triangle_impl.hpp:16-21,102,248-266): target triangle j contributes
+    // max(1, corr_count[j]) equations; equation k of a triangle with correspondences takes the transform of SOURCE triangle
+    // corr_faces[k] (corr_faces holds one filler entry for a triangle without any, viewer/frame.py:72-80), the others the identity
+    if (h_corr_count) {
+        int64_t neq = 0;
+        for (int64_t j = 0; j < n_tris; ++j) neq += std::max<int64_t>(1, h_corr_count[j]);
+        if (!h_corr_faces || n_corr_faces != neq) {
+            fail(SDFA_EINVAL, "mesh_create: corr_faces must hold %lld entries (sum of max(1, corr_count)), got %lld", (long long)neq, (long long)n_corr_faces);
+            return nullptr;
+        }
+        for (int64_t k = 0; k < neq; ++k)
+            if (h_corr_faces[k] >= (uint32_t)n_src_tris) { fail(SDFA_EINVAL, "mesh_create: corr_faces[%lld] out of range", (long long)k); return nullptr; }
+    } else if (n_src_tris != n_tris) {
+        fail(SDFA_EINVAL, "mesh_create: without correspondences the dgrad rows must have one 9-vector per template triangle");
         return nullptr;
     }
     // vertex -> free column (deform_triangle_impl.hpp:36-72: constrained vertices leave A for Ar)
@@ -1010,6 +1034,7 @@ sdfa_mesh *sdfa_mesh_create(const float *h_verts, int64_t n_verts, const uint32_
     // per-triangle U = pinv([v2-v1, v3-v1]) (2x3); A rows 3j..3j+2: v1 -> -U0-U1, v2 -> U0, v3 -> U1   (:81-118)
     std::vector<std::vector<std::pair<int, std::array<double, 3>>>> inc(nf);
     std::vector<double> AtA((size_t)nf * nf, 0.0);
+    int64_t eq = 0;   // running equation index (into corr_faces)
     for (int64_t j = 0; j < n_tris; ++j) {
         const uint32_t vi[3] = {h_faces[3 * j], h_faces[3 * j + 1], h_faces[3 * j + 2]};
         for (int k = 0; k < 3; ++k)
@@ -1028,15 +1053,18 @@ sdfa_mesh *sdfa_mesh_create(const float *h_verts, int64_t n_verts, const uint32_
             u1[k] = (-g12 * e1[k] + g11 * e2[k]) / det;
             c[0][k] = -u0[k] - u1[k]; c[1][k] = u0[k]; c[2][k] = u1[k];
         }
+        const int64_t ncor = h_corr_count ? h_corr_count[j] : 0, nrep = std::max<int64_t>(1, ncor);
         for (int a = 0; a < 3; ++a) {
             const int ca = col[vi[a]];
             if (ca < 0) continue;
-            inc[ca].push_back({(int)j, c[a]});
+            if (!h_corr_count) inc[ca].push_back({(int)j, c[a]});
+            else for (int64_t r = 0; r < ncor; ++r) inc[ca].push_back({(int)h_corr_faces[eq + r], c[a]});   // identity equations add nothing to the displacement rhs
             for (int b = 0; b < 3; ++b) {
                 const int cb = col[vi[b]];
-                if (cb >= 0) AtA[(size_t)ca * nf + cb] += c[a][0] * c[b][0] + c[a][1] * c[b][1] + c[a][2] * c[b][2];
+                if (cb >= 0) AtA[(size_t)ca * nf + cb] += (double)nrep * (c[a][0] * c[b][0] + c[a][1] * c[b][1] + c[a][2] * c[b][2]);
             }
         }
+        eq += nrep;
     }
     for (int i = 0; i < nf; ++i) AtA[(size_t)i * nf + i] += reg;   // :125-131
     // dense Cholesky A^T A = L L^T, then (A^T A)^-1 = L^-T L^-1, all in fp64
@@ -1068,7 +1096,8 @@ sdfa_mesh *sdfa_mesh_create(const float *h_verts, int64_t n_verts, const uint32_
     size_t nnz = 0;
     for (auto &v : inc) nnz += v.size();
     const size_t o_inv = 0, o_ptr = o_inv + (size_t)fp * fp, o_tri = o_ptr + round_up(nf + 1, 64), o_coef = o_tri + round_up(nnz, 64),
-                 o_col = o_coef + round_up(3 * nnz, 64), o_tm = o_col + round_up(n_verts, 64), total = o_tm + round_up(3 * n_verts, 64);
+                 o_col = o_coef + round_up(3 * nnz, 64), o_tm = o_col + round_up(n_verts, 64), o_rx = o_tm + round_up(3 * n_verts, 64),
+                 total = o_rx + round_up(3 * nf, 64);
     std::vector<float> hostf(total, 0.f);
     {   // Inv[i][j] = sum_k Li[k][i] Li[k][j], k >= max(i, j); transpose Li first for unit-stride inner loops
         std::vector<double> LiT((size_t)nf * nf);
@@ -1094,7 +1123,12 @@ sdfa_mesh *sdfa_mesh_create(const float *h_verts, int64_t n_verts, const uint32_
         }
     }
     hp[nf] = (int)p;
-    for (int64_t v = 0; v < n_verts; ++v) hc[v] = col[v];
+    for (int64_t v = 0; v < n_verts; ++v) {
+        hc[v] = col[v];
+        // the regulariser acts on the absolute position: (A^T A + reg) d = A^T (M - M_I) - reg x_template   (:125-131)
+        if (col[v] >= 0)
+            for (int k = 0; k < 3; ++k) hostf[o_rx + 3 * col[v] + k] = (float)(reg * (double)h_verts[3 * v + k]);
+    }
     memcpy(&hostf[o_tm], h_verts, (size_t)n_verts * 3 * 4);
     auto *m = new sdfa_mesh();
     if (hipMalloc(&m->blob, total * 4) != hipSuccess ||
@@ -1106,7 +1140,8 @@ sdfa_mesh *sdfa_mesh_create(const float *h_verts, int64_t n_verts, const uint32_
         return nullptr;
     }
     const float *d = (const float *)m->blob;
-    m->n_verts = (int)n_verts; m->n_tris = (int)n_tris; m->n_free = nf; m->free_pad = fp;
+    m->n_verts = (int)n_verts; m->n_tris = (int)n_tris; m->n_free = nf; m->free_pad = fp; m->n_src_tris = (int)n_src_tris;
+    m->reg_xt = d + o_rx;
     m->inv_k4 = d + o_inv; m->inc_ptr = (const int *)(d + o_ptr); m->inc_tri = (const int *)(d + o_tri);
     m->inc_coef = d + o_coef; m->vert_col = (const int *)(d + o_col); m->tmpl = d + o_tm;
     return m;
@@ -1123,17 +1158,19 @@ int64_t sdfa_mesh_workspace_bytes(const sdfa_mesh *m, int64_t n_frames) {
     return 2 * (int64_t)m->free_pad * round_up(3 * n_frames, 128) * 4;
 }
 
-int sdfa_mesh_from_dgrad(const sdfa_mesh *m, const float *d_dgrad, int64_t n_frames, float *d_verts, void *d_workspace,
-                         int64_t workspace_bytes, void *stream) {
-    if (!m) return fail(SDFA_EINVAL, "mesh_from_dgrad: null mesh");
+static int mesh_solve(const sdfa_mesh *m, const float *d_dgrad, const int64_t *d_src, const float *d_w, int64_t n_frames,
+                      float *d_verts, void *d_workspace, int64_t workspace_bytes, void *stream, const char *who) {
+    if (!m) return fail(SDFA_EINVAL, "%s: null mesh", who);
     if (n_frames == 0) return SDFA_OK;
-    if (!d_dgrad || !d_verts || !d_workspace || n_frames < 0) return fail(SDFA_EINVAL, "mesh_from_dgrad: bad argument");
-    if (workspace_bytes < sdfa_mesh_workspace_bytes(m, n_frames)) return fail(SDFA_ENOSPACE, "mesh_from_dgrad: workspace too small");
+    if (!d_dgrad || !d_verts || !d_workspace || n_frames < 0) return fail(SDFA_EINVAL, "%s: bad argument", who);
+    if ((uintptr_t)d_workspace & 15) return fail(SDFA_EINVAL, "%s: workspace must be 16-byte aligned", who);
+    if (workspace_bytes < sdfa_mesh_workspace_bytes(m, n_frames)) return fail(SDFA_ENOSPACE, "%s: workspace too small", who);
     hipStream_t s = (hipStream_t)stream;
     const int64_t ld = round_up(3 * n_frames, 128);
     float *rhs = (float *)d_workspace, *sol = rhs + (int64_t)m->free_pad * ld;
     MeshArgs a{};
     a.dgrad = d_dgrad; a.n_frames = n_frames; a.n_tris = m->n_tris; a.n_verts = m->n_verts; a.n_free = m->n_free; a.free_pad = m->free_pad;
+    a.n_src_tris = m->n_src_tris; a.seek_src = d_src; a.seek_w = d_w; a.reg_xt = m->reg_xt;
     a.inc_ptr = m->inc_ptr; a.inc_tri = m->inc_tri; a.inc_coef = m->inc_coef; a.vert_col = m->vert_col; a.tmpl = m->tmpl;
     a.rhs = rhs; a.sol = sol; a.verts = d_verts; a.ld = ld;
     HIP_TRY(hipMemsetAsync(rhs, 0, (size_t)m->free_pad * ld * 4, s));   // padding columns / rows feed the GEMM
@@ -1147,4 +1184,161 @@ int sdfa_mesh_from_dgrad(const sdfa_mesh *m, const float *d_dgrad, int64_t n_fra
     return SDFA_OK;
 }
 
+int sdfa_mesh_from_dgrad(const sdfa_mesh *m, const float *d_dgrad, int64_t n_frames, float *d_verts, void *d_workspace,
+                         int64_t workspace_bytes, void *stream) {
+    return mesh_solve(m, d_dgrad, nullptr, nullptr, n_frames, d_verts, d_workspace, workspace_bytes, stream, "mesh_from_dgrad");
+}
+
+int sdfa_mesh_from_dgrad_seek(const sdfa_mesh *m, const float *d_dgrad, const int64_t *d_seek_src, const float *d_seek_w,
+                              int64_t n_queries, float *d_verts, void *d_workspace, int64_t workspace_bytes, void *stream) {
+    if (!d_seek_src || !d_seek_w) return fail(SDFA_EINVAL, "mesh_from_dgrad_seek: seek plan missing");
+    return mesh_solve(m, d_dgrad, d_seek_src, d_seek_w, n_queries, d_verts, d_workspace, workspace_bytes, stream, "mesh_from_dgrad_seek");
+}
+
+int64_t sdfa_mesh_n_verts(const sdfa_mesh *m) { return m ? m->n_verts : fail(SDFA_EINVAL, "null mesh"); }
+int64_t sdfa_mesh_n_src_tris(const sdfa_mesh *m) { return m ? m->n_src_tris : fail(SDFA_EINVAL, "null mesh"); }
+
+// ------------------------------------------------------------------------------------------------
+// saber.stream.seek (saber/data/stream/stream.py:20-46) for the uniform video-rate queries of model.py:204-212
+int64_t sdfa_seek_query_count(int32_t last_timestamp_ms, double fps) {
+    // max_frame = int(tslist[-1] * fps / 1000.0); queries i = 0 .. max_frame          (model.py:205-207)
+    const double v = (double)last_timestamp_ms * fps / 1000.0;
+    const int64_t mf = (int64_t)v;      // int() truncates toward zero
+    return mf < 0 ? 0 : mf + 1;         // range(max_frame + 1) is empty for a negative max_frame
+}
+
+int sdfa_seek_plan(const int32_t *d_tslist, const int64_t *d_clip_frame_off, const int64_t *d_clip_query_off, int32_t n_clips,
+                   double fps, int64_t n_queries, int64_t *d_seek_src, float *d_seek_w, void *stream) {
+    if (n_queries == 0) return SDFA_OK;
+    if (!d_tslist || !d_clip_frame_off || !d_clip_query_off || !d_seek_src || !d_seek_w || n_clips <= 0 || n_queries < 0 || !(fps > 0))
+        return fail(SDFA_EINVAL, "seek_plan: bad argument");
+    HIP_TRY(sdfa_launch_seek_plan(d_tslist, d_clip_frame_off, d_clip_query_off, n_clips, fps, n_queries, d_seek_src, d_seek_w, (hipStream_t)stream));
+    return SDFA_OK;
+}
+
+int sdfa_seek_rows(const float *d_rows, int64_t row_width, const int64_t *d_seek_src, const float *d_seek_w, int64_t n_queries,
+                   float *d_out, void *stream) {
+    if (n_queries == 0) return SDFA_OK;
+    if (!d_rows || !d_seek_src || !d_seek_w || !d_out || row_width <= 0 || n_queries < 0) return fail(SDFA_EINVAL, "seek_rows: bad argument");
+    if (((uintptr_t)d_rows | (uintptr_t)d_out) & 3) return fail(SDFA_EINVAL, "seek_rows: pointers must be 4-byte aligned");
+    HIP_TRY(sdfa_launch_seek_rows(d_rows, row_width, d_seek_src, d_seek_w, n_queries, d_out, (hipStream_t)stream));
+    return SDFA_OK;
+}
+
 }  // extern "C"
+
+// ================================================================================================
+// next row: audio ingest -- kaiser_best resampling (resample.hip)
+// ================================================================================================
+namespace {
+
+double bessel_i0(double x) {   // modified Bessel function of the first kind, order 0: sum_k ((x/2)^k / k!)^2
+    const double q = 0.25 * x * x;
+    double term = 1.0, sum = 1.0;
+    for (int k = 1; k < 500; ++k) {
+        term *= q / ((double)k * (double)k);
+        sum += term;
+        if (term < sum * 1e-18) break;
+    }
+    return sum;
+}
+
+constexpr int RS_ZEROS = 64, RS_TABLE = 512;                       // resampy kaiser_best: num_zeros, 2**precision
+constexpr double RS_BETA = 14.769656459379492, RS_ROLLOFF = 0.9475937167399596;
+constexpr int64_t RS_NWIN = (int64_t)RS_ZEROS * RS_TABLE + 1;
+
+// right half of the Kaiser-windowed sinc (resampy/filters.py sinc_window with scipy.signal.kaiser)
+void kaiser_best_half(std::vector<double> &win) {
+    const int64_t n = RS_NWIN - 1;
+    win.resize(RS_NWIN);
+    const double i0b = bessel_i0(RS_BETA);
+    for (int64_t j = 0; j <= n; ++j) {
+        const double xz = RS_ROLLOFF * ((double)j / (double)RS_TABLE);                 // rolloff * linspace(0, 64, n + 1)[j]
+        const double py = M_PI * (xz == 0.0 ? 1.0e-20 : xz);                           // np.sinc
+        const double sinc = RS_ROLLOFF * (std::sin(py) / py);
+        const double r = (double)j / (double)n;                                        // (k - alpha) / alpha, k = n + j
+        const double taper = bessel_i0(RS_BETA * std::sqrt(1.0 - r * r)) / i0b;
+        win[j] = taper * sinc;
+    }
+}
+
+struct ResampleTable { void *blob = nullptr; const double *win, *delta; };
+std::mutex g_rs_mu;
+std::map<std::array<int, 3>, ResampleTable> g_rs;
+
+}  // namespace
+
+extern "C" {
+
+int64_t sdfa_resample_out_len(int64_t n_in, int sr_orig, int sr_new) {
+    if (n_in <= 0 || sr_orig <= 0 || sr_new <= 0) return fail(SDFA_EINVAL, "resample_out_len: bad argument");
+    if (sr_orig == sr_new) return n_in;
+    const double ratio = (double)sr_new / (double)sr_orig;
+    return (int64_t)std::ceil((double)n_in * ratio);                // librosa.resample: n_samples = int(np.ceil(y.shape[-1] * ratio))
+}
+
+int64_t sdfa_resample_workspace_bytes(int64_t n_in, int sr_orig, int sr_new) {
+    const int64_t n = sdfa_resample_out_len(n_in, sr_orig, sr_new);
+    return n < 0 ? n : round_up(n * 8, 256);
+}
+
+int sdfa_resample_filter(double *h_half_window, int64_t cap) {
+    if (!h_half_window || cap < RS_NWIN) return fail(SDFA_EINVAL, "resample_filter: need room for %lld doubles", (long long)RS_NWIN);
+    std::vector<double> w;
+    kaiser_best_half(w);
+    memcpy(h_half_window, w.data(), RS_NWIN * 8);
+    return (int)RS_NWIN;
+}
+
+int sdfa_resample(const float *d_in, int64_t n_in, int sr_orig, int sr_new, float *d_out, int64_t n_out, void *d_workspace,
+                  int64_t workspace_bytes, void *stream) {
+    if (!d_in || !d_out || n_in <= 0 || sr_orig <= 0 || sr_new <= 0) return fail(SDFA_EINVAL, "resample: bad argument");
+    if (n_out != sdfa_resample_out_len(n_in, sr_orig, sr_new))
+        return fail(SDFA_EINVAL, "resample: n_out must be sdfa_resample_out_len() = %lld", (long long)sdfa_resample_out_len(n_in, sr_orig, sr_new));
+    hipStream_t s = (hipStream_t)stream;
+    if (sr_orig == sr_new) { HIP_TRY(hipMemcpyAsync(d_out, d_in, (size_t)n_in * 4, hipMemcpyDeviceToDevice, s)); return SDFA_OK; }
+    const double ratio = (double)sr_new / (double)sr_orig;
+    const int64_t n_res = (int64_t)((double)n_in * ratio);          // resampy: shape[axis] = int(shape[axis] * sample_ratio)
+    if (n_res < 1) return fail(SDFA_EINVAL, "resample: input signal length=%lld is too small to resample from %d->%d", (long long)n_in, sr_orig, sr_new);
+    if (!d_workspace || workspace_bytes < n_res * 8 || ((uintptr_t)d_workspace & 7)) return fail(SDFA_ENOSPACE, "resample: workspace too small or misaligned");
+    ResampleTable tb;
+    {
+        std::lock_guard<std::mutex> lk(g_rs_mu);
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        const std::array<int, 3> key{sr_orig, sr_new, dev};
+        auto it = g_rs.find(key);
+        if (it == g_rs.end()) {
+            std::vector<double> win, both(2 * RS_NWIN, 0.0);
+            kaiser_best_half(win);
+            for (int64_t j = 0; j < RS_NWIN; ++j) both[j] = ratio < 1.0 ? win[j] * ratio : win[j];     // interp_win *= sample_ratio
+            for (int64_t j = 0; j + 1 < RS_NWIN; ++j) both[RS_NWIN + j] = both[j + 1] - both[j];       // interp_delta[:-1] = np.diff(interp_win)
+            ResampleTable t;
+            HIP_TRY(hipMalloc(&t.blob, both.size() * 8));
+            HIP_TRY(hipMemcpy(t.blob, both.data(), both.size() * 8, hipMemcpyHostToDevice));
+            t.win = (const double *)t.blob; t.delta = t.win + RS_NWIN;
+            it = g_rs.emplace(key, t).first;
+        }
+        tb = it->second;
+    }
+    // time register: time_register += 1 / sample_ratio per output sample, accumulated sequentially in float64 like the
+    // reference loop (t * increment would round differently).  Uploaded with a blocking copy: this ingest call synchronises.
+    std::vector<double> treg((size_t)n_res);
+    {
+        const double inc = 1.0 / ratio;
+        double tr = 0.0;
+        for (int64_t t = 0; t < n_res; ++t) { treg[(size_t)t] = tr; tr += inc; }
+    }
+    HIP_TRY(hipMemcpyAsync(d_workspace, treg.data(), (size_t)n_res * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));     // the host staging vector dies with this call
+    ResampleArgs a{};
+    a.x = d_in; a.n_in = n_in; a.y = d_out; a.n_res = n_res; a.n_out = n_out; a.win = tb.win; a.delta = tb.delta;
+    a.treg = (const double *)d_workspace; a.nwin = RS_NWIN; a.scale = ratio < 1.0 ? ratio : 1.0;
+    a.step = (int64_t)(a.scale * (double)RS_TABLE); a.num_table = RS_TABLE;
+    if (a.step < 1) return fail(SDFA_EINVAL, "resample: ratio %g is too small for the filter table", ratio);
+    HIP_TRY(sdfa_launch_resample(a, s));
+    return SDFA_OK;
+}
+
+}  // extern "C"
+

@@ -152,11 +152,15 @@ hipError_t sdfa_launch_expand_cols(const float *Zu, const int32_t *col_to_u, flo
 
 // ---- dgrad -> mesh (mesh.hip) -----------------------------------------------------------------------
 struct MeshArgs {
-    const float *dgrad;        // [n_frames][n_tris][9]
-    int64_t n_frames;
+    const float *dgrad;        // [rows][n_src_tris][9]
+    int64_t n_frames;          // output frames (= rows without a seek plan, = queries with one)
     int n_tris, n_verts, n_free, free_pad;
+    int n_src_tris;            // triangles per dgrad row (= n_tris without triangle correspondences)
+    const int64_t *seek_src;   // [n_frames][2] dgrad rows blended into each output frame (null: frame f is row f)
+    const float *seek_w;       // [n_frames][2] their float32 weights
+    const float *reg_xt;       // [n_free][3] reg * template position of each free vertex
     const int *inc_ptr;        // [n_free + 1] CSR over free vertices
-    const int *inc_tri;        // [nnz] triangle of each incidence
+    const int *inc_tri;        // [nnz] SOURCE triangle of each incidence
     const float *inc_coef;     // [nnz][3] the A entries of that (triangle, vertex) pair
     const int *vert_col;       // [n_verts] free-vertex row or -1
     const float *tmpl;         // [n_verts][3] template positions
@@ -167,3 +171,21 @@ struct MeshArgs {
 };
 hipError_t sdfa_launch_mesh_rhs(const MeshArgs &a, hipStream_t s);
 hipError_t sdfa_launch_mesh_scatter(const MeshArgs &a, hipStream_t s);
+// saber.stream.seek on the device (mesh.hip): plan = (src rows, float32 weights) per query; rows = the blended rows
+hipError_t sdfa_launch_seek_plan(const int32_t *tslist, const int64_t *frame_off, const int64_t *query_off, int n_clips, double fps,
+                                 int64_t n_queries, int64_t *src, float *w, hipStream_t s);
+hipError_t sdfa_launch_seek_rows(const float *rows, int64_t width, const int64_t *src, const float *w, int64_t nq, float *out, hipStream_t s);
+
+// ---- audio ingest: kaiser_best resampling (resample.hip) --------------------------------------------------------
+struct ResampleArgs {
+    const float *x;            // [n_in] input samples
+    int64_t n_in;
+    float *y;                  // [n_out]
+    int64_t n_res, n_out;      // int(n_in * ratio) filtered samples, then zeros up to n_out = ceil(n_in * ratio)
+    const double *win, *delta; // [nwin] half filter (scaled by the ratio when downsampling) and its forward differences
+    const double *treg;        // [n_res] time register of every output sample
+    int64_t nwin, step;        // table length, table entries per input sample = int(min(1, ratio) * num_table)
+    double scale;              // min(1, ratio)
+    int num_table;             // table entries per zero crossing (512)
+};
+hipError_t sdfa_launch_resample(const ResampleArgs &a, hipStream_t s);

@@ -17,6 +17,7 @@
 //   (3) mesh_scatter_kernel : template + displacement for free vertices, constraints copied, [frame][vertex][3].
 #include "common.h"
 #include "kernels.h"
+#include <algorithm>
 
 namespace {
 
@@ -47,7 +48,29 @@ __device__ __forceinline__ void transform_minus_identity(const float *__restrict
         }
 }
 
-// RHS'[v][frame*3 + comp] = sum over incidences (j, c) of vertex v of ((T_j - I) c)[comp]
+// One triangle's 9-vector of output frame `frame`.  Plain: row `frame` of dgrad.  Seek (a.seek_src != null): the frame is
+// the blend  wa * row[src0] + wb * row[src1]  of saber.stream.seek (saber/data/stream/stream.py:41-46) -- three
+// separately rounded fp32 operations (numpy evaluates a * x, (1-a) * y and the sum as three float32 array ops), so no FMA
+// contraction: the blended dgrad never exists in memory, and is bit-identical to what seek_rows_kernel would write.
+__device__ __forceinline__ void load_dgrad9(const MeshArgs &a, int64_t frame, int j, float d[9]) {
+    if (!a.seek_src) {
+        const float *__restrict__ p = a.dgrad + (frame * (int64_t)a.n_src_tris + j) * 9;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) d[i] = p[i];
+        return;
+    }
+    const int64_t r0 = a.seek_src[2 * frame], r1 = a.seek_src[2 * frame + 1];
+    const float wa = a.seek_w[2 * frame], wb = a.seek_w[2 * frame + 1];
+    const float *__restrict__ p0 = a.dgrad + (r0 * (int64_t)a.n_src_tris + j) * 9;
+    const float *__restrict__ p1 = a.dgrad + (r1 * (int64_t)a.n_src_tris + j) * 9;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) d[i] = __fadd_rn(__fmul_rn(wa, p0[i]), __fmul_rn(wb, p1[i]));
+}
+
+// RHS'[v][frame*3 + comp] = sum over incidences (equation k -> source triangle j, coefficients c) of vertex v of
+// ((T_j - I) c)[comp], minus reg * template[v][comp] (the regulariser acts on the absolute position, the solve on the
+// displacement).  Equations whose transform is the identity (target triangles without a correspondence,
+// deform_triangle_impl.hpp:262-266) contribute nothing and are not in the incidence lists.
 __global__ __launch_bounds__(256) void mesh_rhs_kernel(MeshArgs a) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nquad = a.free_pad / 4;
@@ -57,7 +80,6 @@ __global__ __launch_bounds__(256) void mesh_rhs_kernel(MeshArgs a) {
     float acc[4][3];
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e][0] = acc[e][1] = acc[e][2] = 0.f;
-    const float *__restrict__ dg = a.dgrad + frame * (int64_t)a.n_tris * 9;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int v = vq * 4 + e;
@@ -65,16 +87,74 @@ __global__ __launch_bounds__(256) void mesh_rhs_kernel(MeshArgs a) {
         for (int p = a.inc_ptr[v]; p < a.inc_ptr[v + 1]; ++p) {
             const int j = a.inc_tri[p];
             const float c0 = a.inc_coef[3 * p], c1 = a.inc_coef[3 * p + 1], c2 = a.inc_coef[3 * p + 2];
-            float T[3][3];
-            transform_minus_identity(dg + (int64_t)j * 9, T);
+            float d[9], T[3][3];
+            load_dgrad9(a, frame, j, d);
+            transform_minus_identity(d, T);
             acc[e][0] += T[0][0] * c0 + T[0][1] * c1 + T[0][2] * c2;
             acc[e][1] += T[1][0] * c0 + T[1][1] * c1 + T[1][2] * c2;
             acc[e][2] += T[2][0] * c0 + T[2][1] * c1 + T[2][2] * c2;
         }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[e][c] -= a.reg_xt[3 * v + c];
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c)
         st4(a.rhs + ((int64_t)vq * a.ld + frame * 3 + c) * 4, make_float4(acc[0][c], acc[1][c], acc[2][c], acc[3][c]));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// saber.stream.seek on the device (saber/data/stream/stream.py:20-46; caller speech_anime/model/model.py:204-212):
+// query i of a clip is ts = i * 1000.0 / fps (float64, like the Python expression); binary search for the animation frame
+// m with tslist[m] <= ts < tslist[m+1]; before the first / after the last timestamp, or on the last frame, the row is
+// copied; otherwise  a = (t[m+1] - ts) / (t[m+1] - t[m])  in float64, and the row is  float32(a) * row[m] +
+// float32(1 - a) * row[m+1].  The plan holds global row indices (src0, src1) and the two float32 weights per query;
+// a copy is (m, m, 1, 0).
+__global__ __launch_bounds__(256) void seek_plan_kernel(const int32_t *__restrict__ tslist, const int64_t *__restrict__ frame_off,
+                                                        const int64_t *__restrict__ query_off, int n_clips, double fps,
+                                                        int64_t *__restrict__ src, float *__restrict__ w) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= query_off[n_clips]) return;
+    int lo = 0, hi = n_clips;               // clip c with query_off[c] <= q < query_off[c+1]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (query_off[mid] <= q) lo = mid; else hi = mid; }
+    const int64_t f0 = frame_off[lo], n = frame_off[lo + 1] - f0;
+    const int32_t *__restrict__ t = tslist + f0;
+    const double ts = (double)(q - query_off[lo]) * 1000.0 / fps;
+    int64_t m;
+    float wa = 1.f, wb = 0.f;
+    bool blend = false;
+    if (ts < (double)t[0]) m = 0;
+    else if (ts > (double)t[n - 1]) m = n - 1;
+    else {
+        int64_t l = 0, r = n;               // last m with t[m] <= ts
+        while (r - l > 1) { const int64_t mid = (l + r) >> 1; if ((double)t[mid] <= ts) l = mid; else r = mid; }
+        m = l;
+        if (m + 1 < n) {
+            const double a = ((double)t[m + 1] - ts) / (double)(t[m + 1] - t[m]);
+            wa = (float)a; wb = (float)(1.0 - a);
+            blend = true;
+        }
+    }
+    src[2 * q] = f0 + m; src[2 * q + 1] = f0 + (blend ? m + 1 : m);
+    w[2 * q] = wa; w[2 * q + 1] = wb;
+}
+
+// out[q][c] = wa * rows[src0][c] + wb * rows[src1][c]  (three fp32 roundings, see load_dgrad9); VEC = 4: 16-byte accesses
+template <int VEC>
+__global__ __launch_bounds__(256) void seek_rows_kernel(const float *__restrict__ rows, int64_t width, const int64_t *__restrict__ src,
+                                                        const float *__restrict__ w, int64_t nq, float *__restrict__ out) {
+    const int64_t per = width / VEC;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq * per; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t q = i / per, c = (i % per) * VEC;
+        const float wa = w[2 * q], wb = w[2 * q + 1];
+        const float *__restrict__ p0 = rows + src[2 * q] * width + c, *__restrict__ p1 = rows + src[2 * q + 1] * width + c;
+        if (VEC == 4) {
+            const float4 x = ld4(p0), y = ld4(p1);
+            st4(out + q * width + c, make_float4(__fadd_rn(__fmul_rn(wa, x.x), __fmul_rn(wb, y.x)), __fadd_rn(__fmul_rn(wa, x.y), __fmul_rn(wb, y.y)),
+                                                 __fadd_rn(__fmul_rn(wa, x.z), __fmul_rn(wb, y.z)), __fadd_rn(__fmul_rn(wa, x.w), __fmul_rn(wb, y.w))));
+        } else {
+            out[q * width + c] = __fadd_rn(__fmul_rn(wa, p0[0]), __fmul_rn(wb, p1[0]));
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void mesh_scatter_kernel(MeshArgs a) {
@@ -97,6 +177,21 @@ __global__ __launch_bounds__(256) void mesh_scatter_kernel(MeshArgs a) {
 hipError_t sdfa_launch_mesh_rhs(const MeshArgs &a, hipStream_t s) {
     const int64_t n = a.free_pad / 4 * a.n_frames;
     hipLaunchKernelGGL(mesh_rhs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t sdfa_launch_seek_plan(const int32_t *tslist, const int64_t *frame_off, const int64_t *query_off, int n_clips, double fps,
+                                 int64_t n_queries, int64_t *src, float *w, hipStream_t s) {
+    hipLaunchKernelGGL(seek_plan_kernel, dim3((unsigned)((n_queries + 255) / 256)), dim3(256), 0, s, tslist, frame_off, query_off, n_clips, fps, src, w);
+    return hipGetLastError();
+}
+
+hipError_t sdfa_launch_seek_rows(const float *rows, int64_t width, const int64_t *src, const float *w, int64_t nq, float *out, hipStream_t s) {
+    const bool vec = width % 4 == 0 && (((uintptr_t)rows | (uintptr_t)out) & 15) == 0;
+    const int64_t n = nq * (vec ? width / 4 : width);
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 256 * 32);
+    if (vec) hipLaunchKernelGGL(seek_rows_kernel<4>, dim3(grid), dim3(256), 0, s, rows, width, src, w, nq, out);
+    else hipLaunchKernelGGL(seek_rows_kernel<1>, dim3(grid), dim3(256), 0, s, rows, width, src, w, nq, out);
     return hipGetLastError();
 }
 

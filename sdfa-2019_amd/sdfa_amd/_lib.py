@@ -47,6 +47,17 @@ SYMBOLS = {
     "sdfa_mesh_destroy": (None, [_p]),
     "sdfa_mesh_workspace_bytes": (_i64, [_p, _i64]),
     "sdfa_mesh_from_dgrad": (C.c_int, [_p, _p, _i64, _p, _p, _i64, _p]),
+    "sdfa_mesh_n_verts": (_i64, [_p]),
+    "sdfa_mesh_n_src_tris": (_i64, [_p]),
+    "sdfa_mesh_create_corres": (_p, [_p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i64, C.c_double, _p]),
+    "sdfa_seek_query_count": (_i64, [_i32, C.c_double]),
+    "sdfa_seek_plan": (C.c_int, [_p, _p, _p, _i32, C.c_double, _i64, _p, _p, _p]),
+    "sdfa_seek_rows": (C.c_int, [_p, _i64, _p, _p, _i64, _p, _p]),
+    "sdfa_mesh_from_dgrad_seek": (C.c_int, [_p, _p, _p, _p, _i64, _p, _p, _i64, _p]),
+    "sdfa_resample_out_len": (_i64, [_i64, C.c_int, C.c_int]),
+    "sdfa_resample_workspace_bytes": (_i64, [_i64, C.c_int, C.c_int]),
+    "sdfa_resample_filter": (C.c_int, [_p, _i64]),
+    "sdfa_resample": (C.c_int, [_p, _i64, C.c_int, C.c_int, _p, _i64, _p, _i64, _p]),
     "sdfa_profile_enable": (C.c_int, [_p, C.c_int]),
     "sdfa_profile_reset": (C.c_int, [_p]),
     "sdfa_profile_ms": (_f, [_p, C.c_char_p]),

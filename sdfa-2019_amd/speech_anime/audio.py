@@ -3,9 +3,9 @@
   rms_normalize -- saber.audio.rms.normalize (saber/data/audio/rms.py:45-78), called at speech_anime/model/model.py:165
   load_source   -- the .wav branch of speech_anime/model/eval_utils.py:50-93
 
-The reference loads everything through librosa at 44.1 kHz and resamples with resampy (kaiser_best); neither
-library is available offline, so files must already be PCM WAV at the model rate (or .npy float32 PCM).
-Resampler parity is a listed next row, not part of this path.
+The reference loads everything through librosa at 44.1 kHz and resamples with resampy (kaiser_best); neither library is
+available offline, so the resampling arithmetic is restated as a HIP kernel (csrc/resample.hip, parity unpinned) and WAV
+decoding uses scipy.io.wavfile.
 """
 import os
 
@@ -28,20 +28,57 @@ def rms_normalize(wav, target_db=-20, threshold=None):
     return np.clip(wav * gain, -0.999, 0.999)
 
 
-def load_source(path, sr):
+SOUND_SR = 44100      # every source is first brought to 44.1 kHz (eval_utils.py:77,83; also the rate of the exported audio.wav)
+
+
+def read_wav(path):
+    """Decoded mono float32 signal and the file's own rate -- what librosa.load does before resampling: integer PCM
+    scaled by 1 / 2**(bits-1) (soundfile's float32 read), channels averaged (librosa.to_mono)."""
+    from scipy.io import wavfile
+    file_sr, data = wavfile.read(path)
+    if np.issubdtype(data.dtype, np.integer):
+        if data.dtype == np.uint8:
+            data = (data.astype(np.float32) - 128.0) / 128.0
+        else:
+            data = data.astype(np.float32) / float(np.iinfo(data.dtype).max + 1)
+    data = data.astype(np.float32)
+    if data.ndim > 1:
+        data = data.mean(axis=1, dtype=np.float32)
+    return data, int(file_sr)
+
+
+def write_wav(path, signal, sr):
+    """saber.audio.save (saber/data/audio/io.py:19-24: soundfile.write, 16-bit PCM for a .wav)."""
+    from scipy.io import wavfile
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    x = np.asarray(signal, np.float32).reshape(-1)
+    pcm = np.clip(np.round(x * 32768.0), -32768, 32767).astype(np.int16)      # libsndfile's float -> int16 conversion clips
+    wavfile.write(path, int(sr), pcm)
+
+
+def load_source(path, sr, return_sound=False):
+    """The .wav / .npy branch of speech_anime/model/eval_utils.py:50-93.
+
+    .wav: decode, bring to 44.1 kHz (`sound_signal`, what saber.audio.load(path, 44100) returns), then 44.1 kHz -> `sr`
+    (`signal`) -- both conversions on the GPU (sdfa_amd.resample: the kaiser_best arithmetic of librosa.resample, restated;
+    parity unpinned).  So a 16 kHz WAV takes the reference's 16 k -> 44.1 k -> 8 k route with the in-repo 8 kHz config.
+    .npy: float32 PCM already at the model rate (no reference counterpart; used by tests and synthetic runs).
+    Video / compressed containers (.mp4, .m4v, .avi) go through audioread/ffmpeg in the reference; no decoder exists in
+    this image, so they are refused by name."""
     path = os.path.expanduser(path)
     ext = os.path.splitext(path)[1].lower()
     if ext == ".npy":
-        return np.load(path).astype(np.float32).reshape(-1)
+        signal = np.load(path).astype(np.float32).reshape(-1)
+        return (signal, None) if return_sound else signal
     if ext == ".wav":
-        from scipy.io import wavfile
-        file_sr, data = wavfile.read(path)
-        if data.ndim > 1:
-            data = data.mean(axis=1)
-        if np.issubdtype(data.dtype, np.integer):
-            data = data.astype(np.float32) / float(np.iinfo(data.dtype).max + 1)
-        if file_sr != sr:
-            raise ValueError(f"{path}: sample rate {file_sr} != model rate {sr}; resampling (librosa/resampy in the "
-                             "reference) is not part of this path -- convert the file first")
-        return data.astype(np.float32)
-    raise ValueError(f"{ext} is not supported (the reference decodes video/audio containers through librosa/ffmpeg)")
+        from sdfa_amd.resample import resample
+        data, file_sr = read_wav(path)
+        sound = data if file_sr == SOUND_SR else resample(data, file_sr, SOUND_SR)
+        signal = resample(sound, SOUND_SR, sr).cpu().numpy() if sr != SOUND_SR else np.asarray(sound if not hasattr(sound, "cpu") else sound.cpu().numpy())
+        if return_sound:
+            return signal, (sound.cpu().numpy() if hasattr(sound, "cpu") else sound)
+        return signal
+    if ext in (".mp4", ".m4v", ".avi"):
+        raise ValueError(f"{path}: decoding {ext} needs audioread/ffmpeg (the reference's librosa.load route), which this image "
+                         "does not have -- extract the audio track to a .wav of any sample rate first")
+    raise ValueError(f"{ext} is not supported!")

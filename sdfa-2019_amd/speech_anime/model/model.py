@@ -175,22 +175,34 @@ class SaberSpeechDrivenAnimation:
                     if isinstance(extra, str) and extra.startswith("speaker="):
                         spk = extra.split("=", 1)[1]
                 name = os.path.splitext(os.path.basename(path))[0]
-                signal = _audio.load_source(path, sr)
+                signal, sound_signal = _audio.load_source(path, sr, return_sound=True)         # eval_utils.py:76-86
                 signal = _audio.rms_normalize(signal, target_db).astype(np.float32)            # model.py:165
                 tslist, animes, _ = self.generate_animation(signal=signal, speaker=spk, emotion=0, frame_id=0,
-                                                            dataset_class=DatasetSlidingWindow, want_inputs=False)
+                                                            dataset_class=DatasetSlidingWindow, want_inputs=False,
+                                                            ensembling_ms=kwargs.get("ensembling_ms"))
                 out_dir = os.path.join(output_dir, name)
                 os.makedirs(out_dir, exist_ok=True)
                 np.save(os.path.join(out_dir, "tslist.npy"), np.asarray(tslist, np.int64))
                 np.save(os.path.join(out_dir, f"{self._face_type}.npy"), animes)
                 if export_frames:                                                              # model.py:201-212
                     from .. import viewer
-                    max_frame = int(tslist[-1] * fps / 1000.0)
-                    frames = np.stack([_stream.seek(i * 1000.0 / fps, tslist, animes) for i in range(max_frame + 1)])
+                    from sdfa_amd.seek import SeekPlan
+                    if sound_signal is not None:
+                        _audio.write_wav(os.path.join(out_dir, "audio.wav"), sound_signal, _audio.SOUND_SR)   # model.py:203
+                    # stream.seek for every video frame i at i * 1000 / fps, i = 0 .. int(tslist[-1] * fps / 1000), as ONE
+                    # device stage; with a template the mesh solve is fused into it (the blended track is only
+                    # materialised for the NNNNNN_dgrad.npy dump the reference also writes)
+                    eng = self._model._engine
+                    plan = SeekPlan([tslist], fps, device=eng.device)
+                    track = torch.from_numpy(np.ascontiguousarray(animes, dtype=np.float32)).to(eng.device).reshape(len(tslist), -1)
+                    frames = plan.rows(track).cpu().numpy().reshape((plan.n_queries,) + animes.shape[1:])
                     for i_frame, data_frame in enumerate(frames):
                         np.save(os.path.join(out_dir, f"{i_frame:06d}_dgrad.npy"), data_frame)
-                    if viewer.has_template():          # --template_mesh given: one batched GPU solve, then .obj per frame
-                        verts, faces = viewer.frames_to_mesh(frames.astype(np.float32), self._face_type)
+                    if viewer.has_template():          # --template_mesh given: seek + solve on the GPU, then .obj per frame
+                        if self._face_type == "dgrad_3d":
+                            verts, faces = viewer.track_to_mesh(track, plan).cpu().numpy(), viewer.template_faces()
+                        else:
+                            verts, faces = viewer.frames_to_mesh(frames.astype(np.float32), self._face_type)
                         for i_frame in range(len(frames)):
                             viewer.write_obj(os.path.join(out_dir, f"{i_frame:06d}.obj"), verts[i_frame], faces)
                 print(f"[speech_anime] {name}: {len(tslist)} animation frames -> {out_dir} (video rendering is outside this path)")

@@ -1,5 +1,6 @@
 """Template-mesh state and frame_to_mesh -- the part of speech_anime/viewer/frame.py (:17-141) that turns a
-dgrad / offsets frame into vertices, backed by the GPU deformation solve (sdfa_amd.mesh).  Rendering is out of scope."""
+dgrad / offsets frame into vertices, backed by the GPU deformation solve (sdfa_amd.mesh), including retargeting to a
+template of another topology through triangle correspondences (--mesh_tricorres).  Rendering is out of scope."""
 import numpy as np
 import torch
 
@@ -7,6 +8,7 @@ from sdfa_amd.mesh import MeshSolver
 
 _template_verts, _template_faces = None, None
 _template_c_indices = []
+_template_corres = None
 _solver = None
 
 
@@ -33,14 +35,43 @@ def write_obj(path, verts, faces):
             fp.write("f {} {} {}\n".format(*(f + 1)))
 
 
+N_MODEL_TRIS = 9976      # triangles of the model's FLAME-topology dgrad rows (frame.py:117: 89784 = 9976 * 9)
+
+
 def set_dgrad_static(verts, faces, c_indices=None, corres=None):
-    global _template_verts, _template_faces, _template_c_indices, _solver
-    if corres is not None:
-        raise NotImplementedError("triangle correspondences (--mesh_tricorres) are not part of this build")
+    """frame.py:27-46: template state + deformation.set_target(verts, faces, cnsts, corrs=corr_count)."""
+    global _template_verts, _template_faces, _template_c_indices, _template_corres, _solver
     _template_verts = np.asarray(verts, np.float32).reshape(-1, 3)
     _template_faces = np.asarray(faces, np.uint32).reshape(-1, 3)
     _template_c_indices = [] if c_indices is None else list(c_indices)
-    _solver = MeshSolver(_template_verts, _template_faces, _template_c_indices)      # deformation.set_target
+    _template_corres = None if corres is None else {k: list(corres[k]) for k in ("corr_count", "corr_faces")}
+    if _template_corres is None:
+        _solver = MeshSolver(_template_verts, _template_faces, _template_c_indices)
+    else:
+        _solver = MeshSolver(_template_verts, _template_faces, _template_c_indices, corr_count=_template_corres["corr_count"],
+                             corr_faces=_template_corres["corr_faces"], n_src_tris=N_MODEL_TRIS)
+
+
+def read_tricorres(corres_path, n_faces):
+    """The .tricorrs file of --mesh_tricorres (frame.py:57-80): first line = number of records, then `src,dst,...` per
+    line; every target triangle `dst` collects its source triangles in file order.  Returns corr_count (per target
+    triangle) and corr_faces (concatenated sources, one filler 0 for a triangle without any)."""
+    by_target = {}
+    with open(corres_path) as fp:
+        lines = fp.read().splitlines()
+    remaining = int(lines[0].strip()) if lines else 0
+    for line in lines[1:]:
+        if remaining == 0:
+            break
+        src, dst = (int(x) for x in line.strip().split(",")[:2])
+        by_target.setdefault(dst, []).append(src)
+        remaining -= 1
+    counts, flat = [], []
+    for tri in range(n_faces):
+        sources = by_target.get(tri, [])
+        counts.append(len(sources))
+        flat.extend(sources if sources else [0])
+    return dict(corr_count=counts, corr_faces=flat)
 
 
 def set_template_mesh(template_path, constraints_path=None, corres_path=None):
@@ -49,13 +80,16 @@ def set_template_mesh(template_path, constraints_path=None, corres_path=None):
     if constraints_path is not None:
         with open(constraints_path) as fp:
             c_indices = [int(x) for x in " ".join(l.strip() for l in fp.readlines()).split()]
-    if corres_path is not None:
-        raise NotImplementedError("triangle correspondences (--mesh_tricorres) are not part of this build")
-    set_dgrad_static(verts, faces, c_indices)
+    corres = read_tricorres(corres_path, len(faces)) if corres_path is not None else None
+    set_dgrad_static(verts, faces, c_indices, corres)
 
 
 def has_template():
     return _solver is not None
+
+
+def template_faces():
+    return _template_faces
 
 
 def frames_to_mesh(data_frames, face_data_type):
@@ -70,6 +104,13 @@ def frames_to_mesh(data_frames, face_data_type):
     else:
         verts = x.reshape(n, -1, 3).cpu().numpy()
     return verts, _template_faces
+
+
+def track_to_mesh(anime_rows, plan):
+    """model.py:204-212 as ONE device stage: the animation-rate dgrad rows (n_frames, 89784) on the GPU and a
+    sdfa_amd.seek.SeekPlan -> vertices of every video frame (n_queries, V, 3), cuda."""
+    assert _solver is not None, "set_template_mesh first"
+    return _solver.get_mesh_seek(anime_rows, plan)
 
 
 def frame_to_mesh(data_frame, face_data_type):

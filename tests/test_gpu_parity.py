@@ -223,8 +223,23 @@ def test_error_paths(eng, synth_sd):
     zz, al = eng.encoder(torch.zeros((0, 64, 128, 3), device="cuda"))     # empty batch is a no-op
     assert zz.shape == (0, 512) and al.shape == (0, 64)
     bad = {k: v for k, v in synth_sd["dgrad"].items() if "proj_key" not in k}
-    with pytest.raises(SdfaError):                       # missing tensor -> SDFA_ESTATE at finalize
+    with pytest.raises(RuntimeError, match="Missing key"):   # strict load, like the reference's load_state_dict (checkpoints.py:22-33)
         Engine(bad)
+    with pytest.raises(SdfaError):                       # not strict: the library itself reports SDFA_ESTATE at finalize
+        Engine(bad, strict=False)
+    tr = dict(synth_sd["dgrad"])
+    k = "_model._audio_encoder._layers.10.proj_key.weight"
+    tr[k] = np.ascontiguousarray(np.asarray(tr[k]).T)    # right element count, wrong shape
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        Engine(tr)
+    with pytest.raises(RuntimeError, match="Unexpected key"):
+        Engine({**synth_sd["dgrad"], "_model.junk.weight": np.zeros(3, np.float32)})
+    # misaligned output pointers are refused by the C ABI instead of faulting in a 16-byte store (pca.hip)
+    buf = torch.empty(2 * eng.out_dim + 1, device="cuda")
+    with pytest.raises(SdfaError, match="16-byte aligned"):
+        eng.regress(z, torch.tensor([0, 1]), out=buf[1:].view(2, eng.out_dim))
+    with pytest.raises(RuntimeError, match="out of bounds"):            # CUDA id tensors are validated too
+        eng.regress(z, torch.tensor([0, 9], device="cuda"))
 
 
 def test_gather_front_end_matches_the_per_window_front_end(eng):

@@ -64,6 +64,22 @@ def test_offsets_head_through_surface(golden, synth_sd):
     assert np.abs(pred.cpu().numpy()[:, 0, ::7] - g["offsets_stride7"]).max() <= 1e-4
 
 
+@pytest.mark.parametrize("sr", [8000, 16000])
+def test_ensembling_matches_reference_fixture(golden, synth_sd, sr):
+    """generate_animation(..., ensembling_ms=20) run by the reference itself (oracle/gen_golden_next.py; model.py:369-403)."""
+    g = golden["ensembling"]
+    hp, model = _model(synth_sd["dgrad"], sr)
+    ts, animes, _ = model.generate_animation(synth.make_pcm(0, 2 * sr), "m1", 0, 0, ensembling_ms=20, dataset_class=DatasetSlidingWindow)
+    assert list(ts) == list(g[f"sr{sr}_tslist"]) and list(animes.shape) == list(g[f"sr{sr}_shape"])
+    flat = animes.reshape(len(ts), -1)
+    assert np.abs(flat[:, ::97] - g[f"sr{sr}_stride97"]).max() <= 1e-4
+    assert np.abs(animes[10] - g[f"sr{sr}_frame10"]).max() <= 1e-4
+    assert np.abs(flat.astype(np.float64).sum(1) - g[f"sr{sr}_sum"]).max() <= 89784 * 2e-6
+    # not the single-pass result: the delayed pass really contributes
+    e = golden["e2e_dgrad"]
+    assert np.abs(flat[:, ::97] - e[f"sr{sr}_stride97"].reshape(len(ts), -1)).max() > 1e-3
+
+
 def test_ensembling_averages_two_passes(synth_sd):
     sr = 16000
     hp, model = _model(synth_sd["dgrad"], sr)
