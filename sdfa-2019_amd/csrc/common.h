@@ -65,6 +65,31 @@ __device__ __forceinline__ void mfma_block(f32x16 (&acc)[M][N], const float4 (&a
             for (int j = 0; j < N; ++j) acc[i][j] = MFMA(SDFA_OP(f4c(a[i], q)), SDFA_OP(f4c(b[j], q)), acc[i][j]);
 }
 
+// Single IEEE operations that must NOT be contracted into an FMA: code that reproduces numpy / Python arithmetic op by op
+// (stream.seek's  a * x + (1 - a) * y  on float32 arrays, the resampler's float64 taps).  HIP's __fmul_rn / __dadd_rn are
+// plain operators and contract like any other; the pragma keeps the `contract` flag off these instructions (the library
+// is built with -ffp-contract=fast-honor-pragmas).
+__device__ __forceinline__ float fmul_exact(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float fadd_exact(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ double dmul_exact(double a, double b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ double dadd_exact(double a, double b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ double dsub_exact(double a, double b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+
 __device__ __forceinline__ float lrelu02(float x) { return x >= 0.f ? x : 0.2f * x; }
 
 // v_exp_f32 / v_rcp_f32 based, branch-free (1-2 ulp each; absolute error ~1e-7, which is what the

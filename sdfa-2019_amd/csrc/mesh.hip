@@ -64,7 +64,7 @@ __device__ __forceinline__ void load_dgrad9(const MeshArgs &a, int64_t frame, in
     const float *__restrict__ p0 = a.dgrad + (r0 * (int64_t)a.n_src_tris + j) * 9;
     const float *__restrict__ p1 = a.dgrad + (r1 * (int64_t)a.n_src_tris + j) * 9;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) d[i] = __fadd_rn(__fmul_rn(wa, p0[i]), __fmul_rn(wb, p1[i]));
+    for (int i = 0; i < 9; ++i) d[i] = fadd_exact(fmul_exact(wa, p0[i]), fmul_exact(wb, p1[i]));
 }
 
 // RHS'[v][frame*3 + comp] = sum over incidences (equation k -> source triangle j, coefficients c) of vertex v of
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void seek_plan_kernel(const int32_t *__restric
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (query_off[mid] <= q) lo = mid; else hi = mid; }
     const int64_t f0 = frame_off[lo], n = frame_off[lo + 1] - f0;
     const int32_t *__restrict__ t = tslist + f0;
-    const double ts = (double)(q - query_off[lo]) * 1000.0 / fps;
+    const double ts = dmul_exact((double)(q - query_off[lo]), 1000.0) / fps;
     int64_t m;
     float wa = 1.f, wb = 0.f;
     bool blend = false;
@@ -129,8 +129,8 @@ __global__ __launch_bounds__(256) void seek_plan_kernel(const int32_t *__restric
         while (r - l > 1) { const int64_t mid = (l + r) >> 1; if ((double)t[mid] <= ts) l = mid; else r = mid; }
         m = l;
         if (m + 1 < n) {
-            const double a = ((double)t[m + 1] - ts) / (double)(t[m + 1] - t[m]);
-            wa = (float)a; wb = (float)(1.0 - a);
+            const double a = dsub_exact((double)t[m + 1], ts) / (double)(t[m + 1] - t[m]);
+            wa = (float)a; wb = (float)dsub_exact(1.0, a);
             blend = true;
         }
     }
@@ -149,10 +149,10 @@ __global__ __launch_bounds__(256) void seek_rows_kernel(const float *__restrict_
         const float *__restrict__ p0 = rows + src[2 * q] * width + c, *__restrict__ p1 = rows + src[2 * q + 1] * width + c;
         if (VEC == 4) {
             const float4 x = ld4(p0), y = ld4(p1);
-            st4(out + q * width + c, make_float4(__fadd_rn(__fmul_rn(wa, x.x), __fmul_rn(wb, y.x)), __fadd_rn(__fmul_rn(wa, x.y), __fmul_rn(wb, y.y)),
-                                                 __fadd_rn(__fmul_rn(wa, x.z), __fmul_rn(wb, y.z)), __fadd_rn(__fmul_rn(wa, x.w), __fmul_rn(wb, y.w))));
+            st4(out + q * width + c, make_float4(fadd_exact(fmul_exact(wa, x.x), fmul_exact(wb, y.x)), fadd_exact(fmul_exact(wa, x.y), fmul_exact(wb, y.y)),
+                                                 fadd_exact(fmul_exact(wa, x.z), fmul_exact(wb, y.z)), fadd_exact(fmul_exact(wa, x.w), fmul_exact(wb, y.w))));
         } else {
-            out[q * width + c] = __fadd_rn(__fmul_rn(wa, p0[0]), __fmul_rn(wb, p1[0]));
+            out[q * width + c] = fadd_exact(fmul_exact(wa, p0[0]), fmul_exact(wb, p1[0]));
         }
     }
 }

@@ -22,14 +22,14 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a) {
     if (t >= a.n_res) { a.y[t] = 0.f; return; }          // librosa util.fix_length: zero padding up to ceil(n * ratio)
     const double tr = a.treg[t];
     const int64_t n = (int64_t)tr;
-    double frac = __dmul_rn(a.scale, __dsub_rn(tr, (double)n));
+    double frac = dmul_exact(a.scale, dsub_exact(tr, (double)n));
     float acc = 0.f;
 #pragma unroll 1
     for (int wing = 0; wing < 2; ++wing) {
-        if (wing) frac = __dsub_rn(a.scale, frac);
-        const double index_frac = __dmul_rn(frac, (double)a.num_table);
+        if (wing) frac = dsub_exact(a.scale, frac);
+        const double index_frac = dmul_exact(frac, (double)a.num_table);
         const int64_t offset = (int64_t)index_frac;
-        const double eta = __dsub_rn(index_frac, (double)offset);
+        const double eta = dsub_exact(index_frac, (double)offset);
         const int64_t room = (a.nwin - offset) / a.step;
         const int64_t have = wing ? a.n_in - n - 1 : n + 1;
         const int64_t kmax = have < room ? have : room;
@@ -37,8 +37,8 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a) {
         const float *__restrict__ xp = a.x + (wing ? n + 1 : n);
         const int64_t xs = wing ? 1 : -1;
         for (int64_t i = 0; i < kmax; ++i) {
-            const double w = __dadd_rn(wp[i * a.step], __dmul_rn(eta, dp[i * a.step]));
-            acc = (float)__dadd_rn((double)acc, __dmul_rn(w, (double)xp[i * xs]));
+            const double w = dadd_exact(wp[i * a.step], dmul_exact(eta, dp[i * a.step]));
+            acc = (float)dadd_exact((double)acc, dmul_exact(w, (double)xp[i * xs]));
         }
     }
     a.y[t] = acc;
