@@ -42,7 +42,12 @@ def parse():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--sample-rate", type=int, default=16000)
     ap.add_argument("--chunk", type=int, default=8192, help="frames per encoder launch group")
-    ap.add_argument("--gather", choices=["dgrad", "coef", "none"], default="dgrad")
+    ap.add_argument("--gather", choices=["dgrad", "coef", "none", "direct", "mesh"], default="dgrad",
+                    help="what is reassembled on every rank at N > 1: dgrad = RCCL all-gather of the output rows, chunk by chunk (default); "
+                         "coef = of the PCA coefficients; direct = the regressor stores each row straight into every peer's gathered "
+                         "buffer over xGMI (one-shot direct all-gather, no collective); mesh = dgrad -> seek -> mesh on the device, "
+                         "then all-gather of the vertices (60 KB instead of 359 KB per frame)")
+    ap.add_argument("--mesh-stage", action="store_true", help="run the seek + mesh post-path stage inside the timed step (implied by --gather mesh)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-column-sharing", action="store_true", help="skip the second, column-sharing measurement")
@@ -173,12 +178,36 @@ def main():
     eng.check_speaker_ids(spk)                                         # once, outside the timed region (a host sync)
     feat = torch.empty((F, 64, 128, 3), dtype=torch.float32, device=dev)
     width = eng.out_dim if a.gather != "coef" else eng.coef_dim
-    gatherer = None
+    gatherer = direct = None
     all_counts = sdist.frame_counts_all(F) if (world > 1 and a.ragged_seconds) else [F] * world
     F_all = int(sum(all_counts))
-    if world > 1 and a.gather != "none":
+    if world > 1 and a.gather in ("dgrad", "coef"):
         gatherer = sdist.FrameGatherer(all_counts, width, torch.float32, dev, a.chunk)
-    out = torch.empty((F, eng.out_dim), dtype=torch.float32, device=dev)
+    if a.gather == "direct":
+        if world == 1:
+            raise SystemExit("--gather direct needs N > 1 (it replaces the all-gather)")
+        direct = sdist.DirectGatherer(all_counts, eng.out_dim, dev)
+        out = direct.dests[0]                                       # this rank's slot of its own gathered buffer
+    else:
+        out = torch.empty((F, eng.out_dim), dtype=torch.float32, device=dev)
+
+    # ---- optional post-path stage: saber.stream.seek to the video rate fused into the dgrad -> mesh solve
+    mesh = None
+    if a.gather == "mesh" or a.mesh_stage:
+        if a.head != "dgrad":
+            raise SystemExit("the mesh stage consumes dgrad rows")
+        from sdfa_amd.mesh import MeshSolver
+        from sdfa_amd.seek import SeekPlan
+        tv, tf, tc = synth.make_template_mesh()
+        solver = MeshSolver(tv, tf, tc, device=dev)
+        tslists = [frame_index(L, sr)[1] for L in lengths]
+        plan = SeekPlan(tslists, 60.0, device=dev)
+        verts = torch.empty((plan.n_queries, solver.n_verts, 3), dtype=torch.float32, device=dev)
+        vgather = None
+        if world > 1 and a.gather == "mesh":
+            q_all = sdist.frame_counts_all(plan.n_queries)
+            vgather = sdist.FrameGatherer(q_all, solver.n_verts * 3, torch.float32, dev, max(q_all))
+        mesh = (solver, plan, verts, vgather)
 
     hop = int(0.008 * sr)
 
@@ -189,11 +218,22 @@ def main():
                 z, _ = eng.encoder(feat[f0:f1], want_align=False, frame_clip=frame_clip[f0:f1], frame_start=frame_start[f0:f1], hop=hop)
             else:
                 z, _ = eng.encoder(feat[f0:f1], want_align=False)
+            if direct is not None:        # rows go to this rank's slot in EVERY rank's gathered buffer, written by the epilogue
+                eng.regress_multi(z, spk[f0:f1], direct.dest_views(f0, f1), check_ids=False)
+                return None
             coef, o = eng.regress(z, spk[f0:f1], want_coef=(a.gather == "coef"), out=out[f0:f1], check_ids=False)
             return o if a.gather == "dgrad" else coef
 
         # every rank issues the SAME number of collectives, also when shards are ragged (sdfa_amd/dist.py: run_chunks)
         sdist.run_chunks(F, a.chunk, gatherer, compute)
+        if mesh is not None:
+            solver, plan, verts, vgather = mesh
+            solver.get_mesh_seek(out, plan, out=verts)
+            if vgather is not None:
+                vgather.gather_chunk(verts.view(plan.n_queries, -1), 0)
+                vgather.finish()
+        if direct is not None:
+            direct.finish()
 
     def fence():
         if world > 1:
@@ -260,7 +300,8 @@ def main():
                                     if not a.ragged_seconds else
                                     f"stream of {C} sentences, {a.ragged_seconds} s@{sr} Hz synthetic PCM per GPU -> {a.head} (BASELINE configs[4] rehearsal)"),
                        "clips_per_gpu": C, "frames_per_gpu": F, "head": a.head, "chunk_frames": a.chunk,
-                       "gather": a.gather if world > 1 else "none (1 GPU)", "weights": "synthetic seed 1234"},
+                       "gather": a.gather if world > 1 else "none (1 GPU)", "weights": "synthetic seed 1234",
+                       "mesh_stage": None if mesh is None else f"seek to 60 fps + mesh solve, {mesh[1].n_queries} video frames x {mesh[0].n_verts} vertices per GPU per step"},
             "roofline": {"kernel": "freq_lstm_kernel", "bound": "mfma", "achieved": round(achieved, 2),
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                          "traffic": traffic, "traffic_algorithmic": traffic_alg, "traffic_source": traffic_src,

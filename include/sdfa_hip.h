@@ -189,6 +189,15 @@ int sdfa_regress_forward(const sdfa_model *m, const float *d_z, const int64_t *d
                          int64_t n_frames, float *d_coef, float *d_out, void *d_workspace,
                          int64_t workspace_bytes, void *stream);
 
+/* The same, with the output rows stored to SEVERAL destinations (at most 8): h_d_outs is a HOST array of n_outs device
+ * pointers, each a [n_frames][out_dim] buffer with d_out's alignment rules.  This is the one-shot direct all-gather of the
+ * per-frame output: on a fully connected xGMI node a rank passes its own buffer plus its slot
+ * in every peer's gathered buffer (peer memory mapped with hipIpcOpenMemHandle) and the regressor's epilogue writes each row
+ * once per destination -- no staging copy, no collective, one shard per link.  All destinations receive identical bits. */
+int sdfa_regress_forward_multi(const sdfa_model *m, const float *d_z, const int64_t *d_speaker_id, int64_t n_frames,
+                               float *d_coef, float *const *h_d_outs, int n_outs, void *d_workspace,
+                               int64_t workspace_bytes, void *stream);
+
 /* Debug / parity taps: copy an intermediate activation of the LAST sdfa_encoder_forward call out of
  * the workspace in the reference's layout.  what: 0 = pool1 (n,32,64,64)  1 = conv3 (n,64,32,64)
  * 2 = freq-lstm (n,256,64)  3 = bilstm (n,64,512).  Used by tests only. */

@@ -884,7 +884,21 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
 // ------------------------------------------------------------------------------------------------
 int sdfa_regress_forward(const sdfa_model *m, const float *d_z, const int64_t *d_speaker_id, int64_t n_frames,
                          float *d_coef, float *d_out, void *d_workspace, int64_t workspace_bytes, void *stream) {
+    float *one[1] = {d_out};
+    return sdfa_regress_forward_multi(m, d_z, d_speaker_id, n_frames, d_coef, one, d_out ? 1 : 0, d_workspace, workspace_bytes, stream);
+}
+
+int sdfa_regress_forward_multi(const sdfa_model *m, const float *d_z, const int64_t *d_speaker_id, int64_t n_frames,
+                               float *d_coef, float *const *h_d_outs, int n_outs, void *d_workspace, int64_t workspace_bytes,
+                               void *stream) {
     if (!m || !m->finalized) return fail(SDFA_ESTATE, "regress_forward: model not finalised");
+    if (n_outs < 0 || n_outs > SDFA_MAX_DESTS || (n_outs && !h_d_outs)) return fail(SDFA_EINVAL, "regress_forward: 0..%d output destinations", SDFA_MAX_DESTS);
+    for (int i = 0; i < n_outs; ++i) {
+        if (!h_d_outs[i]) return fail(SDFA_EINVAL, "regress_forward: output destination %d is null", i);
+        if (m->head == SDFA_HEAD_DGRAD && ((uintptr_t)h_d_outs[i] & 15)) return fail(SDFA_EINVAL, "regress_forward: d_out must be 16-byte aligned for the dgrad head");
+        if ((uintptr_t)h_d_outs[i] & 3) return fail(SDFA_EINVAL, "regress_forward: output pointers must be 4-byte aligned");
+    }
+    float *d_out = n_outs ? h_d_outs[0] : nullptr;
     if (n_frames == 0) return SDFA_OK;
     if (!d_z || !d_speaker_id || !d_workspace || n_frames < 0) return fail(SDFA_EINVAL, "regress_forward: bad argument");
     if (((uintptr_t)d_workspace | (uintptr_t)d_z) & 15) return fail(SDFA_EINVAL, "regress_forward: pointers must be 16-byte aligned");
@@ -937,6 +951,8 @@ int sdfa_regress_forward(const sdfa_model *m, const float *d_z, const int64_t *d
                 PcaArgs pa{};
                 pa.coef = coef; pa.basis_s = m->pca_q[0]; pa.basis_r = m->pca_q[1]; pa.mean_s = m->pca_bias[0]; pa.mean_r = m->pca_bias[1];
                 pa.out = d_out + f0 * m->out_dim; pa.N = N; pa.Nc = Nc; pa.out_dim = m->out_dim;
+                pa.n_extra = n_outs - 1;
+                for (int x = 1; x < n_outs; ++x) pa.out_extra[x - 1] = h_d_outs[x] + f0 * m->out_dim;
                 pa.ld_s = m->pca_ld[0]; pa.ld_r = m->pca_ld[1]; pa.cols_s = m->pca_cols[0]; pa.cols_r = m->pca_cols[1];
                 HIP_TRY(sdfa_launch_pca_dgrad(pa, s));
             } else
@@ -947,6 +963,8 @@ int sdfa_regress_forward(const sdfa_model *m, const float *d_z, const int64_t *d
                 g.ldp = Nc; g.ldq = m->pca_ld[b]; g.ldd = m->out_dim; g.Ppad = Nc; g.Qpad = m->pca_ld[b]; g.Pstore = N;
                 g.Qreal = m->pca_cols[b]; g.K = m->pca_K[b]; g.seg_k = g.K; g.act = ACT_NONE; g.out_mode = OUT_ROW;
                 g.col_group = m->pca_group[b]; g.col_stride = 9; g.col_off = m->pca_off[b];
+                g.n_extra = n_outs - 1;
+                for (int x = 1; x < n_outs; ++x) g.D_extra[x - 1] = h_d_outs[x] + f0 * m->out_dim;
                 g.terms = stage_terms(m, STAGE_REGRESSOR);
                 HIP_TRY(sdfa_launch_gemm(g, s));
             }

@@ -55,7 +55,10 @@ __device__ __forceinline__ void store_tile(const GemmArgs &a, const f32x16 &acc,
             const int64_t o = a.col_group ? (q / a.col_group) * a.col_stride + a.col_off + q % a.col_group : q;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (p + e < a.Pstore) a.D[(p + e) * a.ldd + o] = v[e];
+                if (p + e < a.Pstore) {
+                    a.D[(p + e) * a.ldd + o] = v[e];
+                    for (int x = 0; x < a.n_extra; ++x) a.D_extra[x][(p + e) * a.ldd + o] = v[e];
+                }
         }
     }
 }

@@ -14,6 +14,7 @@ enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_TANH = 2 };
 #endif
 constexpr int HF_SLAB_ROWS = 2048 + SDFA_HF_PAD;
 enum { OUT_K4 = 0, OUT_ROW = 1 };
+constexpr int SDFA_MAX_DESTS = 8;   // output destinations of the regressor epilogues: the local buffer + up to 7 peers
 
 struct GemmArgs {
     const float *P;      // K4 [K/4][ldp]
@@ -35,6 +36,8 @@ struct GemmArgs {
     int q_slab_rows;
     const int64_t *q_limit;   // device scalar: tiles whose first column is >= *q_limit exit at once (null = no limit)
     int col_group, col_stride, col_off;   // OUT_ROW only: column q is stored at (q / group) * stride + off + q % group (group 0 = identity)
+    float *D_extra[SDFA_MAX_DESTS - 1];   // OUT_ROW only: further destinations with D's layout (see PcaArgs::out_extra)
+    int n_extra;
 };
 hipError_t sdfa_launch_gemm(const GemmArgs &a, hipStream_t s);
 
@@ -45,6 +48,10 @@ struct PcaArgs {
     const float *mean_s, *mean_r;    // [cols_s], [cols_r]
     float *out;                      // [N][out_dim] row-major, triangle-interleaved [s0..s5 r0 r1 r2]
     int64_t N, Nc, out_dim, ld_s, ld_r, cols_s, cols_r;
+    // one-shot direct all-gather: the same rows are ALSO stored to n_extra more base pointers --
+    // this rank's slot in each peer GPU's gathered buffer, mapped over xGMI (or other buffers on this device)
+    float *out_extra[SDFA_MAX_DESTS - 1];
+    int n_extra;
 };
 hipError_t sdfa_launch_pca_dgrad(const PcaArgs &a, hipStream_t s);
 

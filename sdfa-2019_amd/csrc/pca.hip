@@ -103,8 +103,12 @@ __global__ __launch_bounds__(256, 2) void pca_dgrad_kernel(PcaArgs a) {
         for (int i = 0; i < 9; ++i) {
             const int idx = i * 64 + lane, r = idx / 72, c4 = idx % 72;     // row-local mapping r = 4h' + e  <->  frame 8g + 4h' + e
             const int64_t n = frame0 + 8 * g + r;
-            if (n < a.N && 4 * c4 < orow_valid)
-                *reinterpret_cast<float4 *>(a.out + n * a.out_dim + ocol0 + 4 * c4) = *reinterpret_cast<const float4 *>(sRow + r * PCA_ROW + 4 * c4);
+            if (n < a.N && 4 * c4 < orow_valid) {
+                const float4 v = *reinterpret_cast<const float4 *>(sRow + r * PCA_ROW + 4 * c4);
+                const int64_t o = n * a.out_dim + ocol0 + 4 * c4;
+                *reinterpret_cast<float4 *>(a.out + o) = v;
+                for (int x = 0; x < a.n_extra; ++x) *reinterpret_cast<float4 *>(a.out_extra[x] + o) = v;   // peers' gathered buffers
+            }
         }
         WAVE_LDS_FENCE()
     }

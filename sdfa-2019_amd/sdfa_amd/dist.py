@@ -120,3 +120,57 @@ class FrameGatherer:
         if not self.even:
             return self.buf
         return torch.cat([v for r in range(self.world) for v in self.rows(r)], 0)
+
+
+class DirectGatherer:
+    """One-shot direct all-gather over the fully connected xGMI mesh, independent of RCCL's
+    algorithm choice: every rank owns a gathered buffer [sum(counts)][width] in rank order; each rank maps every peer's
+    buffer into its own address space (CUDA/HIP IPC handles, exchanged ONCE through the process group) and its regressor
+    epilogue stores each output row to its own buffer AND to its slot in the 7 peers' buffers
+    (Engine.regress_multi -> sdfa_regress_forward_multi).  One shard crosses each link once; there is no staging copy and no
+    collective in the data path -- `finish()` is a device synchronise plus a barrier, after which every rank holds all rows.
+
+    Works with any control backend ("nccl" or "gloo"): the data moves by peer stores, not through the process group.
+    """
+
+    def __init__(self, counts, row_width, device, group=None):
+        from torch.multiprocessing.reductions import reduce_tensor
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.counts = [int(c) for c in counts]
+        assert len(self.counts) == self.world and self.world <= 8, "direct gather: one destination per rank, at most 8"
+        self.width = int(row_width)
+        self.offsets = [0]
+        for c in self.counts:
+            self.offsets.append(self.offsets[-1] + c)
+        self.device = torch.device(device)
+        self.buf = torch.empty((self.offsets[-1], self.width), dtype=torch.float32, device=self.device)
+        handles = [None] * self.world
+        dist.all_gather_object(handles, reduce_tensor(self.buf), group=group)      # (rebuild function, IPC handle + geometry)
+        self._peers = []                                                            # keeps the mappings alive
+        lo, hi = self.offsets[self.rank], self.offsets[self.rank + 1]
+        self.dests = []                                                             # my slot in every rank's buffer; own buffer first
+        for r in [self.rank] + [r for r in range(self.world) if r != self.rank]:
+            if r == self.rank:
+                t = self.buf
+            else:
+                fn, args = handles[r]
+                t = fn(*args)
+                self._peers.append(t)
+            self.dests.append(t[lo:hi])
+
+    def dest_views(self, f0, f1):
+        """Destinations of this rank's frames [f0, f1): one (f1 - f0, width) view per rank, the local one first."""
+        return [d[f0:f1] for d in self.dests]
+
+    def finish(self):
+        """Every rank's stores are complete and visible: kernels are done (stream synchronise = system-scope release of
+        the peer stores), then all ranks have said so."""
+        torch.cuda.synchronize(self.device)
+        dist.barrier(group=self.group)
+
+    def rows(self, rank):
+        return [self.buf[self.offsets[rank]: self.offsets[rank + 1]]]
+
+    def gathered(self):
+        return self.buf

@@ -189,6 +189,29 @@ class Engine(FrontendOnly):
                                        _ptr(ws), ws.numel(), _stream()))
         return coef, out
 
+    def regress_multi(self, z, speaker_id, outs, want_coef=False, check_ids=True):
+        """`outs`: 1..8 float32 (n, out_dim) destination tensors (or raw device pointers as ints): every one receives the
+        same rows, written by the regressor's epilogue itself (sdfa_regress_forward_multi -- the direct all-gather path)."""
+        n = z.shape[0]
+        z = z.contiguous()
+        if check_ids:
+            self.check_speaker_ids(speaker_id)
+        spk = speaker_id.to(device=self.device, dtype=torch.int64).contiguous()
+        coef = torch.empty((n, self.coef_dim), dtype=torch.float32, device=self.device) if want_coef else None
+        if n == 0:
+            return coef
+        ptrs = []
+        for o in outs:
+            if torch.is_tensor(o):
+                assert o.is_cuda and o.dtype == torch.float32 and o.is_contiguous() and tuple(o.shape) == (n, self.out_dim)
+                ptrs.append(o.data_ptr())
+            else:
+                ptrs.append(int(o))
+        arr = (C.c_void_p * len(ptrs))(*ptrs)
+        ws = self.workspace(n)
+        check(lib.sdfa_regress_forward_multi(self._m, _ptr(z), _ptr(spk), n, _ptr(coef), arr, len(ptrs), _ptr(ws), ws.numel(), _stream()))
+        return coef
+
     def forward(self, audio_feat, speaker_id, want_coef=False):
         z, align = self.encoder(audio_feat)
         coef, out = self.regress(z, speaker_id, want_coef=want_coef)

@@ -103,3 +103,22 @@ def make_pcm(clip_index, n_samples, kind="uniform"):
         y = np.convolve(x, np.ones(8) / 8, mode="same") * env * 0.9
         return np.clip(y, -0.999, 0.999).astype(np.float32)
     raise ValueError(kind)
+
+
+def make_template_mesh(seed=7):
+    """Synthetic template of FLAME's size for timing the mesh stage (the licensed FLAME geometry is not shipped): an open
+    117 x 44 grid = 5148 vertices, 9976 triangles (the model's triangle count), 3887 vertices constrained -> 1261 free, FLAME's
+    free-vertex count with the reference's non_face mask (speech_anime/datasets/vocaset/mask/non_face.py).
+    Returns (verts float32 (V, 3), faces uint32 (9976, 3), constraint indices uint32)."""
+    nx, ny = 117, 44
+    rs = np.random.RandomState(seed)
+    x, y = np.meshgrid(np.arange(nx) * 0.0015, np.arange(ny) * 0.003, indexing="ij")
+    V = np.stack([x, y, 0.02 * np.sin(20 * x) * np.cos(15 * y)], -1).reshape(-1, 3).astype(np.float32)
+    V += rs.normal(0, 1e-4, V.shape).astype(np.float32)
+    idx = lambda i, j: i * ny + j
+    F = np.asarray([[idx(i, j), idx(i + 1, j), idx(i + 1, j + 1)] for i in range(nx - 1) for j in range(ny - 1)] +
+                   [[idx(i, j), idx(i + 1, j + 1), idx(i, j + 1)] for i in range(nx - 1) for j in range(ny - 1)], np.uint32)
+    assert len(F) == N_TRI
+    n_free = 1261
+    cn = np.sort(rs.choice(len(V), len(V) - n_free, replace=False)).astype(np.uint32)
+    return V, F, cn

@@ -51,5 +51,34 @@ def train_model(args):
 
 
 def jit_trace(args):
-    raise NotImplementedError("torch.jit tracing does not apply: the model is a HIP library behind a C ABI; "
-                              "the traced I/O contract (audio_feat (1,64,128,3), speaker_id (1,)) is SpeechDrivenAnimation.forward")
+    """speech_anime/api.py:136-167: trace the inner model on the example inputs that fix its I/O contract --
+    audio_feat = rand(1, 64, 128, 3), speaker_id = zeros(1, long) -- and save `<traced_dump_path>-gpu.zip`.
+
+    The traced graph is two custom operators, torch.ops.sdfa.encoder and torch.ops.sdfa.regress (sdfa_amd/ops.py), keyed by
+    the checkpoint path: `import sdfa_amd.ops; torch.jit.load(...)` in a fresh process loads the checkpoint on first use.
+    The reference also saves a `-cpu.zip`; this build has no CPU path, so that file is not written (said on stdout)."""
+    import sdfa_amd.ops as ops
+    args = args if isinstance(args, dict) else vars(args)
+    hparams = configure(args)
+    assert args.get("traced_dump_path") is not None
+    if hparams.get("load_from") is None:
+        raise ValueError("--load_from <checkpoint> is required for tracing")
+    path = os.path.abspath(os.path.expanduser(hparams.load_from))
+    if not os.path.exists(path) and hparams.get("log_dir"):                # api.py:143-150: also looked up under <log_dir>/checkpoints
+        for cand in (os.path.join(hparams.log_dir, "checkpoints", hparams.load_from), os.path.join(hparams.log_dir, "checkpoints", hparams.load_from + ".ckpt")):
+            if os.path.exists(cand):
+                path = os.path.abspath(cand)
+    ckpt = _load_checkpoint(path)
+    hparams.set_key("model_key", path)
+    model = build_model(hparams, ckpt["state"])
+    head = "dgrad" if hparams.model.face_data_type == "dgrad_3d" else "offsets"
+    mod = ops.TraceableSpeechDrivenAnimation(path, head).eval()
+    dev = model._model._engine.device
+    audio_feat = torch.rand(1, 64, 128, 3, device=dev)
+    speaker_id = torch.zeros(1, dtype=torch.long, device=dev)
+    traced = torch.jit.trace(mod, (audio_feat, speaker_id))
+    out = os.path.splitext(args["traced_dump_path"])[0] + "-gpu.zip"
+    os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
+    traced.save(out)
+    print(f"[speech_anime] traced model -> {out}; no -cpu.zip: the MI355X build has no CPU implementation")
+    return traced

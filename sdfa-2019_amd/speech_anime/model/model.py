@@ -12,6 +12,7 @@ import torch
 
 from sdfa_amd.engine import Engine
 from sdfa_amd import weights as _weights
+from sdfa_amd import ops as _ops
 from ..datasets import DatasetSlidingWindow
 from .. import audio as _audio
 from .. import stream as _stream
@@ -32,6 +33,7 @@ class SpeechDrivenAnimation:
             raise RuntimeError(f"checkpoint holds a '{head}' output module but hparams.model.face_data_type = {self._face_type}")
         self._engine = Engine(state_dict, device=self.hp.get("device", "cuda:0") or "cuda:0",
                               precision=self.hp.get("precision", "fp32") or "fp32", strict=strict)
+        self._key = _ops.register_model(self.hp.get("model_key") or f"speech_anime@{id(self):x}", self._engine)
         return self
 
     def eval(self):
@@ -49,10 +51,11 @@ class SpeechDrivenAnimation:
         eng = self._engine
         x = audio_feat.to(device=eng.device, dtype=torch.float32)
         n = x.shape[0]
-        z, align = eng.encoder(x, want_align=isinstance(align_dict, dict))
+        # the arithmetic is two dispatcher-visible PyTorch-ROCm custom ops over the C ABI (sdfa_amd/ops.py)
+        z, align = torch.ops.sdfa.encoder(x.contiguous(), self._key)
         if isinstance(align_dict, dict):
             align_dict["audio_encoder10"] = align.view(n, 1, 64)
-        _, out = eng.regress(z, speaker_id)
+        out = torch.ops.sdfa.regress(z, speaker_id.to(eng.device), self._key)
         z_audio = z.view(n, 1, 512)
         if self._face_type == "dgrad_3d":
             tri = out.view(n, 1, -1, 9)

@@ -23,7 +23,7 @@ def test_gpu_mesh_matches_reference_fixture(golden):
     out = ms.get_mesh(torch.from_numpy(g["dgrad"]).cuda()).cpu().numpy()
     assert out.shape == g["mesh"].shape
     assert np.abs(out - g["mesh"]).max() <= 2e-6, np.abs(out - g["mesh"]).max()    # coordinates are O(0.1); float32 output
-    assert np.array_equal(out[0], g["verts"])                                       # zero dgrad: template, exactly
+    assert np.abs(out[0] - g["verts"]).max() <= 1e-9                               # zero dgrad: the template (up to the reg * Inv * x_t of the regularised system, ~1e-16)
     cn = g["cnsts"]
     assert np.array_equal(out[:, cn], np.broadcast_to(g["verts"][cn], out[:, cn].shape))   # constraints pinned
     one = ms.get_mesh(g["dgrad"][2])                                                # single-frame numpy call

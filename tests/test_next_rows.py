@@ -100,7 +100,7 @@ def test_gpu_mesh_at_flame_size_vs_reference_module(golden):
     assert out.shape == (5, 5023, 3)
     err = np.abs(out - g["mesh"]).reshape(5, -1).max(1)
     assert err.max() <= 2e-6, err                                                   # coordinates O(0.1), float32 output
-    assert np.array_equal(out[4], g["verts"])                                       # zero dgrad: the template, exactly
+    assert np.abs(out[4] - g["verts"]).max() <= 1e-9                                # zero dgrad: the template (regulariser term ~1e-16)
     cn = g["cnsts"]
     assert np.array_equal(out[:, cn], np.broadcast_to(g["verts"][cn], out[:, cn].shape))
 
@@ -137,7 +137,7 @@ def test_gpu_mesh_triangle_correspondences(golden):
     out = ms.get_mesh(torch.from_numpy(g["dgrad"]).cuda()).cpu().numpy()
     assert out.shape == g["mesh"].shape
     assert np.abs(out - g["mesh"]).max() <= 2e-6, np.abs(out - g["mesh"]).max()
-    assert np.array_equal(out[0], g["verts"])                                       # zero dgrad: identity everywhere -> template
+    assert np.abs(out[0] - g["verts"]).max() <= 1e-9                                # zero dgrad: identity everywhere -> template
     from sdfa_amd._lib import SdfaError
     with pytest.raises(SdfaError):                                                  # corr_faces of the wrong length
         MeshSolver(g["verts"], g["faces"], g["cnsts"], corr_count=g["corr_count"], corr_faces=g["corr_faces"][:-1], n_src_tris=500)

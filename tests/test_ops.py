@@ -1,0 +1,114 @@
+"""torch.ops.sdfa.* -- the PyTorch-ROCm custom-operator face of the C ABI (BASELINE north_star)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from sdfa_amd import ops, synth
+
+
+class _Stub:
+    out_dim, coef_dim = 89784, 265
+
+
+def test_ops_are_registered_with_schemas():
+    assert str(torch.ops.sdfa.encoder.default._schema) == "sdfa::encoder(Tensor audio_feat, str model) -> (Tensor, Tensor)"
+    assert str(torch.ops.sdfa.regress.default._schema) == "sdfa::regress(Tensor z, Tensor speaker_id, str model) -> Tensor"
+    assert "sdfa::mel_frontend(Tensor pcm, Tensor clip_off, Tensor clip_len, Tensor frame_clip, Tensor frame_start" in str(torch.ops.sdfa.mel_frontend.default._schema)
+    assert "sdfa::regress_coef" in str(torch.ops.sdfa.regress_coef.default._schema)
+
+
+def test_frame_index_op_is_the_bit_exact_host_enumeration(golden):
+    g = golden["tslist"]
+    for key in g.files:
+        sr, L = int(key.split("_")[0][2:]), int(key.split("_L")[1])
+        starts, ts = torch.ops.sdfa.frame_index(L, sr, 60, 100)
+        assert starts.dtype == torch.int64 and ts.dtype == torch.int32
+        assert np.array_equal(ts.numpy(), g[key])
+
+
+def test_fake_tensor_shapes_without_a_gpu():
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    ops.register_model("stub-dgrad", _Stub())
+    with FakeTensorMode():
+        x = torch.empty((7, 64, 128, 3), device="cuda")
+        spk = torch.empty(7, dtype=torch.int64, device="cuda")
+        z, al = torch.ops.sdfa.encoder(x, "stub-dgrad")
+        assert z.shape == (7, 512) and al.shape == (7, 64) and z.device.type == "cuda"
+        assert torch.ops.sdfa.regress(z, spk, "stub-dgrad").shape == (7, 89784)
+        assert torch.ops.sdfa.regress_coef(z, spk, "stub-dgrad").shape == (7, 265)
+        feat = torch.ops.sdfa.mel_frontend(torch.empty(1000, device="cuda"), torch.empty(1, dtype=torch.int64, device="cuda"),
+                                           torch.empty(1, dtype=torch.int64, device="cuda"), torch.empty(9, dtype=torch.int32, device="cuda"),
+                                           torch.empty(9, dtype=torch.int64, device="cuda"), 16000)
+        assert feat.shape == (9, 64, 128, 3)
+        (s, r), za = ops.TraceableSpeechDrivenAnimation("stub-dgrad", "dgrad")(x, spk)
+        assert s.shape == (7, 1, 9976, 6) and r.shape == (7, 1, 9976, 3) and za.shape == (7, 1, 512)
+
+
+def test_device_ops_have_no_cpu_kernel():
+    ops.register_model("stub-dgrad", _Stub())
+    with pytest.raises(NotImplementedError):
+        torch.ops.sdfa.encoder(torch.zeros(1, 64, 128, 3), "stub-dgrad")
+    with pytest.raises(KeyError):
+        ops._model("never-registered")
+
+
+@pytest.mark.gpu
+def test_ops_match_engine_and_compose(synth_sd, golden):
+    from sdfa_amd.engine import Engine
+    eng = Engine(synth_sd["dgrad"])
+    key = ops.register_model("t-dgrad", eng)
+    g = golden["model_dgrad"]
+    x = torch.from_numpy(g["audio_feat"]).cuda()
+    spk = torch.full((x.shape[0],), 2, dtype=torch.int64, device="cuda")
+    z, al = torch.ops.sdfa.encoder(x, key)
+    out = torch.ops.sdfa.regress(z, spk, key)
+    ref_out, ref_z, ref_al, _ = eng.forward(x, spk)
+    assert torch.equal(out, ref_out) and torch.equal(z, ref_z) and torch.equal(al, ref_al)
+    assert np.abs(out.cpu().numpy()[:, ::97] - g["dgrad_stride97"]).max() <= 1e-4
+    coef = torch.ops.sdfa.regress_coef(z, spk, key)
+    assert np.abs(coef.cpu().numpy()[:, :85] - g["coef_scale"][:, 0]).max() <= 1e-4
+    # front-end op against the engine's own call
+    pcm = synth.make_pcm(0, 2 * 16000)
+    feat, tslists, _ = eng.mel_frontend([pcm], 16000)
+    starts, ts = torch.ops.sdfa.frame_index(len(pcm), 16000, 60, 100)
+    f2 = torch.ops.sdfa.mel_frontend(torch.from_numpy(pcm).cuda(), torch.zeros(1, dtype=torch.int64, device="cuda"),
+                                     torch.tensor([len(pcm)], dtype=torch.int64, device="cuda"),
+                                     torch.zeros(len(starts), dtype=torch.int32, device="cuda"), starts.cuda(), 16000)
+    assert torch.equal(feat, f2) and ts.tolist() == tslists[0]
+    # dispatcher-visible: torch.compile traces through the fake-tensor shape functions (aot_eager: no code generation needed)
+    mod = ops.TraceableSpeechDrivenAnimation(key, "dgrad")
+    (s0, r0), z0 = mod(x, spk)
+    (s1, r1), z1 = torch.compile(mod, backend="aot_eager")(x, spk)
+    assert torch.equal(s0, s1) and torch.equal(r0, r1) and torch.equal(z0, z1)
+
+
+@pytest.mark.gpu
+def test_jit_trace_contract_and_reload_in_a_fresh_process(tmp_path, synth_sd):
+    """api.py:136-167: trace on (rand(1,64,128,3), zeros(1, long)), save <path>-gpu.zip; a new process loads and runs it."""
+    from speech_anime.api import jit_trace
+    from speech_anime.datasets import DatasetSlidingWindow
+    ck = tmp_path / "epoch0050.ckpt"
+    torch.save({"epoch": 50, "global_step": 1, "state": {k: torch.from_numpy(np.array(v)) for k, v in synth_sd["dgrad"].items()}}, str(ck))
+    DatasetSlidingWindow.hparams = None
+    traced = jit_trace(dict(mode="trace", load_from=str(ck), custom_hparams="dgrad", traced_dump_path=str(tmp_path / "traced.zip")))
+    zip_path = tmp_path / "traced-gpu.zip"
+    assert zip_path.exists()
+    x = torch.rand(3, 64, 128, 3, device="cuda")           # another batch size than the traced example
+    spk = torch.tensor([0, 2, 5], device="cuda")
+    (s, r), z = traced(x, spk)
+    assert s.shape == (3, 1, 9976, 6) and r.shape == (3, 1, 9976, 3) and z.shape == (3, 1, 512)
+    torch.save({"x": x.cpu(), "spk": spk.cpu(), "s": s.cpu(), "r": r.cpu(), "z": z.cpu()}, str(tmp_path / "io.pt"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch; sys.path.insert(0, sys.argv[1]); import sdfa_amd.ops\n"
+        "m = torch.jit.load(sys.argv[2]); io = torch.load(sys.argv[3])\n"
+        "(s, r), z = m(io['x'].cuda(), io['spk'].cuda())\n"
+        "assert torch.equal(s.cpu(), io['s']) and torch.equal(r.cpu(), io['r']) and torch.equal(z.cpu(), io['z'])\n"
+        "print('reload ok')\n")
+    res = subprocess.run([sys.executable, "-c", code, os.path.join(root, "sdfa-2019_amd"), str(zip_path), str(tmp_path / "io.pt")],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "reload ok" in res.stdout, res.stderr[-2000:]
