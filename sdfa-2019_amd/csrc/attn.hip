@@ -5,80 +5,104 @@
 //     score[t] = v . tanh(qp[:, n] + kp[:, t, n] + b)          t = 0..63
 //     align    = softmax_t(score * 1.0)                         (scale_score_at_eval = 1.0)
 //     ctx      = sum_t align[t] * x[:, t, n]                    (torch.bmm(align, value))
-// One workgroup = 64 consecutive frames (one per lane) so that every global access is a 1 KiB
-// contiguous run of the K4 [feature/4][t*Nc + n] arrays; the 64-way softmax is reduced through LDS.
+// One workgroup = 16 consecutive frames (Nc / 16 workgroups: 512 for an 8192-frame chunk, two per CU), lane = (frame,
+// part p = 0..3).  The kernel is a stream over H (128 KiB per frame) and KP (32 KiB per frame): every global access is a
+// 256-byte run of the K4 [feature/4][t*Nc + n] arrays per quarter wave, 8-16 independent requests in flight per lane.
+//   scores : wave w owns time steps 16w..16w+15 and ALL 128 units -- each quarter wave sums 32 of them, two __shfl_xor
+//            steps combine the quarters, so a score is complete inside its wave (no partial sums through LDS);
+//   softmax: wavefront-reduced, once: each wave keeps its 16 scores in registers, reduces (max, sum of exp) over them,
+//            and the four (max, sum) pairs per frame meet in LDS; align = exp(s - M) / sum over waves of sum_w * exp(m_w - M);
+//   context: the 64 weights of a frame go through LDS once; wave w / part p accumulates feature quads 32w+8p .. +7.
 #include "common.h"
 #include "kernels.h"
 
 namespace {
 
-__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
-    __shared__ float sPart[4][64][64];   // [wave][t][frame] partial scores
-    __shared__ float sAlign[64][64];     // [t][frame]
+constexpr int ATT_FR = 16;   // frames per workgroup
+
+__global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
+    __shared__ float sAlign[64][ATT_FR];     // [t][frame]
+    __shared__ float2 sStat[4][ATT_FR];      // per wave: (max, sum of exp) over its 16 time steps
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t n = (int64_t)blockIdx.x * 64 + lane;
+    const int fr = lane & 15, part = lane >> 4;
+    const int64_t n = (int64_t)blockIdx.x * ATT_FR + fr;
     const float4 *__restrict__ KP = reinterpret_cast<const float4 *>(a.KP);
     const float4 *__restrict__ QP = reinterpret_cast<const float4 *>(a.QP);
     const float4 *__restrict__ H = reinterpret_cast<const float4 *>(a.H);
 
-    // ---- scores: wave w sums units 32w .. 32w+31
-    float4 qb[8], vv[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        float4 qp = QP[(int64_t)(8 * wave + q) * a.Nc + n];
-        float4 bb = ld4(a.b + (8 * wave + q) * 4);
-        qb[q] = make_float4(qp.x + bb.x, qp.y + bb.y, qp.z + bb.z, qp.w + bb.w);
-        vv[q] = ld4(a.v + (8 * wave + q) * 4);
-    }
-    for (int t = 0; t < 64; ++t) {
-        float s = 0.f;
+    // ---- scores: this quarter wave sums units 32p .. 32p+31 (quads 8p .. 8p+7)
+    float sc[16];
+    {
+        float4 qb[8], vv[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            float4 k = KP[(int64_t)(8 * wave + q) * a.Mc + (int64_t)t * a.Nc + n];
-            s += vv[q].x * tanhf_acc(qb[q].x + k.x);
-            s += vv[q].y * tanhf_acc(qb[q].y + k.y);
-            s += vv[q].z * tanhf_acc(qb[q].z + k.z);
-            s += vv[q].w * tanhf_acc(qb[q].w + k.w);
+            const float4 qp = QP[(int64_t)(8 * part + q) * a.Nc + n];
+            const float4 bb = ld4(a.b + (8 * part + q) * 4);
+            qb[q] = make_float4(qp.x + bb.x, qp.y + bb.y, qp.z + bb.z, qp.w + bb.w);
+            vv[q] = ld4(a.v + (8 * part + q) * 4);
         }
-        sPart[wave][t][lane] = s;
+        const float4 *__restrict__ kp = KP + (int64_t)(8 * part) * a.Mc + (int64_t)(16 * wave) * a.Nc + n;
+#pragma unroll 2
+        for (int tt = 0; tt < 16; ++tt) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 k = kp[(int64_t)q * a.Mc + (int64_t)tt * a.Nc];
+                s += vv[q].x * tanhf_acc(qb[q].x + k.x);
+                s += vv[q].y * tanhf_acc(qb[q].y + k.y);
+                s += vv[q].z * tanhf_acc(qb[q].z + k.z);
+                s += vv[q].w * tanhf_acc(qb[q].w + k.w);
+            }
+            s += __shfl_xor(s, 16);                // (p0 + p1), (p2 + p3) -- the same bits on both sides of each pair
+            s += __shfl_xor(s, 32);                // all four quarters hold the complete score of (t = 16w + tt, frame)
+            sc[tt] = s;
+        }
     }
+    // ---- softmax over the 64 time steps of a frame: local (max, sum) per wave, combined through LDS
+    float mw = sc[0];
+#pragma unroll
+    for (int tt = 1; tt < 16; ++tt) mw = fmaxf(mw, sc[tt]);
+    float sw = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < 16; ++tt) { sc[tt] = __expf(sc[tt] - mw); sw += sc[tt]; }
+    if (part == 0) sStat[wave][fr] = make_float2(mw, sw);
     __syncthreads();
-    // ---- softmax over t (every wave redundantly; wave w publishes t = 16w .. 16w+15)
-    float mx = -3.0e38f;
-    for (int t = 0; t < 64; ++t) {
-        float s = sPart[0][t][lane] + sPart[1][t][lane] + sPart[2][t][lane] + sPart[3][t][lane];
-        mx = fmaxf(mx, s);
-    }
+    float M = -3.0e38f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) M = fmaxf(M, sStat[w][fr].x);
     float den = 0.f;
-    for (int t = 0; t < 64; ++t) {
-        float s = sPart[0][t][lane] + sPart[1][t][lane] + sPart[2][t][lane] + sPart[3][t][lane];
-        den += __expf(s - mx);
-    }
-    const float inv = 1.0f / den;
-    for (int t = 16 * wave; t < 16 * wave + 16; ++t) {
-        float s = sPart[0][t][lane] + sPart[1][t][lane] + sPart[2][t][lane] + sPart[3][t][lane];
-        float al = __expf(s - mx) * inv;
-        sAlign[t][lane] = al;
-        if (a.align_out && n < a.N) a.align_out[n * 64 + t] = al;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) den += sStat[w][fr].y * __expf(sStat[w][fr].x - M);
+    const float scale = __expf(mw - M) / den;      // exp(s - M) = exp(s - mw) * exp(mw - M)
+#pragma unroll
+    for (int tt = 0; tt < 16; ++tt) {
+        const float al = sc[tt] * scale;
+        if ((tt & 3) == part) {                    // the quarters hold the same values: each publishes every fourth time step
+            sAlign[16 * wave + tt][fr] = al;
+            if (a.align_out && n < a.N) a.align_out[n * 64 + 16 * wave + tt] = al;
+        }
     }
     __syncthreads();
-    // ---- context: wave w owns feature quads 32w .. 32w+31
-    float4 acc[32];
+    // ---- context: feature quads 32w + 8p .. + 7 of this lane's frame
+    float4 acc[8];
 #pragma unroll
-    for (int q = 0; q < 32; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < 8; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 *__restrict__ hp = H + (int64_t)(32 * wave + 8 * part) * a.Mc + n;
+#pragma unroll 2
     for (int t = 0; t < 64; ++t) {
-        const float al = sAlign[t][lane];
+        const float al = sAlign[t][fr];
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            float4 x = H[(int64_t)(32 * wave + q) * a.Mc + (int64_t)t * a.Nc + n];
+        for (int q = 0; q < 8; ++q) {
+            const float4 x = hp[(int64_t)q * a.Mc + (int64_t)t * a.Nc];
             acc[q].x += al * x.x; acc[q].y += al * x.y; acc[q].z += al * x.z; acc[q].w += al * x.w;
         }
     }
 #pragma unroll
-    for (int q = 0; q < 32; ++q) {
-        st4(a.Zk4 + ((int64_t)(32 * wave + q) * a.Nc + n) * 4, acc[q]);
-        if (a.z_out && n < a.N) st4(a.z_out + n * 512 + (32 * wave + q) * 4, acc[q]);
+    for (int q = 0; q < 8; ++q) {
+        const int fq = 32 * wave + 8 * part + q;
+        st4(a.Zk4 + ((int64_t)fq * a.Nc + n) * 4, acc[q]);
+        if (a.z_out && n < a.N) st4(a.z_out + n * 512 + fq * 4, acc[q]);
     }
 }
 
@@ -132,7 +156,7 @@ __global__ void tap_kernel(const float *__restrict__ src, int what, int64_t N, i
 }  // namespace
 
 hipError_t sdfa_launch_attn(const AttnArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(attn_kernel, dim3((unsigned)(a.Nc / 64)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_kernel, dim3((unsigned)(a.Nc / ATT_FR)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -152,6 +152,9 @@ __global__ __launch_bounds__(256, WGS) void freq_lstm_kernel(FreqLstmArgs a) {
         _Pragma("unroll") for (int j = 0; j < NJ; ++j) mfma4(acc[3][j], W3, B[j]); \
     }
         FL_LOAD(0, wa0, wa1, wa2, wa3, ba)
+        // the wave in its MFMA phase outranks the partner wave (of the CU's other workgroup) that is in its cell update /
+        // staging phase at the SIMD's issue port: +0.8 % (A/B in profiles/r02_ab.txt; priorities 1, 2, 3 measure the same)
+        __builtin_amdgcn_s_setprio(1);
         LSTAMP(q1)
 #ifdef SDFA_STAMPS
         s_init += q1 - q0;
@@ -177,6 +180,7 @@ __global__ __launch_bounds__(256, WGS) void freq_lstm_kernel(FreqLstmArgs a) {
         }
 #undef FL_LOAD
 #undef FL_MFMA
+        __builtin_amdgcn_s_setprio(0);
         LSTAMP(q2)
         __syncthreads();   // every wave has finished reading sH / sX[cur]
         LSTAMP(q3)
@@ -426,7 +430,11 @@ __global__ __launch_bounds__(512, 2) void time_lstm_kernel(TimeLstmArgs a) {
     // are requested one step AHEAD, quad by quad, as the cell update releases the registers -- requested at the top of
     // the step they would put an HBM round trip in front of every step's first MFMA (all 8 waves wait in lock-step).
     f32x16 acc[4][NT];
-#define TL_GX(t_, gt, g, j) GX[(int64_t)(dir * 256 + wave * 32 + (gt) * 8 + 2 * (g) + h) * a.Mc + (int64_t)(t_) * a.Nc + n0 + l31 + (j) * 32]
+    // per-lane base + wave-uniform offsets (scalar registers) instead of 32 lane addresses the optimiser would hoist out of
+    // the step loop and spill (the kernel sits at the 256-register limit)
+    const float4 *__restrict__ GXl = GX + (int64_t)(dir * 256 + wave * 32 + h) * a.Mc + n0 + l31;
+    float4 *__restrict__ Hl = H + (int64_t)(dir * 64 + wave * 8 + h) * a.Mc + n0 + l31;
+#define TL_GX(t_, gt, g, j) GXl[(int64_t)((gt) * 8 + 2 * (g)) * a.Mc + (int64_t)(t_) * a.Nc + (j) * 32]
 #pragma unroll
     for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
@@ -437,25 +445,27 @@ __global__ __launch_bounds__(512, 2) void time_lstm_kernel(TimeLstmArgs a) {
                 acc[gt][j][4 * g + 0] = v.x; acc[gt][j][4 * g + 1] = v.y; acc[gt][j][4 * g + 2] = v.z; acc[gt][j][4 * g + 3] = v.w;
             }
 
+    // recurrent weights one k-block ahead, two alternating register sets, branch-free (see freq_lstm_kernel).  The request
+    // that wraps around at the end of a step's K loop IS k-block 0 of the next step: `wa` stays live across the cell update
+    // and the step barrier, so the first MFMAs after the barrier (all 8 waves start together) do not wait for an L2 round trip.
+    const float4 *__restrict__ wp = Ww + h * 1024;
+    float4 wa[4], wb[4];
+#define TL_LOAD(kb, W) { const float4 *__restrict__ wq = wp + (kb) * 2048; W[0] = wq[0]; W[1] = wq[32]; W[2] = wq[64]; W[3] = wq[96]; }
+    TL_LOAD(0, wa)
     for (int s = 0; s < 64; ++s) {
         const int t = dir ? 63 - s : s;
         const int tn = dir ? t - 1 : t + 1;
-        const int64_t mcol = (int64_t)t * a.Nc + n0 + l31;
+        const int64_t tcol = (int64_t)t * a.Nc;
         const float4 *sHc = sHt + (size_t)(s & 1) * 64 * BT;
         float4 *sHn = sHt + (size_t)((s & 1) ^ 1) * 64 * BT;
 
         if (s > 0) {
-            // recurrent weights one k-block ahead, two alternating register sets, branch-free (see freq_lstm_kernel)
-            const float4 *__restrict__ wp = Ww + h * 1024;
-            float4 wa[4], wb[4];
-#define TL_LOAD(kb, W) { const float4 *__restrict__ wq = wp + (kb) * 2048; W[0] = wq[0]; W[1] = wq[32]; W[2] = wq[64]; W[3] = wq[96]; }
 #define TL_MFMA(kb, W)                                                                    \
     {                                                                                     \
         float4 bq[NT];                                                                    \
         _Pragma("unroll") for (int j = 0; j < NT; ++j) bq[j] = sHc[(2 * (kb) + h) * BT + j * 32 + l31]; \
         mfma_block<4, NT>(acc, W, bq);                                                    \
     }
-            TL_LOAD(0, wa)
 #pragma unroll 1
             for (int kb = 0; kb < 32; kb += 2) {
                 TL_LOAD(kb + 1, wb)
@@ -466,7 +476,6 @@ __global__ __launch_bounds__(512, 2) void time_lstm_kernel(TimeLstmArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 TL_MFMA(kb + 1, wb)
             }
-#undef TL_LOAD
 #undef TL_MFMA
         }
 #pragma unroll
@@ -477,7 +486,7 @@ __global__ __launch_bounds__(512, 2) void time_lstm_kernel(TimeLstmArgs a) {
                 lstm_cell_quad(acc[0][j], acc[1][j], acc[2][j], acc[3][j], c[j], g, hq);
                 const int hq_idx = 8 * wave + 2 * g + h;
                 sHn[hq_idx * BT + j * 32 + l31] = hq;
-                H[(int64_t)(dir * 64 + hq_idx) * a.Mc + mcol + j * 32] = hq;
+                Hl[(int64_t)(2 * g) * a.Mc + tcol + j * 32] = hq;
                 if (s + 1 < 64) {   // this quad's gate registers are free: request the next step's input projection into them
 #pragma unroll
                     for (int gt = 0; gt < 4; ++gt) {
@@ -489,6 +498,104 @@ __global__ __launch_bounds__(512, 2) void time_lstm_kernel(TimeLstmArgs a) {
         __syncthreads();   // h_s complete in sHn before anyone reads it; sHc free for step s+1's writes
     }
 #undef TL_GX
+#undef TL_LOAD
+}
+
+// The same recurrence as 4-wave workgroups of 32 frames: a wave owns TWO hidden blocks (acc[4 gates][2 blocks], the same
+// 8 accumulator tiles as the 64-frame shape), LDS 64 KiB, so TWO workgroups share a CU and run out of phase -- the cell
+// update and step barrier of one overlap the other's MFMAs (the 8-wave shape leaves the matrix pipe idle there: MfmaUtil
+// 73 %).  Each weight quad now feeds one column tile instead of two, i.e. twice the L2 -> register weight traffic per
+// MFMA.  Same k order and same cell arithmetic: bit-identical to time_lstm_kernel.
+__global__ __launch_bounds__(256, 2) void time_lstm_pair_kernel(TimeLstmArgs a) {
+    extern __shared__ float4 sHt[];   // [2][64 k-quads][32 sequences]
+    constexpr int BT = 32;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // 4 waves: hidden blocks 2w, 2w+1
+    const int l31 = lane & 31, h = lane >> 5;
+    const int dir = blockIdx.x & 1;                                   // the directions share no data (separate gate rows of GX)
+    const int64_t n0 = (int64_t)(blockIdx.x >> 1) * BT;
+
+    const float4 *__restrict__ GX = reinterpret_cast<const float4 *>(a.GX);
+    const float4 *__restrict__ Ww = reinterpret_cast<const float4 *>(a.W) + (size_t)dir * 64 * 1024 + wave * 256 + l31;
+    float4 *__restrict__ H = reinterpret_cast<float4 *>(a.H);
+
+    f32x16 c[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[b][r] = 0.f;
+
+    f32x16 acc[4][2];     // [gate][hidden block of this wave]
+    // per-lane base + wave-uniform offsets (scalar registers): 32 hoisted 64-bit lane addresses would not fit the register file
+    const float4 *__restrict__ GXl = GX + (int64_t)(dir * 256 + wave * 64 + h) * a.Mc + n0 + l31;
+    float4 *__restrict__ Hl = H + (int64_t)(dir * 64 + wave * 16 + h) * a.Mc + n0 + l31;
+#define TP_GX(t_, gt, g, b) GXl[(int64_t)((b) * 32 + (gt) * 8 + 2 * (g)) * a.Mc + (int64_t)(t_) * a.Nc]
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const float4 v = TP_GX(dir ? 63 : 0, gt, g, b);
+                acc[gt][b][4 * g + 0] = v.x; acc[gt][b][4 * g + 1] = v.y; acc[gt][b][4 * g + 2] = v.z; acc[gt][b][4 * g + 3] = v.w;
+            }
+
+    for (int s = 0; s < 64; ++s) {
+        const int t = dir ? 63 - s : s;
+        const int tn = dir ? t - 1 : t + 1;
+        const int64_t tcol = (int64_t)t * a.Nc;
+        const float4 *sHc = sHt + (size_t)(s & 1) * 64 * BT;
+        float4 *sHn = sHt + (size_t)((s & 1) ^ 1) * 64 * BT;
+
+        if (s > 0) {
+            // one hidden block after the other: the K loop of time_lstm_kernel (4 weight quads per k-block, two alternating
+            // register sets) run twice -- eight quads in flight for both blocks at once do not fit the 256 registers
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const float4 *__restrict__ wp = Ww + h * 1024 + b * 128;
+                float4 wa[4], wb[4];
+#define TP_LOAD(kb, W) { const float4 *__restrict__ wq = wp + (kb) * 2048; W[0] = wq[0]; W[1] = wq[32]; W[2] = wq[64]; W[3] = wq[96]; }
+#define TP_MFMA(kb, W)                                                                    \
+    {                                                                                     \
+        const float4 bq = sHc[(2 * (kb) + h) * BT + l31];                                 \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                     \
+        _Pragma("unroll") for (int gt = 0; gt < 4; ++gt)                                  \
+            acc[gt][b] = MFMA(SDFA_OP(f4c(W[gt], q)), SDFA_OP(f4c(bq, q)), acc[gt][b]);   \
+    }
+                TP_LOAD(0, wa)
+#pragma unroll 1
+                for (int kb = 0; kb < 32; kb += 2) {
+                    TP_LOAD(kb + 1, wb)
+                    __builtin_amdgcn_sched_barrier(0);
+                    TP_MFMA(kb, wa)
+                    const int kn = kb + 2 < 32 ? kb + 2 : 0;
+                    TP_LOAD(kn, wa)
+                    __builtin_amdgcn_sched_barrier(0);
+                    TP_MFMA(kb + 1, wb)
+                }
+#undef TP_LOAD
+#undef TP_MFMA
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 hq;
+                lstm_cell_quad(acc[0][b], acc[1][b], acc[2][b], acc[3][b], c[b], g, hq);
+                sHn[(8 * (2 * wave + b) + 2 * g + h) * BT + l31] = hq;
+                Hl[(int64_t)(8 * b + 2 * g) * a.Mc + tcol] = hq;
+                if (s + 1 < 64) {
+#pragma unroll
+                    for (int gt = 0; gt < 4; ++gt) {
+                        const float4 v = TP_GX(tn, gt, g, b);
+                        acc[gt][b][4 * g + 0] = v.x; acc[gt][b][4 * g + 1] = v.y; acc[gt][b][4 * g + 2] = v.z; acc[gt][b][4 * g + 3] = v.w;
+                    }
+                }
+            }
+        __syncthreads();
+    }
+#undef TP_GX
 }
 
 // ------------------------------------------------------------------------------ time LSTM on bf16 MFMA
@@ -664,9 +771,20 @@ static hipError_t launch_time_bf16(const TimeLstmArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
+extern thread_local int g_sdfa_time_lstm_shape;   // api.cpp ("time_lstm_shape" option): 0 = auto, 1 = 8-wave shapes only, 2 = paired 4-wave workgroups always
+
+static hipError_t launch_time_pair(const TimeLstmArgs &a, hipStream_t s) {
+    const size_t lds = 2 * 64 * 32 * sizeof(float4);   // 64 KiB: two workgroups per CU
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(time_lstm_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(time_lstm_pair_kernel, dim3((unsigned)(a.Nc / 32 * 2)), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
 hipError_t sdfa_launch_time_lstm(const TimeLstmArgs &a, hipStream_t s) {
     // 64-frame tiles while they fill the 256 CUs (one 8-wave workgroup per CU); otherwise 32-frame tiles
     const bool big = (a.Nc / 64) * 2 >= 256;
+    if (!a.terms && g_sdfa_time_lstm_shape == 2) return launch_time_pair(a, s);
     if (a.terms) {
         if (!a.Wb) return hipErrorInvalidValue;
         if (a.terms == 1) return big ? launch_time_bf16<2, 1>(a, s) : launch_time_bf16<1, 1>(a, s);

@@ -283,6 +283,24 @@ def test_fused_conv_stack_is_bitwise_the_two_kernel_path(eng, synth_sd, golden):
     assert torch.equal(z0, z2)
 
 
+def test_time_lstm_workgroup_shapes_are_bitwise_identical(synth_sd, golden):
+    """time_lstm_kernel<2> (8 waves x 64 frames), <1> (8 waves x 32 frames) and time_lstm_pair_kernel (4 waves x 32 frames, two
+    workgroups per CU) contract k in the same order with the same cell arithmetic: z must not change by a bit."""
+    from sdfa_amd import _lib
+    g = golden["model_dgrad"]
+    rs = np.random.RandomState(12)
+    x = torch.cat([_t(g["audio_feat"]), _t(rs.uniform(0, 1, (300, 64, 128, 3)).astype(np.float32))])
+    eng = Engine(synth_sd["dgrad"], max_frames=8192)
+    z0, a0 = eng.encoder(x)
+    try:
+        _lib.set_option("time_lstm_shape", 2)
+        z1, a1 = eng.encoder(x)
+    finally:
+        _lib.set_option("time_lstm_shape", 0)
+    assert torch.equal(z0, z1) and torch.equal(a0, a1)
+    assert np.abs(z0[:8].cpu().numpy() - g["z"][:, 0]).max() <= TOL_ACT
+
+
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
 def test_gemm_variants_agree(eng, golden, variant):
     """The alternative GEMM data paths (register-direct MT 4 / MT 2, LDS-DMA, split-bf16 x3, 256-tile,
