@@ -43,7 +43,7 @@ def main():
         fk, wk = sum(f) / len(f), sum(w) / len(w)
         print(f"{k[0][:46]:46s} {k[1]:10d} {len(m):5d} {sum(m) / len(m):10.1f} {fk:14.0f} {fk * 1024 * FETCH_CORRECTION / 1e9:13.3f} {wk * 1024 / 1e9:10.3f}")
     if "--traffic-json" in sys.argv:
-        key = max((k for k in M if k[0].startswith("freq_lstm_kernel<false")), key=lambda k: k[1])
+        key = max((k for k in M if k[0].startswith(("freq_lstm_v2_kernel<false", "freq_lstm_kernel<false"))), key=lambda k: (k[0].startswith("freq_lstm_v2"), k[1]))
         frames = key[1] // 256 // 2          # grid = (frames * 64 columns / 64 per workgroup) * 2 directions * 256 threads
         fk, wk = sum(F[key]) / len(F[key]), sum(W[key]) / len(W[key])
         read_b, write_b = fk * 1024 * FETCH_CORRECTION, wk * 1024

@@ -144,6 +144,13 @@ __global__ __launch_bounds__(256, WGS) void freq_lstm_kernel(FreqLstmArgs a) {
         _Pragma("unroll") for (int j = 0; j < NJ; ++j) B[j] = bsrc[j * 32 + l31];                            \
     }
         // (gate-tile-major order: the component-major mfma_block order needs 8 more registers here, which spills)
+#ifdef SDFA_COMPMAJOR   /* experiment: no back-to-back dependent MFMAs (consecutive MFMAs go to different accumulators) */
+#define FL_MFMA(W0, W1, W2, W3, B)                                                \
+    {                                                                             \
+        const float4 wq_[4] = {W0, W1, W2, W3};                                   \
+        mfma_block<4, NJ>(acc, wq_, B);                                           \
+    }
+#else
 #define FL_MFMA(W0, W1, W2, W3, B)                                                \
     {                                                                             \
         _Pragma("unroll") for (int j = 0; j < NJ; ++j) mfma4(acc[0][j], W0, B[j]); \
@@ -151,6 +158,7 @@ __global__ __launch_bounds__(256, WGS) void freq_lstm_kernel(FreqLstmArgs a) {
         _Pragma("unroll") for (int j = 0; j < NJ; ++j) mfma4(acc[2][j], W2, B[j]); \
         _Pragma("unroll") for (int j = 0; j < NJ; ++j) mfma4(acc[3][j], W3, B[j]); \
     }
+#endif
         FL_LOAD(0, wa0, wa1, wa2, wa3, ba)
         // the wave in its MFMA phase outranks the partner wave (of the CU's other workgroup) that is in its cell update /
         // staging phase at the SIMD's issue port: +0.8 % (A/B in profiles/r02_ab.txt; priorities 1, 2, 3 measure the same)
@@ -242,6 +250,122 @@ __global__ __launch_bounds__(256, WGS) void freq_lstm_kernel(FreqLstmArgs a) {
         atomicAdd(&g_lstamp[3], s_b2);
     }
 #endif
+}
+
+// ------------------------------------------------------------------------------- frequency LSTM, second form
+// Same arithmetic and the same per-accumulator order of operations as freq_lstm_kernel<.., 2, 2> (bit-identical output);
+// what changed is WHEN things are requested and in which order the MFMAs are issued:
+//   * the next x_f tile goes HBM -> LDS directly (global_load_lds_dwordx4 into the idle half of sX: no registers, no
+//     staging stores), requested right after the K loop instead of at the top of the step.  Loads return in issue order,
+//     so a tile requested before the first weight quads made every step's first MFMA wait for an HBM round trip;
+//   * the weight request that wraps around at the end of the K loop IS k-block 0 of the next step and stays live across
+//     the cell update (the 16 registers the x tile no longer needs);
+//   * MFMAs are issued component-major (mfma_block): consecutive MFMAs go to different accumulators, so a wave that
+//     has the matrix pipe to itself -- its partner workgroup is in its cell update -- does not stall on the previous
+//     MFMA's result every time;
+//   * the barrier after the K loop is a bare s_barrier (every LDS read has been consumed by an MFMA by then): it does
+//     not wait for the weight request in flight; the barrier at the end of the step waits for the DMA and the LDS writes
+//     but not for the acknowledgements of the hidden-state stores.
+template <bool SHARED>
+__global__ __launch_bounds__(256, 2) void freq_lstm_v2_kernel(FreqLstmArgs a) {
+    constexpr int NJ = 2, BT = 64;
+    __shared__ float4 sH[32][BT];
+    __shared__ float4 sX[2][16][BT];
+    __shared__ float sBias[512];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int dir = (blockIdx.x >> 3) & 1;
+    const int64_t m0 = (int64_t)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) * BT;
+    if (SHARED && m0 >= *a.col_limit) return;
+
+    const float4 *__restrict__ X3 = reinterpret_cast<const float4 *>(a.X3);
+    const float4 *__restrict__ W = reinterpret_cast<const float4 *>(a.W) + (size_t)dir * 48 * 512;
+    float4 *__restrict__ HF = reinterpret_cast<float4 *>(a.HF);
+
+    sBias[tid] = a.bias[dir * 512 + tid];
+    sBias[256 + tid] = a.bias[dir * 512 + 256 + tid];
+
+    // x_f tile = 16 k-quad rows of 64 columns (1 KiB each): wave w moves rows w, w+4, w+8, w+12
+    const float4 *__restrict__ xsrc = X3 + (int64_t)wave * a.Mc + m0 + lane;
+#define XDMA(f, buf)                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                      \
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(xsrc + (int64_t)((f)*16 + 4 * i) * a.Mc), \
+                                         (void __attribute__((address_space(3))) *)(&sX[buf][4 * i + wave][0]), 16, 0, 0);
+    XDMA(dir ? 31 : 0, 0)
+
+    f32x16 c[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[j][r] = 0.f;
+
+    const float4 *__restrict__ wp = W + wave * 128 + l31 + h * 512;   // + k-block * 1024 + gate * 32
+    float4 wa[4], wb[4], ba[NJ], bb[NJ];
+#define FV_WLOAD(kb, Wr) { const float4 *__restrict__ wq = wp + (kb) * 1024; Wr[0] = wq[0]; Wr[1] = wq[32]; Wr[2] = wq[64]; Wr[3] = wq[96]; }
+#define FV_BLOAD(kb, B)                                                                                      \
+    {                                                                                                        \
+        const float4 *bsrc = (kb) < 8 ? &sX[cur][2 * (kb) + h][0] : &sH[2 * ((kb) - 8) + h][0];              \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) B[j] = bsrc[j * 32 + l31];                            \
+    }
+    FV_WLOAD(0, wa)
+    __syncthreads();   // bias and the first x tile are in LDS (the fence drains the DMA)
+
+    for (int s = 0; s < 32; ++s) {
+        const int f = dir ? 31 - s : s;
+        const int cur = s & 1;
+        f32x16 acc[4][NJ];
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 b = *reinterpret_cast<const float4 *>(&sBias[wave * 128 + gt * 32 + 8 * g + 4 * h]);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    acc[gt][j][4 * g + 0] = b.x; acc[gt][j][4 * g + 1] = b.y;
+                    acc[gt][j][4 * g + 2] = b.z; acc[gt][j][4 * g + 3] = b.w;
+                }
+            }
+        const int nkb = s > 0 ? 24 : 8;        // h_{-1} = 0: the first step contracts x_f only
+        FV_BLOAD(0, ba)
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll 1
+        for (int kb = 0; kb < nkb; kb += 2) {
+            FV_WLOAD(kb + 1, wb)
+            FV_BLOAD(kb + 1, bb)
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_block<4, NJ>(acc, wa, ba);
+            const int kb2 = kb + 2 < nkb ? kb + 2 : 0;   // wraps to k-block 0: the NEXT step's first weights (its B operand is re-read then)
+            FV_WLOAD(kb2, wa)
+            FV_BLOAD(kb2, ba)
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_block<4, NJ>(acc, wb, bb);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        // every wave has finished reading sH / sX[cur] (all LDS reads were consumed by MFMAs, the wrap-around one is waited
+        // for here); the weight request in flight is not waited for
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (s + 1 < 32) { XDMA(dir ? 30 - s : s + 1, cur ^ 1) }   // lands during the cell update; sX[cur ^ 1] was last read in step s - 1
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 hq;
+                lstm_cell_quad(acc[0][j], acc[1][j], acc[2][j], acc[3][j], c[j], g, hq);
+                const int hq_idx = 8 * wave + 2 * g + h;
+                sH[hq_idx][j * 32 + l31] = hq;
+                HF[((m0 >> 7) * (int64_t)HF_SLAB_ROWS + (f * 64 + dir * 32 + hq_idx)) * 128 + (m0 & 127) + j * 32 + l31] = hq;
+            }
+        // h_s and the next x tile must be in LDS before anyone starts step s+1: this wave's LDS writes (lgkmcnt) and its four
+        // DMA requests.  Vector-memory operations of a wave complete in issue order on gfx9-family parts (one in-order
+        // vmcnt for loads and stores -- what LLVM's own waitcnt insertion relies on), and the 8 hidden-state stores were
+        // issued after the DMA, so vmcnt(8) is "DMA landed" without waiting for the stores' acknowledgements from L2
+        // (a full __syncthreads() fence costs 0.8 % here).
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+#undef XDMA
+#undef FV_WLOAD
+#undef FV_BLOAD
 }
 
 // --------------------------------------------------------------------- frequency LSTM on bf16 MFMA
@@ -719,10 +843,14 @@ extern "C" int sdfa_debug_read_lstm_stamps(unsigned long long *out, int reset) {
 }
 #endif
 
-extern thread_local int g_sdfa_freq_lstm_shape;   // api.cpp ("freq_lstm_shape" option): 0 = 64 columns x 2 workgroups/CU, 1 = 32 x 4, 2 = 32 x 3
+extern thread_local int g_sdfa_freq_lstm_shape;   // api.cpp ("freq_lstm_shape" option): 0 / 3 = freq_lstm_v2_kernel (default), 4 = freq_lstm_kernel 64 columns x 2 workgroups/CU, 1 = 32 x 4, 2 = 32 x 3
 
 template <bool SHARED>
 static hipError_t launch_freq(const FreqLstmArgs &a, hipStream_t s) {
+    if (g_sdfa_freq_lstm_shape == 0 || g_sdfa_freq_lstm_shape == 3) {      // default: the second form (+1.6 %, bit-identical)
+        hipLaunchKernelGGL((freq_lstm_v2_kernel<SHARED>), dim3((unsigned)(a.Mc / 64 * 2)), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     if (g_sdfa_freq_lstm_shape == 1)
         hipLaunchKernelGGL((freq_lstm_kernel<SHARED, 1, 4>), dim3((unsigned)(a.Mc / 32 * 2)), dim3(256), 0, s, a);
     else if (g_sdfa_freq_lstm_shape == 2)

@@ -301,6 +301,26 @@ def test_time_lstm_workgroup_shapes_are_bitwise_identical(synth_sd, golden):
     assert np.abs(z0[:8].cpu().numpy() - g["z"][:, 0]).max() <= TOL_ACT
 
 
+def test_freq_lstm_kernel_forms_are_bitwise_identical(synth_sd, golden):
+    """freq_lstm_kernel and freq_lstm_v2_kernel (x tile by LDS-DMA, weights kept across the step, component-major MFMA issue)
+    accumulate every gate in the same order: not a bit may differ -- also through the column-sharing launch."""
+    from sdfa_amd import _lib
+    clips = [synth.make_pcm(0, 32000), synth.make_pcm(5, 9088 + 777, "speechlike")]
+    eng = Engine(synth_sd["dgrad"], max_frames=8192)
+    feat, _, _ = eng.mel_frontend(clips, 16000)
+    fc, fs, hop = eng.last_frame_table
+    res = {}
+    for shape in (4, 3):
+        try:
+            _lib.set_option("freq_lstm_shape", shape)
+            res[shape] = (eng.encoder(feat), eng.encoder(feat, frame_clip=fc, frame_start=fs, hop=hop))
+        finally:
+            _lib.set_option("freq_lstm_shape", 0)
+    for k in (0, 1):
+        assert torch.equal(res[4][k][0], res[3][k][0]) and torch.equal(res[4][k][1], res[3][k][1])
+    assert torch.equal(res[4][0][0], res[4][1][0])
+
+
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
 def test_gemm_variants_agree(eng, golden, variant):
     """The alternative GEMM data paths (register-direct MT 4 / MT 2, LDS-DMA, split-bf16 x3, 256-tile,

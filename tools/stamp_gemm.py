@@ -16,10 +16,11 @@ for rep in range(2):
     lib.sdfa_debug_read_stamps(out, 1)
 v = [int(o) for o in out]
 n = v[4]
-print("per even stage, per wave, cycles (K >= 2048 GEMMs only):")
-for name, val in zip(("issue next-next loads", "ds_read + 64 MFMA", "wait loads + ds_write", "barrier"), v[:4]):
-    print(f"  {name:24s} {val / n:9.0f}")
-print(f"  total {sum(v[:4]) / n:9.0f}   (64 MFMAs alone = 4096)")
+if n:
+    print("per even stage, per wave, cycles (K >= 2048 GEMMs only):")
+    for name, val in zip(("issue next-next loads", "ds_read + 64 MFMA", "wait loads + ds_write", "barrier"), v[:4]):
+        print(f"  {name:24s} {val / n:9.0f}")
+    print(f"  total {sum(v[:4]) / n:9.0f}   (64 MFMAs alone = 4096)")
 
 lib.sdfa_debug_read_lstm_stamps.argtypes = [C.c_void_p, C.c_int]
 lib.sdfa_debug_read_lstm_stamps(out, 0)
