@@ -98,6 +98,9 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 
 __device__ __forceinline__ float sigmoidf_acc(float x) { return fast_rcp(1.0f + __expf(-x)); }
 
+// (1 - e) / (1 + e), e = exp(-2|x|), sign restored: seven instructions.  The five-instruction form 1 - 2 / (1 + exp(2x)) was
+// tried in round 2: the frequency LSTM got 0.4 % SLOWER with it (same-call A/B, profiles/r02_ab_tanh.txt), so the cell
+// update is not bound by its vector-ALU instruction count; kept as it was (and the results stay those of round 1).
 __device__ __forceinline__ float tanhf_acc(float x) {
     const float e = __expf(-2.0f * fabsf(x));
     return copysignf((1.0f - e) * fast_rcp(1.0f + e), x);
