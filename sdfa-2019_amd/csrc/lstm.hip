@@ -46,6 +46,8 @@ __device__ __forceinline__ void lstm_cell_quad(const f32x16 &ai, const f32x16 &a
 #ifdef SDFA_FAKE_CELL   /* timing experiment only: what does the cell math cost? */
         { float cn = af[r] * c[r] + ai[r] * ag[r]; c[r] = cn; hv[e] = ao[r] * cn; continue; }
 #endif
+        // (a fused form with one reciprocal per product -- 8 transcendental instructions per element instead of 10 --
+        // measured the same in round 2 and changes the last bits: not taken)
         float ig = sigmoidf_acc(ai[r]);
         float fg = sigmoidf_acc(af[r]);
         float gg = tanhf_acc(ag[r]);
@@ -258,8 +260,9 @@ __global__ __launch_bounds__(256, WGS) void freq_lstm_kernel(FreqLstmArgs a) {
 //   * the next x_f tile goes HBM -> LDS directly (global_load_lds_dwordx4 into the idle half of sX: no registers, no
 //     staging stores), requested right after the K loop instead of at the top of the step.  Loads return in issue order,
 //     so a tile requested before the first weight quads made every step's first MFMA wait for an HBM round trip;
-//   * the weight request that wraps around at the end of the K loop IS k-block 0 of the next step and stays live across
-//     the cell update (the 16 registers the x tile no longer needs);
+//   * k-block 0 of the weights is requested for the NEXT step right after the K loop and stays live across the cell update
+//     (the 16 registers the x tile no longer needs); all weight requests go through a buffer descriptor (scalar base +
+//     per-lane 32-bit offset: no vector-ALU address arithmetic, no 64-bit address registers);
 //   * MFMAs are issued component-major (mfma_block): consecutive MFMAs go to different accumulators, so a wave that
 //     has the matrix pipe to itself -- its partner workgroup is in its cell update -- does not stall on the previous
 //     MFMA's result every time;
@@ -300,20 +303,54 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_v2_kernel(FreqLstmArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) c[j][r] = 0.f;
 
-    const float4 *__restrict__ wp = W + wave * 128 + l31 + h * 512;   // + k-block * 1024 + gate * 32
-    float4 wa[4], wb[4], ba[NJ], bb[NJ];
-#define FV_WLOAD(kb, Wr) { const float4 *__restrict__ wq = wp + (kb) * 1024; Wr[0] = wq[0]; Wr[1] = wq[32]; Wr[2] = wq[64]; Wr[3] = wq[96]; }
-#define FV_BLOAD(kb, B)                                                                                      \
+    // weight quads through a BUFFER descriptor: wave-uniform base in scalar registers (descriptor inputs made provably
+    // uniform with readfirstlane), one loop-invariant 32-bit byte offset per lane, the k-block as scalar offset, the gate as
+    // immediate -- no vector-ALU address arithmetic and no 64-bit address registers inside the K loop (with flat addresses
+    // the loop sat at the register limit and the allocator copied half of each refilled operand set at the end of every
+    // iteration, behind a full s_waitcnt)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned long long wptr = (unsigned long long)(W + wave * 128);
+    // (readfirstlane returns a SIGNED int: without the casts a low half with bit 31 set sign-extends over the high half)
+    const unsigned long long wuni = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(wptr >> 32)) << 32) |
+                                    (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wptr);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)wuni, 0, 48 * 512 * 16, 0x00020000);
+    const unsigned woff = (unsigned)((l31 + h * 512) * 16);
+#define FV_W1(so, g_) __builtin_bit_cast(float4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(wrs, woff + 512 * (g_), so, 0))
+#define FV_WLOAD(kb, W0, W1, W2, W3)                                                                         \
+    {                                                                                                        \
+        const unsigned so = (unsigned)(kb) * (1024 * 16);                                                    \
+        W0 = FV_W1(so, 0); W1 = FV_W1(so, 1); W2 = FV_W1(so, 2); W3 = FV_W1(so, 3);                          \
+    }
+#define FV_BLOAD(kb, B0, B1)                                                                                 \
     {                                                                                                        \
         const float4 *bsrc = (kb) < 8 ? &sX[cur][2 * (kb) + h][0] : &sH[2 * ((kb) - 8) + h][0];              \
-        _Pragma("unroll") for (int j = 0; j < NJ; ++j) B[j] = bsrc[j * 32 + l31];                            \
+        B0 = bsrc[l31]; B1 = bsrc[32 + l31];                                                                 \
     }
-    FV_WLOAD(0, wa)
+    // one k-block: 32 MFMAs, component-major (consecutive MFMAs go to different accumulators)
+#define FV_MFMA(W0, W1, W2, W3, B0, B1)                                                                      \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                          \
+        acc[0][0] = MFMA(SDFA_OP(f4c(W0, q)), SDFA_OP(f4c(B0, q)), acc[0][0]);                               \
+        acc[0][1] = MFMA(SDFA_OP(f4c(W0, q)), SDFA_OP(f4c(B1, q)), acc[0][1]);                               \
+        acc[1][0] = MFMA(SDFA_OP(f4c(W1, q)), SDFA_OP(f4c(B0, q)), acc[1][0]);                               \
+        acc[1][1] = MFMA(SDFA_OP(f4c(W1, q)), SDFA_OP(f4c(B1, q)), acc[1][1]);                               \
+        acc[2][0] = MFMA(SDFA_OP(f4c(W2, q)), SDFA_OP(f4c(B0, q)), acc[2][0]);                               \
+        acc[2][1] = MFMA(SDFA_OP(f4c(W2, q)), SDFA_OP(f4c(B1, q)), acc[2][1]);                               \
+        acc[3][0] = MFMA(SDFA_OP(f4c(W3, q)), SDFA_OP(f4c(B0, q)), acc[3][0]);                               \
+        acc[3][1] = MFMA(SDFA_OP(f4c(W3, q)), SDFA_OP(f4c(B1, q)), acc[3][1]);                               \
+    }
+    float4 wn0, wn1, wn2, wn3;
+    FV_WLOAD(0, wn0, wn1, wn2, wn3)
     __syncthreads();   // bias and the first x tile are in LDS (the fence drains the DMA)
 
     for (int s = 0; s < 32; ++s) {
         const int f = dir ? 31 - s : s;
         const int cur = s & 1;
+        // Two alternating operand sets (wa/ba, wb/bb), each refilled right after the MFMAs that read it were issued: requests
+        // run one k-block (32 MFMAs) ahead.  k-block 0 comes from `wn`, requested during the previous step's cell update.
+        // Named scalars, not arrays: with arrays (or with one set that is loop-carried through BOTH loops, or with the K loop
+        // unrolled completely) the register allocator loaded refills into scratch registers and copied them over behind a
+        // full s_waitcnt at the end of every K iteration, or spilled 253 registers.
+        float4 wa0 = wn0, wa1 = wn1, wa2 = wn2, wa3 = wn3, wb0, wb1, wb2, wb3, ba0, ba1, bb0, bb1;
         f32x16 acc[4][NJ];
 #pragma unroll
         for (int gt = 0; gt < 4; ++gt)
@@ -327,21 +364,30 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_v2_kernel(FreqLstmArgs a) {
                 }
             }
         const int nkb = s > 0 ? 24 : 8;        // h_{-1} = 0: the first step contracts x_f only
-        FV_BLOAD(0, ba)
-        __builtin_amdgcn_s_setprio(1);
+        FV_BLOAD(0, ba0, ba1)
+#ifndef SDFA_PRIO_MFMA
+#define SDFA_PRIO_MFMA 1
+#endif
+#ifndef SDFA_PRIO_EPI
+#define SDFA_PRIO_EPI 0
+#endif
+        __builtin_amdgcn_s_setprio(SDFA_PRIO_MFMA);
 #pragma unroll 1
         for (int kb = 0; kb < nkb; kb += 2) {
-            FV_WLOAD(kb + 1, wb)
-            FV_BLOAD(kb + 1, bb)
+            FV_WLOAD(kb + 1, wb0, wb1, wb2, wb3)
+            FV_BLOAD(kb + 1, bb0, bb1)
             __builtin_amdgcn_sched_barrier(0);
-            mfma_block<4, NJ>(acc, wa, ba);
-            const int kb2 = kb + 2 < nkb ? kb + 2 : 0;   // wraps to k-block 0: the NEXT step's first weights (its B operand is re-read then)
-            FV_WLOAD(kb2, wa)
-            FV_BLOAD(kb2, ba)
+            FV_MFMA(wa0, wa1, wa2, wa3, ba0, ba1)
             __builtin_amdgcn_sched_barrier(0);
-            mfma_block<4, NJ>(acc, wb, bb);
+            const int kb2 = kb + 2 < nkb ? kb + 2 : 0;   // branch-free: the last iteration re-requests k-block 0 and drops it
+            FV_WLOAD(kb2, wa0, wa1, wa2, wa3)
+            FV_BLOAD(kb2, ba0, ba1)
+            __builtin_amdgcn_sched_barrier(0);
+            FV_MFMA(wb0, wb1, wb2, wb3, bb0, bb1)
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_s_setprio(0);
+        FV_WLOAD(0, wn0, wn1, wn2, wn3)     // k-block 0 for the NEXT step: in flight during the cell update (weights do not change)
+        __builtin_amdgcn_s_setprio(SDFA_PRIO_EPI);
         // every wave has finished reading sH / sX[cur] (all LDS reads were consumed by MFMAs, the wrap-around one is waited
         // for here); the weight request in flight is not waited for
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -361,11 +407,16 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_v2_kernel(FreqLstmArgs a) {
         // vmcnt for loads and stores -- what LLVM's own waitcnt insertion relies on), and the 8 hidden-state stores were
         // issued after the DMA, so vmcnt(8) is "DMA landed" without waiting for the stores' acknowledgements from L2
         // (a full __syncthreads() fence costs 0.8 % here).
+        // (the builtin wait is the same instruction again: the compiler's own waitcnt bookkeeping does not look inside asm
+        // and would otherwise put a full vmcnt(0) in front of the next LDS read -- inside the K loop -- for the DMA's sake)
+        __builtin_amdgcn_s_waitcnt(0x0078);     // gfx9 encoding: vmcnt = 8, expcnt = 7 (no wait), lgkmcnt = 0
         asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 #undef XDMA
 #undef FV_WLOAD
 #undef FV_BLOAD
+#undef FV_MFMA
+#undef FV_W1
 }
 
 // --------------------------------------------------------------------- frequency LSTM on bf16 MFMA
