@@ -11,7 +11,7 @@ expansion -> interleaved dgrad rows (F, 89784) in HBM.  Per GPU the batch is 32 
 dgrad rows of all ranks are reassembled on every rank with an RCCL all-gather issued chunk by chunk so that
 it overlaps the next chunk's compute (inside the timed region).
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fused frequency-LSTM recurrence,
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fused frequency-LSTM recurrence freq_lstm_v2_kernel,
 fp32 MFMA), measured live with HIP events on the launch stream; `cpu_baseline` times the CPU port of the reference
 path on the reference's own operator library (oracle/torch_oracle.py, torch CPU) on a bounded sample on rank 0 at N=1.
 """
@@ -302,7 +302,7 @@ def main():
                        "clips_per_gpu": C, "frames_per_gpu": F, "head": a.head, "chunk_frames": a.chunk,
                        "gather": a.gather if world > 1 else "none (1 GPU)", "weights": "synthetic seed 1234",
                        "mesh_stage": None if mesh is None else f"seek to 60 fps + mesh solve, {mesh[1].n_queries} video frames x {mesh[0].n_verts} vertices per GPU per step"},
-            "roofline": {"kernel": "freq_lstm_kernel", "bound": "mfma", "achieved": round(achieved, 2),
+            "roofline": {"kernel": "freq_lstm_v2_kernel", "bound": "mfma", "achieved": round(achieved, 2),
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                          "traffic": traffic, "traffic_algorithmic": traffic_alg, "traffic_source": traffic_src,
                          "launch_ms": round(lstm_ms_per_launch, 3), "flop_per_launch": flop_per_launch},
