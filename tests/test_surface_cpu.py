@@ -73,3 +73,28 @@ def test_rms_normalize_and_seek_match_reference_fixture(golden):
     ts = [int(t) for t in g["seek_ts"]]
     for q, ref in zip(g["seek_q"], g["seek_out"]):
         assert np.abs(np.asarray(stream.seek(float(q), ts, g["seek_seq"]), np.float64) - ref).max() <= 1e-12
+
+
+def test_librosa_restatement_reproduces_published_docstring_examples():
+    """librosa is absent (requirements.txt pins 0.8.0; un-vendored), so the Slaney mel scale / filterbank are restated in
+    oracle/librosa_restate.py.  The reference holds no vectors for them; the only independent anchors are the known answers
+    printed in librosa 0.8.0's own docstrings (librosa.core.convert.hz_to_mel / mel_to_hz, librosa.filters.mel):
+        >>> librosa.hz_to_mel(60)                      0.9
+        >>> librosa.hz_to_mel([110, 220, 440])         array([ 1.65,  3.3 ,  6.6 ])
+        >>> librosa.mel_to_hz(3)                       200.
+        >>> librosa.mel_to_hz([1,2,3,4,5])             array([  66.667,  133.333,  200.   ,  266.667,  333.333])
+        >>> librosa.filters.mel(22050, 2048)           array([[ 0.   ,  0.016, ...,  0.   ,  0.   ], ...   (128 x 1025)
+    Weak (a handful of rounded values) but not circular: fixtures, oracle and product all use the restatement."""
+    assert abs(LR.hz_to_mel(60) - 0.9) < 1e-12
+    assert np.allclose(LR.hz_to_mel(np.array([110, 220, 440])), [1.65, 3.3, 6.6], atol=1e-12)
+    assert LR.mel_to_hz(3) == 200.0
+    assert np.allclose(LR.mel_to_hz(np.array([1, 2, 3, 4, 5])), [66.667, 133.333, 200.0, 266.667, 333.333], atol=5e-4)
+    # above the 1 kHz knee the scale is logarithmic: the knee itself and continuity across it
+    assert abs(LR.hz_to_mel(1000.0) - 15.0) < 1e-12 and abs(LR.mel_to_hz(LR.hz_to_mel(4000.0)) - 4000.0) < 1e-9
+    fb = LR.mel_filters(22050, 2048)
+    assert fb.shape == (128, 1025) and fb.dtype == np.float32
+    assert np.array_equal(np.round(fb[0, :2], 3), np.float32([0.0, 0.016])) and fb[0, -1] == 0 and fb[-1, 0] == 0
+    # Slaney area normalisation: every band integrates to (about) 2 / bandwidth * bandwidth / 2 = 1 in Hz units
+    hz_per_bin = 22050 / 2048
+    area = fb.sum(1) * hz_per_bin
+    assert np.all(np.abs(area[5:-1] - 1.0) < 0.05)
