@@ -215,11 +215,20 @@ __global__ __launch_bounds__(256, 2) void conv123_kernel(ConvArgs a) {
         const int64_t n = n0 + col;
         int64_t row = n < a.N ? n * 64 + t : -1;
         if (a.col_src) row = a.col_src[m0 + col];
-        const float *src = a.audio_feat + (row >= 0 ? row : 0) * 384 + k_lo;
+        // all nine requests first (clamped, unconditional addresses), the zero padding applied afterwards: a load behind a
+        // divergent condition is compiled as branch + load + s_waitcnt vmcnt(0) + LDS store, i.e. nine SERIAL memory round
+        // trips in front of every workgroup's first barrier
+        const float *src = a.audio_feat + (row >= 0 ? row : 0) * 384;
+        float v[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int gk = k_lo + kb0 + i;
+            v[i] = src[gk < 0 ? 0 : (gk > 383 ? 383 : gk)];
+        }
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const int k = kb0 + i, gk = k_lo + k;
-            if (k < 68) sIn[k][col] = (row >= 0 && k < 66 && gk >= 0 && gk < 384) ? src[k] : 0.f;
+            if (k < 68) sIn[k][col] = (row >= 0 && k < 66 && gk >= 0 && gk < 384) ? v[i] : 0.f;
         }
     }
     if (tid < 64) {

@@ -231,9 +231,12 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(FrontendConsts c, 
     for (int i = tid; i < c.nnz; i += FE_THREADS) { sBin[i] = c.mel_bin[i]; sW[i] = c.mel_w[i]; }
     // window cut, zero pad, pre-emphasis (fp32, one rounding per op as numpy does)
     for (int i = tid; i < SLIDING; i += FE_THREADS) {
-        const int64_t g = s0 + i;
-        float x = (g >= 0 && g < len) ? pcm[off + g] : 0.f;
-        float xm = (i > 0 && g - 1 >= 0 && g - 1 < len) ? pcm[off + g - 1] : 0.f;
+        const int64_t g = s0 + i, last = len - 1;
+        // unconditional requests at clamped addresses, zero padding applied afterwards (see mel_columns_kernel)
+        const float r0 = pcm[off + (g < 0 ? 0 : (g > last ? last : g))];
+        const float rm = pcm[off + (g - 1 < 0 ? 0 : (g - 1 > last ? last : g - 1))];
+        float x = (g >= 0 && g < len) ? r0 : 0.f;
+        float xm = (i > 0 && g - 1 >= 0 && g - 1 < len) ? rm : 0.f;
         sY[i] = (i == 0) ? x : __fsub_rn(x, __fmul_rn(0.65f, xm));
     }
     __syncthreads();
@@ -349,10 +352,16 @@ __global__ __launch_bounds__(64 * MC_WAVES) void mel_columns_kernel(FrontendCons
             for (int r = 0; r < 4; ++r) {
                 const int i = 2 * (j + r * (M / 4));                       // even sample of z[j + r M/4]
                 const int64_t g = p + i;
-                // zero-padded clip; pre-emphasis with one rounding per op (misc.py:8-17)
-                const float xm = (g - 1 >= 0 && g - 1 < len) ? x[g - 1] : 0.f;
-                const float x0 = (g >= 0 && g < len) ? x[g] : 0.f;
-                const float x1 = (g + 1 >= 0 && g + 1 < len) ? x[g + 1] : 0.f;
+                // zero-padded clip; pre-emphasis with one rounding per op (misc.py:8-17).  The three samples are requested
+                // UNCONDITIONALLY at clamped addresses and zeroed afterwards: a load behind a divergent condition compiles to
+                // branch + load + wait, which serialised the 24 requests of a column into ~10 memory round trips
+                const int64_t last = len - 1;
+                const float rm = x[g - 1 < 0 ? 0 : (g - 1 > last ? last : g - 1)];
+                const float r0 = x[g < 0 ? 0 : (g > last ? last : g)];
+                const float r1 = x[g + 1 < 0 ? 0 : (g + 1 > last ? last : g + 1)];
+                const float xm = (g - 1 >= 0 && g - 1 < len) ? rm : 0.f;
+                const float x0 = (g >= 0 && g < len) ? r0 : 0.f;
+                const float x1 = (g + 1 >= 0 && g + 1 < len) ? r1 : 0.f;
                 const float y0 = (raw0 && i == 0) ? x0 : __fsub_rn(x0, __fmul_rn(0.65f, xm));
                 const float y1 = __fsub_rn(x1, __fmul_rn(0.65f, x0));
                 v[b][r] = make_float2(sHamm[i] * y0, sHamm[i + 1] * y1);
