@@ -74,43 +74,50 @@ int build_frontend(int sr, FrontendCache &fc) {
     std::vector<double> mel_f(n_mels + 2);
     const double m_lo = hz_to_mel(fmin), m_hi = hz_to_mel(fmax);
     for (int i = 0; i < n_mels + 2; ++i) mel_f[i] = mel_to_hz(m_lo + (m_hi - m_lo) * i / (n_mels + 1));
-    std::vector<int> ptr(n_mels + 1, 0), bins;
-    std::vector<float> wts;
-    int used = 0;
+    // sparse mel rows in a fixed-width form: a band's non-zero bins are consecutive (triangular filters), the widest
+    // band has 8 of them -- first bin + 8 weights (zero padded), so the kernels' band loop unrolls
+    std::vector<int> bin0(n_mels, 0);
+    std::vector<float> w8((size_t)8 * n_mels, 0.f);
+    int used = 0, nnz = 0;
     for (int i = 0; i < n_mels; ++i) {
         const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+        int first = -1, last = -1;
+        std::vector<float> row(nbins, 0.f);
         for (int b = 0; b < nbins; ++b) {
             const double fr = (double)sr / 2 * b / (nbins - 1);
             const double lower = -(mel_f[i] - fr) / (mel_f[i + 1] - mel_f[i]);
             const double upper = (mel_f[i + 2] - fr) / (mel_f[i + 2] - mel_f[i + 1]);
             const float w = (float)std::fmax(0.0, std::fmin(lower, upper));
             const float wn = (float)((double)w * enorm);   // float32 weights *= float64 enorm -> float32
-            if (wn != 0.f) {
-                bins.push_back(b);
-                wts.push_back(wn);
-                if (b + 1 > used) used = b + 1;
-            }
+            row[b] = wn;
+            if (wn != 0.f) { if (first < 0) first = b; last = b; ++nnz; }
         }
-        ptr[i + 1] = (int)bins.size();
+        if (first < 0) { first = 0; last = 0; }             // an empty band (none at these settings): all-zero taps
+        if (last - first + 1 > 8) return fail(SDFA_EINVAL, "mel band %d spans %d bins: the kernels hold 8 taps per band", i, last - first + 1);
+        for (int b = first; b <= last; ++b)
+            if (row[b] == 0.f) return fail(SDFA_EINVAL, "mel band %d is not contiguous", i);
+        bin0[i] = first;
+        for (int e = 0; e < 8 && first + e < nbins; ++e) w8[(size_t)e * n_mels + i] = (first + e <= last) ? row[first + e] : 0.f;
+        if (last + 1 > used) used = last + 1;
     }
-    if (bins.size() > 512 || used > 256) return fail(SDFA_EINVAL, "mel filterbank does not fit the kernel tables");
-    const size_t o_h = 0, o_t = o_h + win * 4, o_p = o_t + win * 8, o_b = o_p + 132 * 4, o_w = o_b + 512 * 4, total = o_w + 512 * 4;
+    // the kernels keep 256 power bins per column and read 8 taps from a band's first bin on
+    for (int i = 0; i < n_mels; ++i)
+        if (bin0[i] + 8 > 256) return fail(SDFA_EINVAL, "mel filterbank does not fit the kernel tables (band %d starts at bin %d)", i, bin0[i]);
+    const size_t o_h = 0, o_t = o_h + win * 4, o_p = o_t + win * 8, o_w = o_p + 128 * 4, total = o_w + 1024 * 4;
     std::vector<char> host(total, 0);
     memcpy(&host[o_h], hamm.data(), win * 4);
     memcpy(&host[o_t], tw.data(), win * 8);
-    memcpy(&host[o_p], ptr.data(), ptr.size() * 4);
-    memcpy(&host[o_b], bins.data(), bins.size() * 4);
-    memcpy(&host[o_w], wts.data(), wts.size() * 4);
+    memcpy(&host[o_p], bin0.data(), bin0.size() * 4);
+    memcpy(&host[o_w], w8.data(), w8.size() * 4);
     HIP_TRY(hipMalloc(&fc.blob, total));
     HIP_TRY(hipMemcpy(fc.blob, host.data(), total, hipMemcpyHostToDevice));
     char *d = (char *)fc.blob;
     fc.c.hamm = (const float *)(d + o_h);
     fc.c.twiddle = (const float2 *)(d + o_t);
-    fc.c.mel_ptr = (const int *)(d + o_p);
-    fc.c.mel_bin = (const int *)(d + o_b);
-    fc.c.mel_w = (const float *)(d + o_w);
+    fc.c.mel_bin0 = (const int *)(d + o_p);
+    fc.c.mel_w8 = (const float *)(d + o_w);
     fc.c.win = win; fc.c.hop = hop; fc.c.sliding = hop * 63 + win;
-    fc.c.nbins_used = used; fc.c.nnz = (int)bins.size();
+    fc.c.nbins_used = used; fc.c.nnz = nnz;
     return SDFA_OK;
 }
 

@@ -35,8 +35,8 @@ constexpr int FE_WAVES = 8, FE_THREADS = 64 * FE_WAVES;
 // spectra, sparse mel gather, dB, normalise, clamp.  Returns mel[col][bb] for band = lane + 64 * bb.  Everything stays in
 // the wave's own LDS buffer `buf`, so only wavefront-scope fences separate the stages.
 template <int WIN>
-__device__ __forceinline__ void fft_pair_to_mel(float2 (&v)[WIN / 256][4], float2 *buf, const float2 *sTw, const int *sPtr, const int *sBin,
-                                                const float *sW, int lane, float (&mel)[2][2]) {
+__device__ __forceinline__ void fft_pair_to_mel(float2 (&v)[WIN / 256][4], float2 *buf, const float2 *sTw, const int *sBin0,
+                                                const float (*sW8)[128], int lane, float (&mel)[2][2]) {
     constexpr int NB = 256, NR4 = WIN / 256;
     constexpr bool HAS_R2 = (WIN == 512);
     float *pw0 = reinterpret_cast<float *>(buf), *pw1 = pw0 + NB;   // power spectra of the two columns (bins < 256) reuse the buffer
@@ -112,7 +112,9 @@ __device__ __forceinline__ void fft_pair_to_mel(float2 (&v)[WIN / 256][4], float
                 const int band = lane + 64 * bb;
                 float m = 0.f;
                 const float *pw = col ? pw1 : pw0;
-                for (int e = sPtr[band]; e < sPtr[band + 1]; ++e) m += sW[e] * pw[sBin[e]];
+                const int b0 = sBin0[band];     // fixed 8 taps per band (zero-weight padding): unrolled, all reads in flight together
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m += sW8[e][band] * pw[b0 + e];
                 float db = __fmul_rn(10.0f, log10f(fmaxf(m, 1.1920929e-07f)));
                 float nv = __fdiv_rn(__fadd_rn(__fsub_rn(db, 20.0f), 80.0f), 80.0f);
                 mel[col][bb] = fminf(fmaxf(nv, 0.f), 1.f);
@@ -126,8 +128,8 @@ __device__ __forceinline__ void fft_pair_to_mel(float2 (&v)[WIN / 256][4], float
 // column shares the transform, so the result is a function of the column's samples alone -- whichever batch, chunk or
 // neighbour it is computed with.  v: stage-0 butterfly inputs (.x = even sample, .y = odd sample, windowed).
 template <int WIN>
-__device__ __forceinline__ void fft_real_to_mel(float2 (&v)[WIN / 512][4], float2 *buf, const float2 *sTw, const int *sPtr, const int *sBin,
-                                                const float *sW, int lane, float (&mel)[2]) {
+__device__ __forceinline__ void fft_real_to_mel(float2 (&v)[WIN / 512][4], float2 *buf, const float2 *sTw, const int *sBin0,
+                                                const float (*sW8)[128], int lane, float (&mel)[2]) {
     constexpr int M = WIN / 2, NR4 = M / 256;
     constexpr bool HAS_R2 = (M == 512);            // 512 = 4^4 * 2, 256 = 4^4
     float *pw = reinterpret_cast<float *>(buf);    // power spectrum (bins < 256) reuses the buffer
@@ -197,7 +199,9 @@ __device__ __forceinline__ void fft_real_to_mel(float2 (&v)[WIN / 512][4], float
     for (int bb = 0; bb < 2; ++bb) {
         const int band = lane + 64 * bb;
         float m = 0.f;
-        for (int e = sPtr[band]; e < sPtr[band + 1]; ++e) m += sW[e] * pw[sBin[e]];
+        const int b0 = sBin0[band];         // fixed 8 taps per band (zero-weight padding): unrolled, all reads in flight together
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m += sW8[e][band] * pw[b0 + e];
         float db = __fmul_rn(10.0f, log10f(fmaxf(m, 1.1920929e-07f)));
         float nv = __fdiv_rn(__fadd_rn(__fsub_rn(db, 20.0f), 80.0f), 80.0f);
         mel[bb] = fminf(fmaxf(nv, 0.f), 1.f);
@@ -217,9 +221,8 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(FrontendConsts c, 
     __shared__ float2 sTw[WIN];
     __shared__ float sHamm[WIN];
     __shared__ float sMel[64][128];   // lanes walk the band index in every access: no padding needed
-    __shared__ int sPtr[132];
-    __shared__ int sBin[512];
-    __shared__ float sW[512];
+    __shared__ int sBin0[128];        // first FFT bin of each mel band (a band's bins are consecutive)
+    __shared__ float sW8[8][128];     // its weights, tap-major, zero padded to 8 taps (the widest band has 8)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t frame = blockIdx.x;
@@ -227,8 +230,8 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(FrontendConsts c, 
     const int64_t off = clip_off[clip], len = clip_len[clip], s0 = frame_start[frame];
 
     for (int i = tid; i < WIN; i += FE_THREADS) { sTw[i] = c.twiddle[i]; sHamm[i] = c.hamm[i]; }
-    for (int i = tid; i < 129; i += FE_THREADS) sPtr[i] = c.mel_ptr[i];
-    for (int i = tid; i < c.nnz; i += FE_THREADS) { sBin[i] = c.mel_bin[i]; sW[i] = c.mel_w[i]; }
+    for (int i = tid; i < 128; i += FE_THREADS) sBin0[i] = c.mel_bin0[i];
+    for (int i = tid; i < 1024; i += FE_THREADS) sW8[i >> 7][i & 127] = c.mel_w8[i];
     // window cut, zero pad, pre-emphasis (fp32, one rounding per op as numpy does)
     for (int i = tid; i < SLIDING; i += FE_THREADS) {
         const int64_t g = s0 + i, last = len - 1;
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(FrontendConsts c, 
             }
         }
         float mel[2][2];
-        fft_pair_to_mel<WIN>(v, buf, sTw, sPtr, sBin, sW, lane, mel);
+        fft_pair_to_mel<WIN>(v, buf, sTw, sBin0, sW8, lane, mel);
 #pragma unroll
         for (int col = 0; col < 2; ++col)
 #pragma unroll
@@ -327,13 +330,12 @@ __global__ __launch_bounds__(64 * MC_WAVES) void mel_columns_kernel(FrontendCons
     __shared__ float2 sFft[MC_WAVES][M];
     __shared__ float2 sTw[WIN];
     __shared__ float sHamm[WIN];
-    __shared__ int sPtr[132];
-    __shared__ int sBin[512];
-    __shared__ float sW[512];
+    __shared__ int sBin0[128];        // first FFT bin of each mel band (a band's bins are consecutive)
+    __shared__ float sW8[8][128];     // its weights, tap-major, zero padded to 8 taps (the widest band has 8)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < WIN; i += 64 * MC_WAVES) { sTw[i] = c.twiddle[i]; sHamm[i] = c.hamm[i]; }
-    for (int i = tid; i < 129; i += 64 * MC_WAVES) sPtr[i] = c.mel_ptr[i];
-    for (int i = tid; i < c.nnz; i += 64 * MC_WAVES) { sBin[i] = c.mel_bin[i]; sW[i] = c.mel_w[i]; }
+    for (int i = tid; i < 128; i += 64 * MC_WAVES) sBin0[i] = c.mel_bin0[i];
+    for (int i = tid; i < 1024; i += 64 * MC_WAVES) sW8[i >> 7][i & 127] = c.mel_w8[i];
     __syncthreads();
 
     const int64_t nd = *n_distinct;
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(64 * MC_WAVES) void mel_columns_kernel(FrontendCons
             }
         }
         float mel[2];
-        fft_real_to_mel<WIN>(v, buf, sTw, sPtr, sBin, sW, lane, mel);
+        fft_real_to_mel<WIN>(v, buf, sTw, sBin0, sW8, lane, mel);
         mel_table[u * 128 + lane] = mel[0];
         mel_table[u * 128 + 64 + lane] = mel[1];
     }
@@ -416,7 +418,7 @@ hipError_t sdfa_launch_frontend(const FrontendConsts &c, const float *pcm, const
                                 const int64_t *clip_len, const int32_t *frame_clip, const int64_t *frame_start,
                                 int64_t n_frames, float *audio_feat, hipStream_t s) {
     if (n_frames <= 0) return hipSuccess;
-    if (c.nnz > 512 || c.nbins_used > 256) return hipErrorInvalidValue;
+    if (c.nbins_used > 256) return hipErrorInvalidValue;
     if (c.win == 1024)
         hipLaunchKernelGGL(frontend_kernel<1024>, dim3((unsigned)n_frames), dim3(FE_THREADS), 0, s, c, pcm, clip_off, clip_len,
                            frame_clip, frame_start, audio_feat);
@@ -431,7 +433,7 @@ hipError_t sdfa_launch_frontend(const FrontendConsts &c, const float *pcm, const
 hipError_t sdfa_launch_mel_columns(const FrontendConsts &c, const float *pcm, const int64_t *clip_off, const int64_t *clip_len,
                                    const int32_t *frame_clip, const int64_t *frame_start, const int32_t *col_src,
                                    const int64_t *n_distinct, float *mel_table, hipStream_t s) {
-    if (c.nnz > 512 || c.nbins_used > 256) return hipErrorInvalidValue;
+    if (c.nbins_used > 256) return hipErrorInvalidValue;
     const unsigned grid = 256 * 6;      // persistent waves: each takes column pairs round-robin until the device-side count runs out
     if (c.win == 1024)
         hipLaunchKernelGGL(mel_columns_kernel<1024>, dim3(grid), dim3(64 * MC_WAVES), 0, s, c, pcm, clip_off, clip_len, frame_clip,

@@ -59,9 +59,8 @@ hipError_t sdfa_launch_pca_dgrad(const PcaArgs &a, hipStream_t s);
 struct FrontendConsts {      // device pointers, built once per sample rate
     const float *hamm;       // [win]
     const float2 *twiddle;   // [win]  exp(-2*pi*i*m/win)
-    const int *mel_ptr;      // [129]  CSR over mel bands
-    const int *mel_bin;      // [nnz]
-    const float *mel_w;      // [nnz]
+    const int *mel_bin0;     // [128]     first FFT bin of each mel band (the bins of a band are consecutive)
+    const float *mel_w8;     // [8][128]  its weights, tap-major, zero padded to 8 taps
     int win, hop, sliding, nbins_used, nnz;
 };
 hipError_t sdfa_launch_frontend(const FrontendConsts &c, const float *pcm, const int64_t *clip_off,
