@@ -620,13 +620,21 @@ __global__ __launch_bounds__(512, 2) void time_lstm_kernel(TimeLstmArgs a) {
                 acc[gt][j][4 * g + 0] = v.x; acc[gt][j][4 * g + 1] = v.y; acc[gt][j][4 * g + 2] = v.z; acc[gt][j][4 * g + 3] = v.w;
             }
 
-    // recurrent weights one k-block ahead, two alternating register sets, branch-free (see freq_lstm_kernel).  The request
-    // that wraps around at the end of a step's K loop IS k-block 0 of the next step: `wa` stays live across the cell update
-    // and the step barrier, so the first MFMAs after the barrier (all 8 waves start together) do not wait for an L2 round trip.
-    const float4 *__restrict__ wp = Ww + h * 1024;
-    float4 wa[4], wb[4];
-#define TL_LOAD(kb, W) { const float4 *__restrict__ wq = wp + (kb) * 2048; W[0] = wq[0]; W[1] = wq[32]; W[2] = wq[64]; W[3] = wq[96]; }
-    TL_LOAD(0, wa)
+    // Recurrent weights one k-block ahead, two alternating operand sets, branch-free (see freq_lstm_v2_kernel): named
+    // scalars and a buffer descriptor (wave-uniform base in scalar registers + one 32-bit lane offset), so the K loop
+    // carries no copies and no 64-bit address registers.  The request that wraps around at the end of a step's K loop IS
+    // k-block 0 of the next step (weights do not change): it goes into `wn`, which stays live across the cell update and
+    // the step barrier, so the first MFMAs after the barrier (all 8 waves start together) do not wait for L2.
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned long long wptr = (unsigned long long)(reinterpret_cast<const float4 *>(a.W) + (size_t)dir * 64 * 1024 + wave * 128);
+    const unsigned long long wuni = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(wptr >> 32)) << 32) |
+                                    (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wptr);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)wuni, 0, 64 * 1024 * 16, 0x00020000);
+    const unsigned woff = (unsigned)((l31 + h * 1024) * 16);
+#define TL_W1(so, g_) __builtin_bit_cast(float4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(wrs, woff + 512 * (g_), so, 0))
+#define TL_LOAD(kb, W0, W1, W2, W3) { const unsigned so = (unsigned)(kb) * (2048 * 16); W0 = TL_W1(so, 0); W1 = TL_W1(so, 1); W2 = TL_W1(so, 2); W3 = TL_W1(so, 3); }
+    float4 wn0, wn1, wn2, wn3;
+    TL_LOAD(0, wn0, wn1, wn2, wn3)
     for (int s = 0; s < 64; ++s) {
         const int t = dir ? 63 - s : s;
         const int tn = dir ? t - 1 : t + 1;
@@ -635,23 +643,30 @@ __global__ __launch_bounds__(512, 2) void time_lstm_kernel(TimeLstmArgs a) {
         float4 *sHn = sHt + (size_t)((s & 1) ^ 1) * 64 * BT;
 
         if (s > 0) {
-#define TL_MFMA(kb, W)                                                                    \
-    {                                                                                     \
-        float4 bq[NT];                                                                    \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j) bq[j] = sHc[(2 * (kb) + h) * BT + j * 32 + l31]; \
-        mfma_block<4, NT>(acc, W, bq);                                                    \
-    }
+            float4 wa0 = wn0, wa1 = wn1, wa2 = wn2, wa3 = wn3, wb0, wb1, wb2, wb3, ba[NT], bb[NT];
+#define TL_BLOAD(kb, B) _Pragma("unroll") for (int j = 0; j < NT; ++j) B[j] = sHc[(2 * (kb) + h) * BT + j * 32 + l31];
+#define TL_ROW(gt, Wg, B) _Pragma("unroll") for (int j = 0; j < NT; ++j) acc[gt][j] = MFMA(SDFA_OP(f4c(Wg, q)), SDFA_OP(f4c(B[j], q)), acc[gt][j]);
+            // component-major, weight operands by name (an array of them is built by copying); h operands one k-block ahead too
+#define TL_MFMA(W0, W1, W2, W3, B) _Pragma("unroll") for (int q = 0; q < 4; ++q) { TL_ROW(0, W0, B) TL_ROW(1, W1, B) TL_ROW(2, W2, B) TL_ROW(3, W3, B) }
+            TL_BLOAD(0, ba)
 #pragma unroll 1
             for (int kb = 0; kb < 32; kb += 2) {
-                TL_LOAD(kb + 1, wb)
+                TL_LOAD(kb + 1, wb0, wb1, wb2, wb3)
+                TL_BLOAD(kb + 1, bb)
                 __builtin_amdgcn_sched_barrier(0);
-                TL_MFMA(kb, wa)
+                TL_MFMA(wa0, wa1, wa2, wa3, ba)
+                __builtin_amdgcn_sched_barrier(0);
                 const int kn = kb + 2 < 32 ? kb + 2 : 0;
-                TL_LOAD(kn, wa)
+                TL_LOAD(kn, wa0, wa1, wa2, wa3)
+                TL_BLOAD(kn, ba)
                 __builtin_amdgcn_sched_barrier(0);
-                TL_MFMA(kb + 1, wb)
+                TL_MFMA(wb0, wb1, wb2, wb3, bb)
+                __builtin_amdgcn_sched_barrier(0);
             }
 #undef TL_MFMA
+#undef TL_ROW
+#undef TL_BLOAD
+            wn0 = wa0; wn1 = wa1; wn2 = wa2; wn3 = wa3;      // k-block 0 again: the next step's first operands
         }
 #pragma unroll
         for (int j = 0; j < NT; ++j)
@@ -674,6 +689,7 @@ __global__ __launch_bounds__(512, 2) void time_lstm_kernel(TimeLstmArgs a) {
     }
 #undef TL_GX
 #undef TL_LOAD
+#undef TL_W1
 }
 
 // The same recurrence as 4-wave workgroups of 32 frames: a wave owns TWO hidden blocks (acc[4 gates][2 blocks], the same
