@@ -599,15 +599,44 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs a) {
     }
 #define BG_LSTORE_A(buf) BG_LSTORE1(buf, 0, ra0, rb0) BG_LSTORE1(buf, 1, ra1, rb1) BG_LSTORE1(buf, 2, ra2, rb2) BG_LSTORE1(buf, 3, ra3, rb3)
 #define BG_LSTORE_B(buf) BG_LSTORE1(buf, 0, rc0, rd0) BG_LSTORE1(buf, 1, rc1, rd1) BG_LSTORE1(buf, 2, rc2, rd2) BG_LSTORE1(buf, 3, rc3, rd3)
+    // operand reads ahead of the MFMAs (see gemm_k4_kernel).  This kernel sits at 240 registers, so only HALF of a k-block's
+    // operands (fb and fa[0..1]: what the first MFMAs of the block read) are requested one k-block ahead in a second set;
+    // fa[2..3] are requested at the top of their own block and arrive behind its first four MFMAs (256 cycles)
+#define BG_RD_HEAD(kb, FA, FB)                                                                          \
+    {                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) FA[i] = sp[(2 * (kb) + h) * BT + wp * 128 + i * 32 + l31]; \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) FB[j] = sq[(2 * (kb) + h) * BT + wq * 64 + j * 32 + l31];  \
+    }
+#define BG_RD_TAIL(kb, FA)                                                                              \
+    _Pragma("unroll") for (int i = 2; i < 4; ++i) FA[i] = sp[(2 * (kb) + h) * BT + wp * 128 + i * 32 + l31];
+#define BG_BLOCK(FA, FB, FT)                                                                            \
+    {                                                                                                   \
+        const float4 fa_[4] = {FA[0], FA[1], FT[2], FT[3]};                                             \
+        mfma_block<4, 2>(acc, fa_, FB);                                                                 \
+    }
 #define BG_COMPUTE(buf)                                                                                 \
     {                                                                                                   \
         const float4 *sp = SP(buf), *sq = SQ(buf);                                                      \
-        _Pragma("unroll") for (int kb = 0; kb < KQ / 2; ++kb) {                                         \
-            float4 fa[4], fb[2];                                                                        \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[i] = sp[(2 * kb + h) * BT + wp * 128 + i * 32 + l31]; \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j) fb[j] = sq[(2 * kb + h) * BT + wq * 64 + j * 32 + l31];  \
-            mfma_block<4, 2>(acc, fa, fb);                                                              \
-        }                                                                                               \
+        float4 fa0[2], fb0[2], fa1[2], fb1[2], ft[4];                                                   \
+        BG_RD_HEAD(0, fa0, fb0)                                                                         \
+        BG_RD_TAIL(0, ft)                                                                               \
+        BG_RD_HEAD(1, fa1, fb1)                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        BG_BLOCK(fa0, fb0, ft)                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        BG_RD_TAIL(1, ft)                                                                               \
+        BG_RD_HEAD(2, fa0, fb0)                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        BG_BLOCK(fa1, fb1, ft)                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        BG_RD_TAIL(2, ft)                                                                               \
+        BG_RD_HEAD(3, fa1, fb1)                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        BG_BLOCK(fa0, fb0, ft)                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        BG_RD_TAIL(3, ft)                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        BG_BLOCK(fa1, fb1, ft)                                                                          \
     }
 
     f32x16 acc[4][2];
@@ -637,6 +666,9 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs a) {
 #undef BG_GLOAD1
 #undef BG_ADVANCE
 #undef BG_COMPUTE
+#undef BG_RD_HEAD
+#undef BG_RD_TAIL
+#undef BG_BLOCK
 
 #pragma unroll
     for (int i = 0; i < 4; ++i)
