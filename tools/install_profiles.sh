@@ -1,0 +1,17 @@
+#!/bin/bash
+# Copies the summaries of gpurun_out/<tag>/ (tools/collect_profiles.sh + the rehearsal benches) into profiles/ as r<NN>_*.
+# usage: tools/install_profiles.sh <tag> <round prefix, e.g. r02>
+set -e
+T=gpurun_out/$1; R=$2
+rm -rf profiles/${R}_pmc && mkdir -p profiles/${R}_pmc && cp $T/pmc/* profiles/${R}_pmc/
+sed -i "s#(pmc);#(profiles/${R}_pmc);#" profiles/${R}_pmc/freq_lstm_traffic.json
+cp $T/bench.json profiles/${R}_bench.json
+cp $T/bench_under_rocprof.json profiles/${R}_bench_under_rocprof.json
+cp $T/kernel_stats.csv profiles/${R}_kernel_stats.csv
+cp $T/per_launch.txt profiles/${R}_per_launch.txt
+cp $T/trace/run_kernel_trace.csv profiles/${R}_kernel_trace.csv
+[ -f $T/bench_8khz.json ] && cp $T/bench_8khz.json profiles/${R}_bench_8khz.json
+[ -f $T/bench_config5.json ] && cp $T/bench_config5.json profiles/${R}_bench_config5_rehearsal.json
+[ -f $T/bench_mesh_stage.json ] && cp $T/bench_mesh_stage.json profiles/${R}_bench_mesh_stage.json
+[ -f gpurun_out/precision_modes.json ] && cp gpurun_out/precision_modes.json profiles/${R}_precision_modes.json
+ls -la profiles/${R}_* | head -20
