@@ -708,12 +708,14 @@ thread_local int g_sdfa_freq_lstm_shape = 0;
 thread_local int g_sdfa_pca_unfused = 0;
 thread_local int g_sdfa_conv_unfused = 0;
 thread_local int g_sdfa_time_lstm_shape = 0;
+thread_local int g_sdfa_pca_lds = 0;
 int sdfa_debug_set_option(const char *name, int value) {
     if (name && !strcmp(name, "gemm_variant")) { g_sdfa_gemm_variant = value; return SDFA_OK; }
     if (name && !strcmp(name, "freq_lstm_shape")) { g_sdfa_freq_lstm_shape = value; return SDFA_OK; }
     if (name && !strcmp(name, "pca_unfused")) { g_sdfa_pca_unfused = value; return SDFA_OK; }
     if (name && !strcmp(name, "conv_unfused")) { g_sdfa_conv_unfused = value; return SDFA_OK; }
     if (name && !strcmp(name, "time_lstm_shape")) { g_sdfa_time_lstm_shape = value; return SDFA_OK; }
+    if (name && !strcmp(name, "pca_lds")) { g_sdfa_pca_lds = value; return SDFA_OK; }
     return fail(SDFA_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }
 

@@ -283,6 +283,25 @@ def test_fused_conv_stack_is_bitwise_the_two_kernel_path(eng, synth_sd, golden):
     assert torch.equal(z0, z2)
 
 
+def test_pca_basis_through_lds_is_bitwise_identical(synth_sd):
+    """pca_dgrad_kernel<true> (basis slab staged through LDS once per workgroup) vs <false> (every wave fetches it): same k
+    order per accumulator -> identical dgrad rows, on a ragged batch (partial frame block, early-exit waves)."""
+    from sdfa_amd import _lib
+    eng = Engine(synth_sd["dgrad"], max_frames=512)
+    rs = np.random.RandomState(21)
+    for n in (1, 130, 700):
+        z = _t(rs.normal(0, 1, (n, 512)).astype(np.float32))
+        spk = torch.from_numpy(rs.randint(0, 8, n))
+        try:
+            _lib.set_option("pca_lds", 0)
+            _, a = eng.regress(z, spk)
+            _lib.set_option("pca_lds", 1)
+            _, b = eng.regress(z, spk)
+        finally:
+            _lib.set_option("pca_lds", 0)
+        assert torch.equal(a, b), n
+
+
 def test_time_lstm_workgroup_shapes_are_bitwise_identical(synth_sd, golden):
     """time_lstm_kernel<2> (8 waves x 64 frames), <1> (8 waves x 32 frames) and time_lstm_pair_kernel (4 waves x 32 frames, two
     workgroups per CU) contract k in the same order with the same cell arithmetic: z must not change by a bit."""
