@@ -8,8 +8,10 @@ One "step" = one pass of the whole hot path over one batch of synthetic PCM that
 in HBM: frame windows -> mel/delta front end -> conv + freq-LSTM + BiLSTM + attention encoder -> MLPs + PCA
 expansion -> interleaved dgrad rows (F, 89784) in HBM.  Per GPU the batch is 32 clips x 10 s @ 16 kHz
 (20,352 animation frames); with N GPUs every rank takes its own 32 clips (weak scaling) and the per-frame
-dgrad rows of all ranks are reassembled on every rank with an RCCL all-gather issued chunk by chunk so that
-it overlaps the next chunk's compute (inside the timed region).
+dgrad rows of all ranks are reassembled on every rank inside the timed region: either an RCCL all-gather of the rows
+issued chunk by chunk so that it overlaps the next chunk's compute (`--gather dgrad`), or an RCCL all-gather of the PCA
+coefficients followed by a local, bit-identical re-expansion of the peers' rows (`--gather expand`); the default `auto`
+times both before the measurement and uses the faster (reported in `config`).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fused frequency-LSTM recurrence freq_lstm_v2_kernel,
 fp32 MFMA), measured live with HIP events on the launch stream; `cpu_baseline` times the CPU port of the reference
@@ -42,9 +44,12 @@ def parse():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--sample-rate", type=int, default=16000)
     ap.add_argument("--chunk", type=int, default=8192, help="frames per encoder launch group")
-    ap.add_argument("--gather", choices=["dgrad", "coef", "none", "direct", "mesh"], default="dgrad",
-                    help="what is reassembled on every rank at N > 1: dgrad = RCCL all-gather of the output rows, chunk by chunk (default); "
-                         "coef = of the PCA coefficients; direct = the regressor stores each row straight into every peer's gathered "
+    ap.add_argument("--gather", choices=["auto", "dgrad", "expand", "coef", "none", "direct", "mesh"], default="auto",
+                    help="how the output rows of all ranks are reassembled on every rank at N > 1: dgrad = RCCL all-gather of the rows, "
+                         "chunk by chunk; expand = RCCL all-gather of the PCA coefficients (1 KB instead of 359 KB per frame), every "
+                         "rank expands its peers' frames with the regressor's own last stage (bit-identical rows); auto (default) = "
+                         "both are timed for two untimed-region steps before the measurement and the faster one is used; "
+                         "coef = only the coefficients are gathered (no rows); direct = the regressor stores each row straight into every peer's gathered "
                          "buffer over xGMI (one-shot direct all-gather, no collective); mesh = dgrad -> seek -> mesh on the device, "
                          "then all-gather of the vertices (60 KB instead of 359 KB per frame)")
     ap.add_argument("--mesh-stage", action="store_true", help="run the seek + mesh post-path stage inside the timed step (implied by --gather mesh)")
@@ -177,19 +182,29 @@ def main():
     spk = torch.full((F,), 2, dtype=torch.int64, device=dev)          # speaker "m1"
     eng.check_speaker_ids(spk)                                         # once, outside the timed region (a host sync)
     feat = torch.empty((F, 64, 128, 3), dtype=torch.float32, device=dev)
-    width = eng.out_dim if a.gather != "coef" else eng.coef_dim
-    gatherer = direct = None
     all_counts = sdist.frame_counts_all(F) if (world > 1 and a.ragged_seconds) else [F] * world
     F_all = int(sum(all_counts))
-    if world > 1 and a.gather in ("dgrad", "coef"):
-        gatherer = sdist.FrameGatherer(all_counts, width, torch.float32, dev, a.chunk)
-    if a.gather == "direct":
-        if world == 1:
-            raise SystemExit("--gather direct needs N > 1 (it replaces the all-gather)")
-        direct = sdist.DirectGatherer(all_counts, eng.out_dim, dev)
-        out = direct.dests[0]                                       # this rank's slot of its own gathered buffer
-    else:
-        out = torch.empty((F, eng.out_dim), dtype=torch.float32, device=dev)
+    if world == 1 and a.gather == "direct":
+        raise SystemExit("--gather direct needs N > 1 (it replaces the all-gather)")
+
+    class Mode:          # how the rows are reassembled: set once (or, for auto, after the two candidates were timed)
+        kind = gatherer = direct = out = None
+
+    def set_mode(kind):
+        Mode.kind, Mode.gatherer, Mode.direct, Mode.out = kind, None, None, None
+        torch.cuda.empty_cache()
+        if world > 1 and kind in ("dgrad", "coef"):
+            Mode.gatherer = sdist.FrameGatherer(all_counts, eng.out_dim if kind == "dgrad" else eng.coef_dim, torch.float32, dev, a.chunk)
+        if world > 1 and kind == "expand":
+            Mode.gatherer = sdist.ExpandGatherer(all_counts, eng, dev, a.chunk)
+            Mode.out = Mode.gatherer.own(0, F)                          # own rows are written in place
+        elif kind == "direct":
+            Mode.direct = sdist.DirectGatherer(all_counts, eng.out_dim, dev)
+            Mode.out = Mode.direct.dests[0]                             # this rank's slot of its own gathered buffer
+        else:
+            Mode.out = torch.empty((F, eng.out_dim), dtype=torch.float32, device=dev)
+
+    set_mode(a.gather if (world > 1 and a.gather != "auto") else "dgrad")
 
     # ---- optional post-path stage: saber.stream.seek to the video rate fused into the dgrad -> mesh solve
     mesh = None
@@ -218,22 +233,22 @@ def main():
                 z, _ = eng.encoder(feat[f0:f1], want_align=False, frame_clip=frame_clip[f0:f1], frame_start=frame_start[f0:f1], hop=hop)
             else:
                 z, _ = eng.encoder(feat[f0:f1], want_align=False)
-            if direct is not None:        # rows go to this rank's slot in EVERY rank's gathered buffer, written by the epilogue
-                eng.regress_multi(z, spk[f0:f1], direct.dest_views(f0, f1), check_ids=False)
+            if Mode.direct is not None:   # rows go to this rank's slot in EVERY rank's gathered buffer, written by the epilogue
+                eng.regress_multi(z, spk[f0:f1], Mode.direct.dest_views(f0, f1), check_ids=False)
                 return None
-            coef, o = eng.regress(z, spk[f0:f1], want_coef=(a.gather == "coef"), out=out[f0:f1], check_ids=False)
-            return o if a.gather == "dgrad" else coef
+            coef, o = eng.regress(z, spk[f0:f1], want_coef=(Mode.kind in ("coef", "expand")), out=Mode.out[f0:f1], check_ids=False)
+            return o if Mode.kind == "dgrad" else coef
 
         # every rank issues the SAME number of collectives, also when shards are ragged (sdfa_amd/dist.py: run_chunks)
-        sdist.run_chunks(F, a.chunk, gatherer, compute)
+        sdist.run_chunks(F, a.chunk, Mode.gatherer, compute)
         if mesh is not None:
             solver, plan, verts, vgather = mesh
-            solver.get_mesh_seek(out, plan, out=verts)
+            solver.get_mesh_seek(Mode.out, plan, out=verts)
             if vgather is not None:
                 vgather.gather_chunk(verts.view(plan.n_queries, -1), 0)
                 vgather.finish()
-        if direct is not None:
-            direct.finish()
+        if Mode.direct is not None:
+            Mode.direct.finish()
 
     def fence():
         if world > 1:
@@ -261,7 +276,40 @@ def main():
         eng.profile(False)
         return float(tmax.item()), st
 
+    auto = None
+    if world > 1 and a.gather == "auto":
+        # both reassembly forms do the full job (every rank ends up holding every rank's rows); which is faster depends on
+        # what RCCL makes of a 7.3 GB-per-rank all-gather on this node, so measure: one warm step + two timed, max over ranks
+        auto = {}
+        for kind in ("dgrad", "expand"):
+            set_mode(kind)
+            step(False); fence()
+            t0 = time.perf_counter()
+            step(False); step(False); fence()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            auto[kind] = float(t.item()) / 2 * 1e3
+        best = min(auto, key=auto.get)                                  # identical on every rank (all-reduced times)
+        if best != Mode.kind:
+            set_mode(best)
+
     dt, stages = timed(False)
+    gather_check = None
+    if world > 1 and Mode.kind in ("dgrad", "expand", "direct"):
+        # every rank holds every rank's rows: order-independent integer checksum (bit patterns summed in int64) of each rank's
+        # own rows against the same rows as they arrived here
+        def cks(t):
+            return t.contiguous().view(torch.int32).sum(dtype=torch.int64)
+        mine = cks(Mode.out).view(1)
+        sums = [torch.empty(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(sums, mine)
+        holder = Mode.gatherer if Mode.gatherer is not None else Mode.direct
+        ok = all(int(sum(cks(v) for v in holder.rows(r)).item()) == int(sums[r].item()) for r in range(world))
+        okt = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        gather_check = bool(okt.item())
+        if not gather_check:
+            raise SystemExit(f"rank {rank}: gathered rows differ from the owners' rows (gather mode {Mode.kind})")
     n_chunks = (F + a.chunk - 1) // a.chunk
     shared = None
     if not a.no_column_sharing:
@@ -300,7 +348,9 @@ def main():
                                     if not a.ragged_seconds else
                                     f"stream of {C} sentences, {a.ragged_seconds} s@{sr} Hz synthetic PCM per GPU -> {a.head} (BASELINE configs[4] rehearsal)"),
                        "clips_per_gpu": C, "frames_per_gpu": F, "head": a.head, "chunk_frames": a.chunk,
-                       "gather": a.gather if world > 1 else "none (1 GPU)", "weights": "synthetic seed 1234",
+                       "gather": Mode.kind if world > 1 else "none (1 GPU)",
+                       "gather_auto_ms_per_step": None if auto is None else {k: round(v, 2) for k, v in auto.items()},
+                       "gather_checksum_ok": gather_check, "weights": "synthetic seed 1234",
                        "mesh_stage": None if mesh is None else f"seek to 60 fps + mesh solve, {mesh[1].n_queries} video frames x {mesh[0].n_verts} vertices per GPU per step"},
             "roofline": {"kernel": "freq_lstm_v2_kernel", "bound": "mfma", "achieved": round(achieved, 2),
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),

@@ -198,6 +198,15 @@ int sdfa_regress_forward_multi(const sdfa_model *m, const float *d_z, const int6
                                float *d_coef, float *const *h_d_outs, int n_outs, void *d_workspace,
                                int64_t workspace_bytes, void *stream);
 
+/* The PCA expansion alone: coefficients (as sdfa_regress_forward's d_coef returns them) -> output rows, bit-identical to the
+ * rows the regressor itself writes for the same coefficients.  PcaInversion.forward
+ * (speech_anime/modules/output_module.py:94-116) + data_to_anime_feat (speech_anime/model/model.py:246-257).
+ * Multi-GPU use (sdfa_amd/dist.py ExpandGatherer): ranks all-gather the 1 KB-per-frame coefficients instead of the
+ * 359 KB-per-frame dgrad rows and every rank expands the peers' frames locally.
+ *   d_coef  [n_frames][coef_dim]   d_out  [n_frames][out_dim]   alignment as for sdfa_regress_forward */
+int sdfa_expand_coef(const sdfa_model *m, const float *d_coef, int64_t n_frames, float *d_out, void *d_workspace,
+                     int64_t workspace_bytes, void *stream);
+
 /* Debug / parity taps: copy an intermediate activation of the LAST sdfa_encoder_forward call out of
  * the workspace in the reference's layout.  what: 0 = pool1 (n,32,64,64)  1 = conv3 (n,64,32,64)
  * 2 = freq-lstm (n,256,64)  3 = bilstm (n,64,512).  Used by tests only. */

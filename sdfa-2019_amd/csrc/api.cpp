@@ -893,6 +893,38 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
 }
 
 // ------------------------------------------------------------------------------------------------
+// PCA expansion of N frames' coefficients (K4, 288 / 64 rows): out[n][o] = sum_k coef[k][n] * basis[k][o] + means[o]
+// (rows = frames), stored to every destination.  PcaInversion.forward, speech_anime/modules/output_module.py:94-116
+static hipError_t expand_rows(const sdfa_model *m, const float *coef, int64_t N, int64_t Nc, int64_t f0,
+                              float *const *h_d_outs, int n_outs, hipStream_t s) {
+    float *d_out = h_d_outs[0];
+    if (m->pca_n == 2 && !g_sdfa_pca_unfused) {
+        // dgrad head: both bases in one fp32 kernel (all precision modes) so that every output line is written
+        // once, whole (pca.hip)
+        PcaArgs pa{};
+        pa.coef = coef; pa.basis_s = m->pca_q[0]; pa.basis_r = m->pca_q[1]; pa.mean_s = m->pca_bias[0]; pa.mean_r = m->pca_bias[1];
+        pa.out = d_out + f0 * m->out_dim; pa.N = N; pa.Nc = Nc; pa.out_dim = m->out_dim;
+        pa.n_extra = n_outs - 1;
+        for (int x = 1; x < n_outs; ++x) pa.out_extra[x - 1] = h_d_outs[x] + f0 * m->out_dim;
+        pa.ld_s = m->pca_ld[0]; pa.ld_r = m->pca_ld[1]; pa.cols_s = m->pca_cols[0]; pa.cols_r = m->pca_cols[1];
+        return sdfa_launch_pca_dgrad(pa, s);
+    }
+    for (int b = 0; b < m->pca_n; ++b) {
+        GemmArgs g{};
+        g.P = coef + (int64_t)m->pca_k0[b] * Nc; g.Q = m->pca_q[b]; g.D = d_out + f0 * m->out_dim;
+        g.bias = m->pca_bias[b]; g.bias_on_q = 1;
+        g.ldp = Nc; g.ldq = m->pca_ld[b]; g.ldd = m->out_dim; g.Ppad = Nc; g.Qpad = m->pca_ld[b]; g.Pstore = N;
+        g.Qreal = m->pca_cols[b]; g.K = m->pca_K[b]; g.seg_k = g.K; g.act = ACT_NONE; g.out_mode = OUT_ROW;
+        g.col_group = m->pca_group[b]; g.col_stride = 9; g.col_off = m->pca_off[b];
+        g.n_extra = n_outs - 1;
+        for (int x = 1; x < n_outs; ++x) g.D_extra[x - 1] = h_d_outs[x] + f0 * m->out_dim;
+        g.terms = stage_terms(m, STAGE_REGRESSOR);
+        hipError_t e = sdfa_launch_gemm(g, s);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 int sdfa_regress_forward(const sdfa_model *m, const float *d_z, const int64_t *d_speaker_id, int64_t n_frames,
                          float *d_coef, float *d_out, void *d_workspace, int64_t workspace_bytes, void *stream) {
     float *one[1] = {d_out};
@@ -954,33 +986,43 @@ int sdfa_regress_forward_multi(const sdfa_model *m, const float *d_z, const int6
         }
         pf.end();
         if (d_out) {
-            // PCA expansion: out[n][o] = sum_k coef[k][n] * basis[k][o] + means[o]   (rows = frames)
             pf.begin("pca");
-            if (m->pca_n == 2 && !g_sdfa_pca_unfused) {
-                // dgrad head: both bases in one fp32 kernel (all precision modes) so that every output line is written
-                // once, whole (pca.hip)
-                PcaArgs pa{};
-                pa.coef = coef; pa.basis_s = m->pca_q[0]; pa.basis_r = m->pca_q[1]; pa.mean_s = m->pca_bias[0]; pa.mean_r = m->pca_bias[1];
-                pa.out = d_out + f0 * m->out_dim; pa.N = N; pa.Nc = Nc; pa.out_dim = m->out_dim;
-                pa.n_extra = n_outs - 1;
-                for (int x = 1; x < n_outs; ++x) pa.out_extra[x - 1] = h_d_outs[x] + f0 * m->out_dim;
-                pa.ld_s = m->pca_ld[0]; pa.ld_r = m->pca_ld[1]; pa.cols_s = m->pca_cols[0]; pa.cols_r = m->pca_cols[1];
-                HIP_TRY(sdfa_launch_pca_dgrad(pa, s));
-            } else
-            for (int b = 0; b < m->pca_n; ++b) {
-                GemmArgs g{};
-                g.P = coef + (int64_t)m->pca_k0[b] * Nc; g.Q = m->pca_q[b]; g.D = d_out + f0 * m->out_dim;
-                g.bias = m->pca_bias[b]; g.bias_on_q = 1;
-                g.ldp = Nc; g.ldq = m->pca_ld[b]; g.ldd = m->out_dim; g.Ppad = Nc; g.Qpad = m->pca_ld[b]; g.Pstore = N;
-                g.Qreal = m->pca_cols[b]; g.K = m->pca_K[b]; g.seg_k = g.K; g.act = ACT_NONE; g.out_mode = OUT_ROW;
-                g.col_group = m->pca_group[b]; g.col_stride = 9; g.col_off = m->pca_off[b];
-                g.n_extra = n_outs - 1;
-                for (int x = 1; x < n_outs; ++x) g.D_extra[x - 1] = h_d_outs[x] + f0 * m->out_dim;
-                g.terms = stage_terms(m, STAGE_REGRESSOR);
-                HIP_TRY(sdfa_launch_gemm(g, s));
-            }
+            HIP_TRY(expand_rows(m, coef, N, Nc, f0, h_d_outs, n_outs, s));
             pf.end();
         }
+    }
+    return SDFA_OK;
+}
+
+int sdfa_expand_coef(const sdfa_model *m, const float *d_coef, int64_t n_frames, float *d_out, void *d_workspace,
+                     int64_t workspace_bytes, void *stream) {
+    if (!m || !m->finalized) return fail(SDFA_ESTATE, "expand_coef: model not finalised");
+    if (n_frames == 0) return SDFA_OK;
+    if (!d_coef || !d_out || !d_workspace || n_frames < 0) return fail(SDFA_EINVAL, "expand_coef: bad argument");
+    if ((uintptr_t)d_workspace & 15) return fail(SDFA_EINVAL, "expand_coef: d_workspace must be 16-byte aligned");
+    if (m->head == SDFA_HEAD_DGRAD && ((uintptr_t)d_out & 15)) return fail(SDFA_EINVAL, "expand_coef: d_out must be 16-byte aligned for the dgrad head");
+    if (((uintptr_t)d_out | (uintptr_t)d_coef) & 3) return fail(SDFA_EINVAL, "expand_coef: pointers must be 4-byte aligned");
+    const int64_t cap = capacity(workspace_bytes, m->keep);
+    if (cap < 128) return fail(SDFA_ENOSPACE, "expand_coef: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    Prof pf{m, s};
+    float *ws = (float *)d_workspace;
+    for (int64_t f0 = 0; f0 < n_frames; f0 += cap) {
+        const int64_t N = std::min(cap, n_frames - f0);
+        const int64_t Nc = round_up(N, 128);
+        const Ws w = layout(Nc, m->keep);
+        float *coef = ws + w.R + 1280 * Nc;                  // the regressor's coefficient slab: same place, same layout
+        const float *src = d_coef + f0 * m->coef_dim;
+        pf.begin("pca");
+        if (m->head == SDFA_HEAD_DGRAD) {
+            HIP_TRY(sdfa_launch_rows_seg_to_k4(src, m->coef_dim, N, 0, SDFA_COEF_SCALE, coef, Nc, 0, 96, s));
+            HIP_TRY(sdfa_launch_rows_seg_to_k4(src, m->coef_dim, N, SDFA_COEF_SCALE, SDFA_COEF_ROTAT, coef, Nc, 96, 192, s));
+        } else {
+            HIP_TRY(sdfa_launch_rows_seg_to_k4(src, m->coef_dim, N, 0, SDFA_COEF_OFFSETS, coef, Nc, 0, 64, s));
+        }
+        float *outs[1] = {d_out};
+        HIP_TRY(expand_rows(m, coef, N, Nc, f0, outs, 1, s));
+        pf.end();
     }
     return SDFA_OK;
 }

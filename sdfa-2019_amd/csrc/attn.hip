@@ -117,6 +117,20 @@ __global__ void rows_to_k4_kernel(const float *__restrict__ src, int64_t N, int 
     }
 }
 
+// row-major src[n*src_ld + c0 + j], j < nf  ->  K4 features f0 .. f0+nf_pad-1 (f0, nf_pad multiples of 4); features past nf
+// and columns n >= N are zero-filled
+__global__ void rows_seg_to_k4_kernel(const float *__restrict__ src, int64_t src_ld, int64_t N, int c0, int nf,
+                                      float *__restrict__ dst, int64_t ld, int f0, int nf_pad) {
+    const int64_t n = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    if (n >= ld) return;
+    for (int q = threadIdx.x >> 6; q < nf_pad / 4; q += blockDim.x >> 6) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (n < N && 4 * q + e < nf) ? src[n * src_ld + c0 + 4 * q + e] : 0.f;
+        st4(dst + ((int64_t)(f0 / 4 + q) * ld + n) * 4, make_float4(v[0], v[1], v[2], v[3]));
+    }
+}
+
 // K4 [.. /4][ld] features f0 .. f0+nf-1  ->  row-major dst[n*dst_ld + (f - f0)]
 __global__ void k4_to_rows_kernel(const float *__restrict__ src, int64_t ld, int64_t N, int f0, int nf,
                                   float *__restrict__ dst, int64_t dst_ld) {
@@ -162,6 +176,12 @@ hipError_t sdfa_launch_attn(const AttnArgs &a, hipStream_t s) {
 
 hipError_t sdfa_launch_rows_to_k4(const float *src, int64_t N, int F, float *dst, int64_t ld, hipStream_t s) {
     hipLaunchKernelGGL(rows_to_k4_kernel, dim3((unsigned)((ld + 63) / 64)), dim3(256), 0, s, src, N, F, dst, ld);
+    return hipGetLastError();
+}
+
+hipError_t sdfa_launch_rows_seg_to_k4(const float *src, int64_t src_ld, int64_t N, int c0, int nf, float *dst, int64_t ld,
+                                      int f0, int nf_pad, hipStream_t s) {
+    hipLaunchKernelGGL(rows_seg_to_k4_kernel, dim3((unsigned)((ld + 63) / 64)), dim3(256), 0, s, src, src_ld, N, c0, nf, dst, ld, f0, nf_pad);
     return hipGetLastError();
 }
 

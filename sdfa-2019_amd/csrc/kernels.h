@@ -134,6 +134,8 @@ hipError_t sdfa_launch_attn(const AttnArgs &a, hipStream_t s);
 // ---- layout helpers --------------------------------------------------------------------------
 // row-major [n][F] (n < N) -> K4 [F/4][ld]  (zero for n >= N), and back
 hipError_t sdfa_launch_rows_to_k4(const float *src, int64_t N, int F, float *dst, int64_t ld, hipStream_t s);
+hipError_t sdfa_launch_rows_seg_to_k4(const float *src, int64_t src_ld, int64_t N, int c0, int nf, float *dst, int64_t ld,
+                                      int f0, int nf_pad, hipStream_t s);
 hipError_t sdfa_launch_k4_to_rows(const float *src, int64_t ld, int64_t N, int F, int f0, int nf, float *dst,
                                   int64_t dst_ld, hipStream_t s);
 // debug taps (tests): K4 [F/4][Mc] with m = t*Nc+n  ->  reference layouts

@@ -122,6 +122,54 @@ class FrameGatherer:
         return torch.cat([v for r in range(self.world) for v in self.rows(r)], 0)
 
 
+class ExpandGatherer:
+    """Reassembles the per-frame output on every rank WITHOUT moving it: the regressor's output is a fixed linear map of
+    the PCA coefficients (output_module.py:94-116), 1 KB per frame against 359 KB of dgrad, so the ranks all-gather the
+    coefficients (RCCL, chunk by chunk as FrameGatherer does) and every rank expands its peers' frames locally with the
+    same kernel that wrote its own (Engine.expand_coef -> sdfa_expand_coef: bit-identical rows).  Per step and rank this
+    trades (world - 1) x 7.3 GB over xGMI for (world - 1) x one extra PCA expansion of a shard (4.8 ms for 20,352 frames).
+
+    `buf` is [sum(counts)][out_dim] in rank order; a rank's own rows are written into its slot directly (`own(f0, f1)` is
+    the `out=` of Engine.regress)."""
+
+    def __init__(self, counts, engine, device, chunk_len, group=None):
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.counts = [int(c) for c in counts]
+        self.engine = engine
+        self.offsets = [0]
+        for c in self.counts:
+            self.offsets.append(self.offsets[-1] + c)
+        self.coefs = FrameGatherer(self.counts, engine.coef_dim, torch.float32, device, chunk_len, group)
+        self.n_chunks, self.chunk = self.coefs.n_chunks, self.coefs.chunk
+        self.buf = torch.empty((self.offsets[-1], engine.out_dim), dtype=torch.float32, device=device)
+
+    def own(self, f0, f1):
+        lo = self.offsets[self.rank]
+        return self.buf[lo + f0: lo + f1]
+
+    def gather_chunk(self, coef_rows, chunk_index):
+        self.coefs.gather_chunk(coef_rows, chunk_index)
+
+    def finish(self):
+        self.coefs.finish()
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            f0 = self.offsets[r]
+            for view in self.coefs.rows(r):            # per-chunk views (even shards) or one view (ragged)
+                for g0 in range(0, view.shape[0], self.chunk):
+                    c = view[g0: g0 + self.chunk]
+                    self.engine.expand_coef(c if c.is_contiguous() else c.contiguous(), out=self.buf[f0: f0 + c.shape[0]])
+                    f0 += c.shape[0]
+
+    def rows(self, rank):
+        return [self.buf[self.offsets[rank]: self.offsets[rank + 1]]]
+
+    def gathered(self):
+        return self.buf
+
+
 class DirectGatherer:
     """One-shot direct all-gather over the fully connected xGMI mesh, independent of RCCL's
     algorithm choice: every rank owns a gathered buffer [sum(counts)][width] in rank order; each rank maps every peer's

@@ -212,6 +212,19 @@ class Engine(FrontendOnly):
         check(lib.sdfa_regress_forward_multi(self._m, _ptr(z), _ptr(spk), n, _ptr(coef), arr, len(ptrs), _ptr(ws), ws.numel(), _stream()))
         return coef
 
+    def expand_coef(self, coef, out=None):
+        """PCA coefficients (n, coef_dim) -> output rows (n, out_dim): the regressor's last stage alone (sdfa_expand_coef),
+        bit-identical to what `regress` writes for the same coefficients."""
+        n = coef.shape[0]
+        assert coef.is_cuda and coef.dtype == torch.float32 and coef.is_contiguous() and coef.shape[1] == self.coef_dim
+        if out is None:
+            out = torch.empty((n, self.out_dim), dtype=torch.float32, device=self.device)
+        assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (n, self.out_dim)
+        if n:
+            ws = self.workspace(min(n, self.max_frames))
+            check(lib.sdfa_expand_coef(self._m, _ptr(coef), n, _ptr(out), _ptr(ws), ws.numel(), _stream()))
+        return out
+
     def forward(self, audio_feat, speaker_id, want_coef=False):
         z, align = self.encoder(audio_feat)
         coef, out = self.regress(z, speaker_id, want_coef=want_coef)

@@ -60,6 +60,66 @@ def test_sharded_gather_reassembles_clip_order(frames_per_clip):
         assert np.array_equal(out, expect), rank
 
 
+class _LinearEngine:
+    """Stand-in for Engine on CPU: the expansion is a fixed linear map of the coefficients, as the PCA stage is."""
+    coef_dim, out_dim = 5, 12
+
+    def __init__(self):
+        rs = np.random.RandomState(3)
+        self.basis = torch.tensor(rs.normal(0, 1, (self.coef_dim, self.out_dim)).astype(np.float32))
+        self.mean = torch.tensor(rs.normal(0, 1, self.out_dim).astype(np.float32))
+
+    def expand_coef(self, coef, out=None):
+        r = coef @ self.basis + self.mean
+        if out is None:
+            return r
+        out.copy_(r)
+        return out
+
+
+def _expand_worker(rank, world, port, counts_in, chunk, q):
+    import sys
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(here, "sdfa-2019_amd"))
+    from sdfa_amd import dist as sd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = _LinearEngine()
+    n = counts_in[rank]
+    coef = torch.tensor(np.random.RandomState(100 + rank).normal(0, 1, (n, eng.coef_dim)).astype(np.float32))
+    counts = sd.frame_counts_all(n)
+    g = sd.ExpandGatherer(counts, eng, "cpu", chunk)
+    for step in range(2):
+        g.buf.fill_(float("nan"))
+
+        def compute(f0, f1):
+            eng.expand_coef(coef[f0:f1], out=g.own(f0, f1))         # the regressor writes this rank's rows in place
+            return coef[f0:f1]
+        sd.run_chunks(n, chunk, g, compute)
+    q.put((rank, counts, g.gathered().numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("counts", [[8, 8], [9, 3], [2, 11]])
+def test_expand_gather_rebuilds_every_ranks_rows(counts):
+    """ExpandGatherer: coefficients travel, rows are rebuilt on every rank, rank order, even and ragged shards."""
+    world, chunk = 2, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_expand_worker, args=(r, world, port, counts, chunk, q)) for r in range(world)]
+    for p in procs: p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs: p.join(timeout=60)
+    eng = _LinearEngine()
+    expect = np.concatenate([(torch.tensor(np.random.RandomState(100 + r).normal(0, 1, (counts[r], 5)).astype(np.float32)) @ eng.basis + eng.mean).numpy()
+                             for r in range(world)])
+    for rank, got_counts, out in res:
+        assert got_counts == counts
+        assert np.array_equal(out, expect), rank
+
+
 def test_shard_range_partitions():
     import sys
     from sdfa_amd.dist import shard_range

@@ -302,6 +302,29 @@ def test_pca_basis_through_lds_is_bitwise_identical(synth_sd):
         assert torch.equal(a, b), n
 
 
+@pytest.mark.parametrize("head", ["dgrad", "offsets"])
+def test_expand_coef_rebuilds_the_regressors_rows_bitwise(synth_sd, golden, head):
+    """sdfa_expand_coef(coefficients) == the rows sdfa_regress_forward wrote for them (ExpandGatherer relies on it), both
+    heads, ragged sizes incl. more frames than one workspace pass; and the coefficients are the reference fixture's."""
+    eng = Engine(synth_sd[head], max_frames=256)
+    rs = np.random.RandomState(31)
+    for n in (1, 130, 700):
+        z = _t(rs.normal(0, 1, (n, 512)).astype(np.float32))
+        spk = torch.from_numpy(rs.randint(0, 8, n))
+        coef, rows = eng.regress(z, spk, want_coef=True)
+        again = eng.expand_coef(coef)
+        assert again.shape == rows.shape and torch.equal(again, rows), (head, n)
+    out = torch.full((5, eng.out_dim), float("nan"), device="cuda")
+    eng.expand_coef(coef[:5].contiguous(), out=out)
+    assert torch.equal(out, rows[:5])
+    assert eng.expand_coef(coef[:0].contiguous()).shape == (0, eng.out_dim)
+    if head == "dgrad":
+        g = golden["model_dgrad"]
+        ref_coef = np.ascontiguousarray(np.concatenate([g["coef_scale"].reshape(8, -1), g["coef_rotat"].reshape(8, -1)], 1), dtype=np.float32)
+        got = eng.expand_coef(_t(ref_coef)).cpu().numpy()       # the REFERENCE's coefficients through this expansion
+        assert np.abs(got[:, ::97] - g["dgrad_stride97"]).max() <= 1e-4
+
+
 def test_time_lstm_workgroup_shapes_are_bitwise_identical(synth_sd, golden):
     """time_lstm_kernel<2> (8 waves x 64 frames), <1> (8 waves x 32 frames) and time_lstm_pair_kernel (4 waves x 32 frames, two
     workgroups per CU) contract k in the same order with the same cell arithmetic: z must not change by a bit."""
