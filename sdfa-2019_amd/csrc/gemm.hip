@@ -434,7 +434,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_big_kernel(GemmArgs a) {
 
     const float4 *__restrict__ P = reinterpret_cast<const float4 *>(a.P);
     const float4 *__restrict__ Q = reinterpret_cast<const float4 *>(a.Q);
-    const int nkq_total = a.K / 4, seg_kq = a.seg_k / 4, nstage = a.K / 32;
+    const int seg_kq = a.seg_k / 4, nstage = a.K / 32;
     // staging: item it = 0, 1 of a thread is (octet g = 2*it + (tid >> 8), column c = tid & 255): K4 quads 2g and 2g+1.
     // Uniform running bases + loop-invariant thread byte offsets, as in gemm_k4_kernel.
     const int c = tid & 255, g0 = tid >> 8;

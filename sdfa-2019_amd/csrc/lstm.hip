@@ -592,7 +592,6 @@ __global__ __launch_bounds__(512, 2) void time_lstm_kernel(TimeLstmArgs a) {
     const int64_t n0 = (int64_t)(blockIdx.x >> 1) * BT;
 
     const float4 *__restrict__ GX = reinterpret_cast<const float4 *>(a.GX);
-    const float4 *__restrict__ Ww = reinterpret_cast<const float4 *>(a.W) + (size_t)dir * 64 * 1024 + wave * 128 + l31;
     float4 *__restrict__ H = reinterpret_cast<float4 *>(a.H);
 
     f32x16 c[NT];
