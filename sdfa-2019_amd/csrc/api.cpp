@@ -631,7 +631,7 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
 namespace {
 
 struct Ws {
-    int64_t P1, X3, HF, Z, GX, H0, H1, KP, QC, QP, ZK, R, SH, ZU, total;   // offsets in floats
+    int64_t P1, X3, HF, Z, GX, H0, H1, KP, QC, QP, ZK, R, SH, ZU, CT, total;   // offsets in floats
 };
 
 Ws layout(int64_t Nc, bool keep) {
@@ -653,6 +653,7 @@ Ws layout(int64_t Nc, bool keep) {
     w.R = take(2560 * Nc);   // regressor scratch: trunk 512 | a 512 | b 256 | coef 288 (+ second branch a/b)
     w.SH = take(2 * Nc + 5 * Mc + Mc / 1024 + 128);   // column-sharing tables (int32 / int64 counters)
     w.ZU = keep ? take(256 * Mc) : w.P1; // freq-proj output over distinct columns (pool1 is dead by then)
+    w.CT = take(64);                     // work-queue heads of persistent kernels (ints)
     w.total = o;
     return w;
 }
@@ -836,7 +837,7 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
             pf.begin("conv23"); HIP_TRY(sdfa_launch_conv123(ca, s)); pf.end();
         }
 
-        FreqLstmArgs fa{ws + w.X3, m->fl_w, m->fl_b, ws + w.HF, Mc, d_ulimit, m->fl_wb, stage_terms(m, STAGE_BODY)};
+        FreqLstmArgs fa{ws + w.X3, m->fl_w, m->fl_b, ws + w.HF, Mc, d_ulimit, m->fl_wb, stage_terms(m, STAGE_BODY), reinterpret_cast<int *>(ws + w.CT)};
         pf.begin("freq_lstm"); HIP_TRY(sdfa_launch_freq_lstm(fa, s)); pf.end();
 
         GemmArgs g{};   // FreqLstm._proj: Linear(8192 -> 256) + bias

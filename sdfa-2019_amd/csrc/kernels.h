@@ -104,6 +104,7 @@ struct FreqLstmArgs {
     const int64_t *col_limit;   // see ConvArgs
     const void *Wb;      // mixed-precision modes: per direction bf16x8 [hi | lo][24 octets][512 rows] (lstm.hip)
     int terms;           // 0 = fp32 MFMA; 1 = bf16 MFMA; 3 = split-bf16 (hi/lo) MFMA
+    int *tile_counter;   // one int of workspace: the persistent form's work queue head (zeroed by the launcher)
 };
 hipError_t sdfa_launch_freq_lstm(const FreqLstmArgs &a, hipStream_t s);
 

@@ -19,6 +19,8 @@
 
 #ifdef SDFA_STAMPS
 __device__ unsigned long long g_lstamp[8];
+__device__ unsigned long long g_lspan[4] = {~0ull, 0ull, 0ull, 0ull};
+__device__ unsigned long long g_lxcd[8][4];   // per XCD (block id % 8): max end, sum of lifetimes, count, last start   // min start, max end, sum of lifetimes (100 MHz ticks), sum of lifetimes (shader cycles)
 #define LSTAMP(t) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
 #else
 #define LSTAMP(t)
@@ -269,22 +271,43 @@ __global__ __launch_bounds__(256, WGS) void freq_lstm_kernel(FreqLstmArgs a) {
 //   * the barrier after the K loop is a bare s_barrier (every LDS read has been consumed by an MFMA by then): it does
 //     not wait for the weight request in flight; the barrier at the end of the step waits for the DMA and the LDS writes
 //     but not for the acknowledgements of the hidden-state stores.
-template <bool SHARED>
+//
+// PERSIST (option freq_lstm_shape=5): the grid is two workgroups per CU and every workgroup takes (direction, column tile)
+// pairs from a queue head in the workspace until the queue is empty, instead of one hardware-dispatched workgroup per
+// pair.  Built because the stamps (tools/stamp_lstm2.py) show a CU slot empty 2.5-3 % of a launch between the end of one
+// 1.5 ms workgroup and the start of the next, plus +-2 % between XCDs under the static block-id -> XCD partition.
+// Bit-identical; measured 2.4-3.4 % SLOWER than hardware dispatch (48.3 -> 49.4 ms per 8192 frames), with or without an
+// initial phase offset between the two workgroups of a CU: kept as an option, not the default.
+template <bool SHARED, bool PERSIST>
 __global__ __launch_bounds__(256, 2) void freq_lstm_v2_kernel(FreqLstmArgs a) {
     constexpr int NJ = 2, BT = 64;
     __shared__ float4 sH[32][BT];
     __shared__ float4 sX[2][16][BT];
     __shared__ float sBias[512];
+    __shared__ int sTile;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    const int dir = (blockIdx.x >> 3) & 1;
-    const int64_t m0 = (int64_t)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) * BT;
-    if (SHARED && m0 >= *a.col_limit) return;
-
     const float4 *__restrict__ X3 = reinterpret_cast<const float4 *>(a.X3);
-    const float4 *__restrict__ W = reinterpret_cast<const float4 *>(a.W) + (size_t)dir * 48 * 512;
     float4 *__restrict__ HF = reinterpret_cast<float4 *>(a.HF);
+    const int n_tiles = (int)(a.Mc / BT) * 2;
+  for (;;) {      // PERSIST: one pass per tile taken from the queue; otherwise a single pass
+    int dir;
+    int64_t m0;
+    if (PERSIST) {
+        if (tid == 0) sTile = atomicAdd(a.tile_counter, 1);
+        __syncthreads();                       // (also: every wave has left the previous tile's last step)
+        const int t = __builtin_amdgcn_readfirstlane(sTile);
+        if (t >= n_tiles) break;               // queue empty: every workgroup gets here
+        dir = t & 1;
+        m0 = (int64_t)(t >> 1) * BT;
+        if (SHARED && m0 >= *a.col_limit) break;      // tiles come in column order: all later ones are past the limit too
+    } else {
+        dir = (blockIdx.x >> 3) & 1;
+        m0 = (int64_t)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) * BT;
+        if (SHARED && m0 >= *a.col_limit) return;
+    }
+    const float4 *__restrict__ W = reinterpret_cast<const float4 *>(a.W) + (size_t)dir * 48 * 512;
 
     sBias[tid] = a.bias[dir * 512 + tid];
     sBias[256 + tid] = a.bias[dir * 512 + 256 + tid];
@@ -340,6 +363,10 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_v2_kernel(FreqLstmArgs a) {
     }
     float4 wn0, wn1, wn2, wn3;
     FV_WLOAD(0, wn0, wn1, wn2, wn3)
+#ifdef SDFA_STAMPS
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, v_init = 0, v_k = 0, v_b1 = 0, v_ep = 0, v_b2 = 0;
+    const unsigned long long life_r0 = wall_clock64(), life_c0 = clock64();
+#endif
     __syncthreads();   // bias and the first x tile are in LDS (the fence drains the DMA)
 
     for (int s = 0; s < 32; ++s) {
@@ -352,6 +379,7 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_v2_kernel(FreqLstmArgs a) {
         // full s_waitcnt at the end of every K iteration, or spilled 253 registers.
         float4 wa0 = wn0, wa1 = wn1, wa2 = wn2, wa3 = wn3, wb0, wb1, wb2, wb3, ba0, ba1, bb0, bb1;
         f32x16 acc[4][NJ];
+        LSTAMP(t0)
 #pragma unroll
         for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
@@ -372,6 +400,7 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_v2_kernel(FreqLstmArgs a) {
 #define SDFA_PRIO_EPI 0
 #endif
         __builtin_amdgcn_s_setprio(SDFA_PRIO_MFMA);
+        LSTAMP(t1)
 #pragma unroll 1
         for (int kb = 0; kb < nkb; kb += 2) {
             FV_WLOAD(kb + 1, wb0, wb1, wb2, wb3)
@@ -388,9 +417,14 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_v2_kernel(FreqLstmArgs a) {
         }
         FV_WLOAD(0, wn0, wn1, wn2, wn3)     // k-block 0 for the NEXT step: in flight during the cell update (weights do not change)
         __builtin_amdgcn_s_setprio(SDFA_PRIO_EPI);
+#ifdef SDFA_STAMPS
+        asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]), "v"(acc[0][1]), "v"(acc[1][1]), "v"(acc[2][1]), "v"(acc[3][1]));   // all MFMAs done
+#endif
+        LSTAMP(t2)
         // every wave has finished reading sH / sX[cur] (all LDS reads were consumed by MFMAs, the wrap-around one is waited
         // for here); the weight request in flight is not waited for
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        LSTAMP(t3)
         if (s + 1 < 32) { XDMA(dir ? 30 - s : s + 1, cur ^ 1) }   // lands during the cell update; sX[cur ^ 1] was last read in step s - 1
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
@@ -410,8 +444,27 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_v2_kernel(FreqLstmArgs a) {
         // (the builtin wait is the same instruction again: the compiler's own waitcnt bookkeeping does not look inside asm
         // and would otherwise put a full vmcnt(0) in front of the next LDS read -- inside the K loop -- for the DMA's sake)
         __builtin_amdgcn_s_waitcnt(0x0078);     // gfx9 encoding: vmcnt = 8, expcnt = 7 (no wait), lgkmcnt = 0
+        LSTAMP(t4)
         asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef SDFA_STAMPS
+        LSTAMP(t5)
+        if (s > 0) { v_init += t1 - t0; v_k += t2 - t1; v_b1 += t3 - t2; v_ep += t4 - t3; v_b2 += t5 - t4; }
+#endif
     }
+#ifdef SDFA_STAMPS
+    if (lane == 0) {
+        atomicAdd(&g_lstamp[0], v_init); atomicAdd(&g_lstamp[1], v_k); atomicAdd(&g_lstamp[2], v_b1); atomicAdd(&g_lstamp[3], v_ep);
+        atomicAdd(&g_lstamp[4], v_b2); atomicAdd(&g_lstamp[6], 31ull);
+        if (wave == 0) {
+            const unsigned long long r1 = wall_clock64();
+            atomicMin(&g_lspan[0], life_r0); atomicMax(&g_lspan[1], r1);
+            atomicAdd(&g_lspan[2], r1 - life_r0); atomicAdd(&g_lspan[3], (unsigned long long)clock64() - life_c0);
+            atomicMax(&g_lxcd[blockIdx.x & 7][0], r1); atomicAdd(&g_lxcd[blockIdx.x & 7][1], r1 - life_r0); atomicAdd(&g_lxcd[blockIdx.x & 7][2], 1ull); atomicMax(&g_lxcd[blockIdx.x & 7][3], life_r0);
+        }
+    }
+#endif
+    if (!PERSIST) break;
+  }
 #undef XDMA
 #undef FV_WLOAD
 #undef FV_BLOAD
@@ -907,14 +960,40 @@ extern "C" int sdfa_debug_read_lstm_stamps(unsigned long long *out, int reset) {
     if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_lstamp), z, sizeof z) != hipSuccess) return -3; }
     return 0;
 }
+extern "C" int sdfa_debug_read_lstm_xcd(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lxcd), sizeof(unsigned long long) * 32) != hipSuccess) return -3;
+    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_lxcd), z, sizeof z) != hipSuccess) return -3; }
+    return 0;
+}
+extern "C" int sdfa_debug_read_lstm_span(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lspan), sizeof(unsigned long long) * 4) != hipSuccess) return -3;
+    if (reset) { unsigned long long z[4] = {~0ull, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_lspan), z, sizeof z) != hipSuccess) return -3; }
+    return 0;
+}
 #endif
 
-extern thread_local int g_sdfa_freq_lstm_shape;   // api.cpp ("freq_lstm_shape" option): 0 / 3 = freq_lstm_v2_kernel (default), 4 = freq_lstm_kernel 64 columns x 2 workgroups/CU, 1 = 32 x 4, 2 = 32 x 3
+extern thread_local int g_sdfa_freq_lstm_shape;   // api.cpp ("freq_lstm_shape" option): 0 / 3 = freq_lstm_v2_kernel (default), 5 = its persistent form, 4 = freq_lstm_kernel 64 columns x 2 workgroups/CU, 1 = 32 x 4, 2 = 32 x 3
 
 template <bool SHARED>
 static hipError_t launch_freq(const FreqLstmArgs &a, hipStream_t s) {
     if (g_sdfa_freq_lstm_shape == 0 || g_sdfa_freq_lstm_shape == 3) {      // default: the second form (+1.6 %, bit-identical)
-        hipLaunchKernelGGL((freq_lstm_v2_kernel<SHARED>), dim3((unsigned)(a.Mc / 64 * 2)), dim3(256), 0, s, a);
+        const unsigned n_tiles = (unsigned)(a.Mc / 64 * 2);
+        if (g_sdfa_freq_lstm_shape == 5) {      // persistent: two workgroups per CU pull tiles from a queue (bit-identical, 2-3 % slower: option only)
+            static const unsigned slots = [] {
+                int dev = 0, cus = 256;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+                return (unsigned)(2 * cus);
+            }();
+            hipError_t e = hipMemsetAsync(a.tile_counter, 0, sizeof(int), s);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((freq_lstm_v2_kernel<SHARED, true>), dim3(n_tiles < slots ? n_tiles : slots), dim3(256), 0, s, a);
+            return hipGetLastError();
+        }
+#ifdef SDFA_STAMPS   /* SDFA_LONE=1: 32 KB of unused dynamic LDS per workgroup (66 KB static) -> one workgroup per CU */
+        hipLaunchKernelGGL((freq_lstm_v2_kernel<SHARED, false>), dim3(n_tiles), dim3(256), getenv("SDFA_LONE") ? 32 * 1024 : 0, s, a);
+#else
+        hipLaunchKernelGGL((freq_lstm_v2_kernel<SHARED, false>), dim3(n_tiles), dim3(256), 0, s, a);
+#endif
         return hipGetLastError();
     }
     if (g_sdfa_freq_lstm_shape == 1)

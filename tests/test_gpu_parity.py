@@ -344,22 +344,25 @@ def test_time_lstm_workgroup_shapes_are_bitwise_identical(synth_sd, golden):
 
 
 def test_freq_lstm_kernel_forms_are_bitwise_identical(synth_sd, golden):
-    """freq_lstm_kernel and freq_lstm_v2_kernel (x tile by LDS-DMA, weights kept across the step, component-major MFMA issue)
-    accumulate every gate in the same order: not a bit may differ -- also through the column-sharing launch."""
+    """freq_lstm_kernel (4), freq_lstm_v2_kernel (3 = 0, the default) and its persistent form, two workgroups per CU pulling
+    tiles from a queue (5), accumulate every gate in the same order: not a bit may differ -- also through the column-sharing
+    launch, and when a persistent workgroup works through several tiles (1,100 frames = 2,304 tiles)."""
     from sdfa_amd import _lib
     clips = [synth.make_pcm(0, 32000), synth.make_pcm(5, 9088 + 777, "speechlike")]
     eng = Engine(synth_sd["dgrad"], max_frames=8192)
     feat, _, _ = eng.mel_frontend(clips, 16000)
     fc, fs, hop = eng.last_frame_table
     res = {}
-    for shape in (4, 3):
+    big = torch.rand((1100, 64, 128, 3), device="cuda")
+    for shape in (4, 0, 5):
         try:
             _lib.set_option("freq_lstm_shape", shape)
-            res[shape] = (eng.encoder(feat), eng.encoder(feat, frame_clip=fc, frame_start=fs, hop=hop))
+            res[shape] = (eng.encoder(feat), eng.encoder(feat, frame_clip=fc, frame_start=fs, hop=hop), eng.encoder(big))
         finally:
             _lib.set_option("freq_lstm_shape", 0)
-    for k in (0, 1):
-        assert torch.equal(res[4][k][0], res[3][k][0]) and torch.equal(res[4][k][1], res[3][k][1])
+    for k in (0, 1, 2):
+        for shape in (0, 5):
+            assert torch.equal(res[4][k][0], res[shape][k][0]) and torch.equal(res[4][k][1], res[shape][k][1]), (k, shape)
     assert torch.equal(res[4][0][0], res[4][1][0])
 
 

@@ -1,0 +1,42 @@
+"""Phase times of freq_lstm_v2_kernel from in-kernel s_memtime stamps (diagnostic build: make -C sdfa-2019_amd/csrc STAMPS=1).
+SDFA_LONE=1 in the environment launches one workgroup per CU (no partner on the SIMDs): what a step costs by itself."""
+import ctypes as C, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["SDFA_HIP_LIB"] = os.path.join(ROOT, "sdfa-2019_amd", "sdfa_amd", "libsdfa_hip_stamps.so")
+sys.path.insert(0, os.path.join(ROOT, "sdfa-2019_amd"))
+import torch
+from sdfa_amd import synth
+from sdfa_amd.engine import Engine
+lib = C.CDLL(os.environ["SDFA_HIP_LIB"])
+lib.sdfa_debug_read_lstm_stamps.argtypes = [C.c_void_p, C.c_int]
+eng = Engine(synth.make_state_dict("dgrad", 1234), max_frames=8192)
+x = torch.rand((8192, 64, 128, 3), device="cuda")
+out = (C.c_ulonglong * 8)()
+span = (C.c_ulonglong * 4)()
+xcd = (C.c_ulonglong * 32)()
+lib.sdfa_debug_read_lstm_xcd.argtypes = [C.c_void_p, C.c_int]
+lib.sdfa_debug_read_lstm_span.argtypes = [C.c_void_p, C.c_int]
+for rep in range(2):
+    lib.sdfa_debug_read_lstm_stamps(out, 1)
+    lib.sdfa_debug_read_lstm_span(span, 1)
+    lib.sdfa_debug_read_lstm_xcd(xcd, 1)
+    eng.profile(True)
+    z, _ = eng.encoder(x, want_align=False); torch.cuda.synchronize()
+    ms = eng.profile_ms("freq_lstm"); eng.profile(False)
+lib.sdfa_debug_read_lstm_stamps(out, 0)
+v = [int(o) for o in out]
+n = v[6]
+print(f"freq_lstm_v2_kernel ({'ONE workgroup per CU' if os.environ.get('SDFA_LONE') else 'two workgroups per CU'}): launch {ms:.2f} ms; per step (steps 1..31) and wave, shader cycles; 768 MFMAs alone = 49,152")
+for name, val in zip(("accumulator init + first operand reads", "K loop (24 k-blocks)", "barrier 1 (all waves done with K loop)", "x DMA + cell update + stores", "barrier 2 (h, x in LDS)"), v[:5]):
+    print(f"  {name:44s} {val / n:9.0f}")
+print(f"  total {sum(v[:5]) / n:9.0f}")
+lib.sdfa_debug_read_lstm_span(span, 0)
+t0, t1, life_ticks, life_cyc = (int(x) for x in span)
+slots = 256 * (1 if os.environ.get("SDFA_LONE") else 2)
+n_wg = 8192 * 2
+print(f"  launch span (first workgroup start -> last end) {(t1 - t0) / 100e3:.2f} ms; sum of workgroup lifetimes / {slots} slots = {life_ticks / slots / 100e3:.2f} ms "
+      f"-> slot occupancy {life_ticks / slots / (t1 - t0):.3f}; mean lifetime {life_ticks / n_wg / 100:.0f} us; shader clock inside workgroups {life_cyc / life_ticks * 100 / 1e3:.3f} GHz")
+lib.sdfa_debug_read_lstm_xcd(xcd, 0)
+for x in range(8):
+    end, life, cnt, last_start = (int(v) for v in xcd[4 * x: 4 * x + 4])
+    print(f"  XCD {x}: {cnt} workgroups, mean lifetime {life / max(cnt, 1) / 100:.0f} us, last start at {(last_start - t0) / 100e3:.2f} ms, last end at {(end - t0) / 100e3:.2f} ms")
