@@ -161,7 +161,7 @@ def main():
         _lib.check(_lib.lib.sdfa_debug_set_option(k.encode(), int(v)))
     sr = a.sample_rate
     sd = synth.make_state_dict(a.head, 1234)
-    eng = Engine(sd, device=dev, max_frames=a.chunk, precision=a.precision)
+    eng = Engine(sd, device=dev, max_frames=a.chunk, precision=a.precision, autotune=not any(kv.startswith("freq_lstm_shape=") for kv in a.opt))
 
     # ---- this rank's clips: global clip ids [rank*C, (rank+1)*C), PCM resident in HBM before timing
     C = a.clips_per_gpu
@@ -348,6 +348,7 @@ def main():
                                     if not a.ragged_seconds else
                                     f"stream of {C} sentences, {a.ragged_seconds} s@{sr} Hz synthetic PCM per GPU -> {a.head} (BASELINE configs[4] rehearsal)"),
                        "clips_per_gpu": C, "frames_per_gpu": F, "head": a.head, "chunk_frames": a.chunk,
+                       "freq_lstm_form": eng.freq_lstm_form,      # picked by sdfa_model_autotune in the first warm-up step (bit-identical forms)
                        "gather": Mode.kind if world > 1 else "none (1 GPU)",
                        "gather_auto_ms_per_step": None if auto is None else {k: round(v, 2) for k, v in auto.items()},
                        "gather_checksum_ok": gather_check, "weights": "synthetic seed 1234",

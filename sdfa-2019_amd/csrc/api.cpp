@@ -148,6 +148,7 @@ struct sdfa_model {
     int pca_n = 0;
     const float *pca_q[2], *pca_bias[2];
     int pca_K[2], pca_k0[2], pca_group[2], pca_off[2];
+    int freq_shape = 5;   // launch form of the fp32 frequency LSTM (kernels.h FreqLstmArgs::shape); sdfa_model_autotune measures and sets it
     int64_t pca_ld[2], pca_cols[2];
     int64_t out_dim, coef_dim;
     // profiling
@@ -779,6 +780,42 @@ int sdfa_model_set_precision(sdfa_model *m, int mode) {
 
 int sdfa_model_precision(const sdfa_model *m) { return m ? m->precision : SDFA_EINVAL; }
 
+// The four launch forms of the fp32 frequency LSTM are bit-identical and within 1-3 % of each other, in an order that is
+// a property of how the two resident workgroups of a CU happen to interleave: measure, don't guess.
+int sdfa_model_autotune(sdfa_model *m, int64_t n_frames, void *d_workspace, int64_t workspace_bytes, void *stream) {
+    if (!m || !m->finalized) return fail(SDFA_ESTATE, "autotune: model not finalised");
+    if (!d_workspace || n_frames <= 0 || ((uintptr_t)d_workspace & 15)) return fail(SDFA_EINVAL, "autotune: bad argument");
+    const int64_t cap = capacity(workspace_bytes, m->keep);
+    if (cap < 128) return fail(SDFA_ENOSPACE, "autotune: workspace too small");
+    const int64_t Nc = round_up(std::min(cap, n_frames), 128), Mc = 64 * Nc;
+    const Ws w = layout(Nc, m->keep);
+    float *ws = (float *)d_workspace;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(ws + w.X3, 0, (size_t)2048 * Mc * sizeof(float), s));      // any finite input: the kernel's time does not depend on the data
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    static const int forms[] = {5, 3, 7, 6};
+    float best_ms = 0.f;
+    int best = m->freq_shape, rc = SDFA_OK;
+    for (int form : forms) {
+        FreqLstmArgs fa{ws + w.X3, m->fl_w, m->fl_b, ws + w.HF, Mc, nullptr, m->fl_wb, 0, reinterpret_cast<int *>(ws + w.CT), form};
+        float ms = 0.f;
+        for (int rep = 0; rep < 3 && rc == SDFA_OK; ++rep) {      // one warm launch, two timed
+            if (rep == 1 && hipEventRecord(e0, s) != hipSuccess) rc = SDFA_EHIP;
+            if (sdfa_launch_freq_lstm(fa, s) != hipSuccess) rc = SDFA_EHIP;
+        }
+        if (rc == SDFA_OK && (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)) rc = SDFA_EHIP;
+        if (rc != SDFA_OK) break;
+        if (best_ms == 0.f || ms < best_ms) { best_ms = ms; best = form; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != SDFA_OK) return fail(rc, "autotune: a HIP call failed: %s", hipGetErrorString(hipGetLastError()));
+    m->freq_shape = best;
+    return best;
+}
+
 int sdfa_encoder_forward(const sdfa_model *m, const float *d_audio_feat, int64_t n_frames, float *d_z, float *d_align,
                          void *d_workspace, int64_t workspace_bytes, void *stream) {
     return encoder_impl(m, d_audio_feat, n_frames, nullptr, nullptr, 0, d_z, d_align, d_workspace, workspace_bytes, stream);
@@ -837,7 +874,8 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
             pf.begin("conv23"); HIP_TRY(sdfa_launch_conv123(ca, s)); pf.end();
         }
 
-        FreqLstmArgs fa{ws + w.X3, m->fl_w, m->fl_b, ws + w.HF, Mc, d_ulimit, m->fl_wb, stage_terms(m, STAGE_BODY), reinterpret_cast<int *>(ws + w.CT)};
+        FreqLstmArgs fa{ws + w.X3, m->fl_w, m->fl_b, ws + w.HF, Mc, d_ulimit, m->fl_wb, stage_terms(m, STAGE_BODY), reinterpret_cast<int *>(ws + w.CT),
+                        g_sdfa_freq_lstm_shape ? g_sdfa_freq_lstm_shape : m->freq_shape};
         pf.begin("freq_lstm"); HIP_TRY(sdfa_launch_freq_lstm(fa, s)); pf.end();
 
         GemmArgs g{};   // FreqLstm._proj: Linear(8192 -> 256) + bias

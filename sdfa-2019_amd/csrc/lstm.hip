@@ -20,6 +20,7 @@
 #ifdef SDFA_STAMPS
 __device__ unsigned long long g_lstamp[8];
 __device__ unsigned long long g_lspan[4] = {~0ull, 0ull, 0ull, 0ull};
+__device__ unsigned long long g_lsub[4];     // cell-update sub-phases: x DMA issue, columns 0-31, columns 32-63
 __device__ unsigned long long g_lxcd[8][4];   // per XCD (block id % 8): max end, sum of lifetimes, count, last start   // min start, max end, sum of lifetimes (100 MHz ticks), sum of lifetimes (shader cycles)
 #define LSTAMP(t) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
 #else
@@ -39,26 +40,53 @@ extern "C" int sdfa_debug_read_clockprobe(unsigned long long *out, int reset) {
 
 namespace {
 
+// fp32 MFMA and the vector ALU do NOT overlap on this chip -- neither across the waves of a SIMD nor inside one wave
+// (tools/mfma_cowave.hip, tools/mfma_shadow.hip: a wave streaming v_mfma_f32_32x32x2_f32 starves its partner's vector
+// instructions completely, and a vector instruction issued behind an MFMA of the same wave costs the matrix pipe its full
+// 4-5 cycles) -- so every vector instruction of the cell update is matrix-pipe time lost, and the update is written for
+// the fewest of them: two elements per instruction (v_pk_mul/add/fma_f32), exponent arguments negated / made absolute by
+// the source modifiers of v_exp_f32 instead of by separate multiplies.  Same operations on the same values as the scalar
+// form sigmoidf_acc / tanhf_acc of common.h (x * -log2e == -(x * log2e); (|x| * -2) * log2e == -|x * (2 log2e)|: a scaling by
+// two commutes with rounding), so the results are bit-identical to rounds 1-2.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 rcp2(f32x2 d) { return f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)}; }
+
+__device__ __forceinline__ f32x2 sigmoid2(f32x2 x) {      // 1 / (1 + exp(-x))
+    const f32x2 y = x * 1.4426950408889634f;
+    const f32x2 e = {__builtin_amdgcn_exp2f(-y.x), __builtin_amdgcn_exp2f(-y.y)};
+    return rcp2(e + 1.0f);
+}
+
+__device__ __forceinline__ f32x2 tanh2(f32x2 x) {         // (1 - e) / (1 + e), e = exp(-2|x|), sign restored
+    const f32x2 y = x * 2.8853900817779268f;
+    const f32x2 e = {__builtin_amdgcn_exp2f(-__builtin_fabsf(y.x)), __builtin_amdgcn_exp2f(-__builtin_fabsf(y.y))};
+    const f32x2 t = (1.0f - e) * rcp2(1.0f + e);
+    return f32x2{__builtin_copysignf(t.x, x.x), __builtin_copysignf(t.y, x.y)};
+}
+
 __device__ __forceinline__ void lstm_cell_quad(const f32x16 &ai, const f32x16 &af, const f32x16 &ag, const f32x16 &ao,
                                                f32x16 &c, int g, float4 &hq) {
-    float hv[4];
+    f32x2 hv[2];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int r = 4 * g + e;
+    for (int p = 0; p < 2; ++p) {
+        const int r = 4 * g + 2 * p;
+        f32x2 cp = {c[r], c[r + 1]};
 #ifdef SDFA_FAKE_CELL   /* timing experiment only: what does the cell math cost? */
-        { float cn = af[r] * c[r] + ai[r] * ag[r]; c[r] = cn; hv[e] = ao[r] * cn; continue; }
+        { const f32x2 cn = f32x2{af[r], af[r + 1]} * cp + f32x2{ai[r], ai[r + 1]} * f32x2{ag[r], ag[r + 1]}; c[r] = cn.x; c[r + 1] = cn.y; hv[p] = f32x2{ao[r], ao[r + 1]} * cn; continue; }
 #endif
         // (a fused form with one reciprocal per product -- 8 transcendental instructions per element instead of 10 --
         // measured the same in round 2 and changes the last bits: not taken)
-        float ig = sigmoidf_acc(ai[r]);
-        float fg = sigmoidf_acc(af[r]);
-        float gg = tanhf_acc(ag[r]);
-        float og = sigmoidf_acc(ao[r]);
-        float cn = fg * c[r] + ig * gg;
-        c[r] = cn;
-        hv[e] = og * tanhf_acc(cn);
+        const f32x2 ig = sigmoid2(f32x2{ai[r], ai[r + 1]});
+        const f32x2 fg = sigmoid2(f32x2{af[r], af[r + 1]});
+        const f32x2 gg = tanh2(f32x2{ag[r], ag[r + 1]});
+        const f32x2 og = sigmoid2(f32x2{ao[r], ao[r + 1]});
+        const f32x2 fc = fg * cp;                                   // rounded product first, then one fused multiply-add:
+        const f32x2 cn = __builtin_elementwise_fma(ig, gg, fc);     // what the scalar form compiled to in rounds 1-2
+        c[r] = cn.x; c[r + 1] = cn.y;
+        hv[p] = og * tanh2(cn);
     }
-    hq = make_float4(hv[0], hv[1], hv[2], hv[3]);
+    hq = make_float4(hv[0].x, hv[0].y, hv[1].x, hv[1].y);
 }
 
 // ------------------------------------------------------------------------------------ frequency LSTM
@@ -364,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_v2_kernel(FreqLstmArgs a) {
     float4 wn0, wn1, wn2, wn3;
     FV_WLOAD(0, wn0, wn1, wn2, wn3)
 #ifdef SDFA_STAMPS
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, v_init = 0, v_k = 0, v_b1 = 0, v_ep = 0, v_b2 = 0;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t3a = 0, t3b = 0, t3c = 0, t4 = 0, t5 = 0, v_init = 0, v_k = 0, v_b1 = 0, v_ep = 0, v_b2 = 0, v_e0 = 0, v_e1 = 0, v_e2 = 0;
     const unsigned long long life_r0 = wall_clock64(), life_c0 = clock64();
 #endif
     __syncthreads();   // bias and the first x tile are in LDS (the fence drains the DMA)
@@ -426,8 +454,9 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_v2_kernel(FreqLstmArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         LSTAMP(t3)
         if (s + 1 < 32) { XDMA(dir ? 30 - s : s + 1, cur ^ 1) }   // lands during the cell update; sX[cur ^ 1] was last read in step s - 1
+        LSTAMP(t3a)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+        for (int j = 0; j < NJ; ++j) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float4 hq;
@@ -436,6 +465,10 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_v2_kernel(FreqLstmArgs a) {
                 sH[hq_idx][j * 32 + l31] = hq;
                 HF[((m0 >> 7) * (int64_t)HF_SLAB_ROWS + (f * 64 + dir * 32 + hq_idx)) * 128 + (m0 & 127) + j * 32 + l31] = hq;
             }
+#ifdef SDFA_STAMPS
+            if (j == 0) LSTAMP(t3b) else LSTAMP(t3c)
+#endif
+        }
         // h_s and the next x tile must be in LDS before anyone starts step s+1: this wave's LDS writes (lgkmcnt) and its four
         // DMA requests.  Vector-memory operations of a wave complete in issue order on gfx9-family parts (one in-order
         // vmcnt for loads and stores -- what LLVM's own waitcnt insertion relies on), and the 8 hidden-state stores were
@@ -448,13 +481,14 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_v2_kernel(FreqLstmArgs a) {
         asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #ifdef SDFA_STAMPS
         LSTAMP(t5)
-        if (s > 0) { v_init += t1 - t0; v_k += t2 - t1; v_b1 += t3 - t2; v_ep += t4 - t3; v_b2 += t5 - t4; }
+        if (s > 0) { v_init += t1 - t0; v_k += t2 - t1; v_b1 += t3 - t2; v_ep += t4 - t3; v_b2 += t5 - t4; v_e0 += t3a - t3; v_e1 += t3b - t3a; v_e2 += t3c - t3b; }
 #endif
     }
 #ifdef SDFA_STAMPS
     if (lane == 0) {
         atomicAdd(&g_lstamp[0], v_init); atomicAdd(&g_lstamp[1], v_k); atomicAdd(&g_lstamp[2], v_b1); atomicAdd(&g_lstamp[3], v_ep);
         atomicAdd(&g_lstamp[4], v_b2); atomicAdd(&g_lstamp[6], 31ull);
+        atomicAdd(&g_lsub[0], v_e0); atomicAdd(&g_lsub[1], v_e1); atomicAdd(&g_lsub[2], v_e2);
         if (wave == 0) {
             const unsigned long long r1 = wall_clock64();
             atomicMin(&g_lspan[0], life_r0); atomicMax(&g_lspan[1], r1);
@@ -960,6 +994,11 @@ extern "C" int sdfa_debug_read_lstm_stamps(unsigned long long *out, int reset) {
     if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_lstamp), z, sizeof z) != hipSuccess) return -3; }
     return 0;
 }
+extern "C" int sdfa_debug_read_lstm_sub(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lsub), sizeof(unsigned long long) * 4) != hipSuccess) return -3;
+    if (reset) { unsigned long long z[4] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_lsub), z, sizeof z) != hipSuccess) return -3; }
+    return 0;
+}
 extern "C" int sdfa_debug_read_lstm_xcd(unsigned long long *out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lxcd), sizeof(unsigned long long) * 32) != hipSuccess) return -3;
     if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_lxcd), z, sizeof z) != hipSuccess) return -3; }
@@ -972,33 +1011,35 @@ extern "C" int sdfa_debug_read_lstm_span(unsigned long long *out, int reset) {
 }
 #endif
 
-extern thread_local int g_sdfa_freq_lstm_shape;   // api.cpp ("freq_lstm_shape" option): 0 / 3 = freq_lstm_v2_kernel (default), 5 = its persistent form, 4 = freq_lstm_kernel 64 columns x 2 workgroups/CU, 1 = 32 x 4, 2 = 32 x 3
-
 template <bool SHARED>
 static hipError_t launch_freq(const FreqLstmArgs &a, hipStream_t s) {
-    if (g_sdfa_freq_lstm_shape == 0 || g_sdfa_freq_lstm_shape == 3) {      // default: the second form (+1.6 %, bit-identical)
+    const int shape = a.shape;
+    if (shape == 3 || shape >= 5) {      // the second form
         const unsigned n_tiles = (unsigned)(a.Mc / 64 * 2);
-        if (g_sdfa_freq_lstm_shape == 5) {      // persistent: two workgroups per CU pull tiles from a queue (bit-identical, 2-3 % slower: option only)
-            static const unsigned slots = [] {
-                int dev = 0, cus = 256;
-                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-                return (unsigned)(2 * cus);
+        // one workgroup per CU: 32 KB of unused dynamic LDS per workgroup (66 KB static)
+        if (shape == 5 || shape == 7) {      // persistent: workgroups pull tiles from a queue; 5: two per CU, 7: one per CU
+            static const unsigned cus = [] {
+                int dev = 0, n = 256;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+                return (unsigned)n;
             }();
+            const bool one = shape == 7;
+            const unsigned slots = one ? cus : 2 * cus;
             hipError_t e = hipMemsetAsync(a.tile_counter, 0, sizeof(int), s);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((freq_lstm_v2_kernel<SHARED, true>), dim3(n_tiles < slots ? n_tiles : slots), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((freq_lstm_v2_kernel<SHARED, true>), dim3(n_tiles < slots ? n_tiles : slots), dim3(256), one ? 32 * 1024 : 0, s, a);
             return hipGetLastError();
         }
-#ifdef SDFA_STAMPS   /* SDFA_LONE=1: 32 KB of unused dynamic LDS per workgroup (66 KB static) -> one workgroup per CU */
-        hipLaunchKernelGGL((freq_lstm_v2_kernel<SHARED, false>), dim3(n_tiles), dim3(256), getenv("SDFA_LONE") ? 32 * 1024 : 0, s, a);
-#else
-        hipLaunchKernelGGL((freq_lstm_v2_kernel<SHARED, false>), dim3(n_tiles), dim3(256), 0, s, a);
+        bool lone = shape == 6;
+#ifdef SDFA_STAMPS
+        lone = lone || getenv("SDFA_LONE");
 #endif
+        hipLaunchKernelGGL((freq_lstm_v2_kernel<SHARED, false>), dim3(n_tiles), dim3(256), lone ? 32 * 1024 : 0, s, a);
         return hipGetLastError();
     }
-    if (g_sdfa_freq_lstm_shape == 1)
+    if (shape == 1)
         hipLaunchKernelGGL((freq_lstm_kernel<SHARED, 1, 4>), dim3((unsigned)(a.Mc / 32 * 2)), dim3(256), 0, s, a);
-    else if (g_sdfa_freq_lstm_shape == 2)
+    else if (shape == 2)
         hipLaunchKernelGGL((freq_lstm_kernel<SHARED, 1, 3>), dim3((unsigned)(a.Mc / 32 * 2)), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((freq_lstm_kernel<SHARED, 2, 2>), dim3((unsigned)(a.Mc / 64 * 2)), dim3(256), 0, s, a);

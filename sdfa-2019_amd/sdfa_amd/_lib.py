@@ -40,6 +40,7 @@ SYMBOLS = {
     "sdfa_encoder_forward_shared": (C.c_int, [_p, _p, _i64, _p, _p, C.c_int, _p, _p, _p, _i64, _p]),
     "sdfa_regress_forward": (C.c_int, [_p, _p, _p, _i64, _p, _p, _p, _i64, _p]),
     "sdfa_regress_forward_multi": (C.c_int, [_p, _p, _p, _i64, _p, _p, C.c_int, _p, _i64, _p]),
+    "sdfa_model_autotune": (C.c_int, [_p, _i64, _p, _i64, _p]),
     "sdfa_expand_coef": (C.c_int, [_p, _p, _i64, _p, _p, _i64, _p]),
     "sdfa_debug_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "sdfa_debug_keep_intermediates": (C.c_int, [_p, C.c_int]),

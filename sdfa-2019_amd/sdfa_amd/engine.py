@@ -97,8 +97,14 @@ class Engine(FrontendOnly):
 
     PRECISIONS = {"fp32": 0, "bf16_attention": 1, "bf16x3": 2, "bf16": 3}      # include/sdfa_hip.h SDFA_PREC_*
 
-    def __init__(self, state_dict, device="cuda:0", max_frames=8192, debug_keep=False, precision="fp32", strict=True):
+    AUTOTUNE_MIN_FRAMES = 2048      # below this a launch is too short for the choice to matter (or to be measured)
+
+    def __init__(self, state_dict, device="cuda:0", max_frames=8192, debug_keep=False, precision="fp32", strict=True, autotune=False):
+        """autotune: at the first encoder call of at least AUTOTUNE_MIN_FRAMES frames, time the bit-identical launch forms of
+        the frequency-LSTM recurrence on this device and keep the fastest (sdfa_model_autotune; about half a second, once)."""
         super().__init__(device)
+        self._autotune_pending = bool(autotune)
+        self.freq_lstm_form = None          # set by autotune(): 3 / 5 / 6 / 7 (include/sdfa_hip.h)
         folded = fold_state_dict(state_dict)
         self.head = head_of(state_dict)
         if strict:
@@ -137,6 +143,15 @@ class Engine(FrontendOnly):
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    def autotune(self, n_frames=None):
+        """Measures the launch forms of the frequency-LSTM kernel on `n_frames` (default max_frames) frames and keeps the
+        fastest; returns the form chosen.  Outputs do not depend on it."""
+        n = min(int(n_frames or self.max_frames), self.max_frames)
+        ws = self.workspace(n)
+        self.freq_lstm_form = int(check(lib.sdfa_model_autotune(self._m, n, _ptr(ws), ws.numel(), _stream())))
+        self._autotune_pending = False
+        return self.freq_lstm_form
+
     # ------------------------------------------------------------------ model
     def encoder(self, audio_feat, want_align=True, frame_clip=None, frame_start=None, hop=None):
         """z (n,512), align (n,64).  With the frame table (`frame_clip` int32, `frame_start` int64, `hop`) the
@@ -148,6 +163,8 @@ class Engine(FrontendOnly):
         align = torch.empty((n, 64), dtype=torch.float32, device=self.device) if want_align else None
         if n == 0:
             return z, align
+        if self._autotune_pending and n >= self.AUTOTUNE_MIN_FRAMES:
+            self.autotune(n)
         ws = self.workspace(n)
         if frame_clip is None:
             check(lib.sdfa_encoder_forward(self._m, _ptr(audio_feat), n, _ptr(z), _ptr(align), _ptr(ws), ws.numel(), _stream()))

@@ -1,0 +1,159 @@
+// Microbenchmark: how fast does the vector-ALU work of ONE wave run while ANOTHER wave of the same SIMD feeds the fp32
+// matrix pipe back to back -- the situation of the frequency-LSTM kernel (one workgroup of a CU in its MFMA loop, the other
+// in its cell update) -- and what does it cost the matrix pipe?
+//   hipcc -O3 --offload-arch=gfx950 tools/mfma_cowave.hip -o /tmp/mfma_cowave && /tmp/mfma_cowave
+// One 512-thread workgroup per CU: waves 0-3 (one per SIMD) issue independent MFMAs only (or sleep: the baseline), waves
+// 4-7 (their SIMD partners) run a vector-ALU loop of a given kind UNTIL the first group raises a flag in LDS, counting
+// iterations.  Reported: the MFMA waves' pipe efficiency (ideal cycles / elapsed s_memtime cycles) and the partner's cycles
+// per VALU instruction during exactly that time.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ unsigned long long g_res[4];   // MFMA waves: sum cycles, count; VALU waves: sum cycles, sum iterations
+
+// SHAPE 0: v_mfma_f32_32x32x2_f32 x 8 accumulators; 1: v_mfma_f32_16x16x4_f32 x 32 accumulators; -1: no MFMAs (sleep)
+// ACC 0: compiler's choice (accumulation registers), 1: pinned to architectural VGPRs
+// GAP: idle cycles (s_nop) the MFMA wave inserts after every MFMA, leaving the issue port to its partner while the matrix
+// pipe works on the MFMA just issued (a 32x32x2 MFMA occupies the pipe for 64 cycles)
+// SWAP: the vector-ALU waves are the OLDER ones (waves 0-3), the MFMA waves the younger (4-7)
+template <int SHAPE, int KIND, int PRIO, int ACC, int GAP = 0, bool SWAP = false>
+__global__ __launch_bounds__(512) void k(float *out, int iters, float a0) {
+    __shared__ volatile int done[4];
+    const int wave = SWAP ? ((threadIdx.x >> 6) ^ 4) : (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (threadIdx.x < 4) done[threadIdx.x] = 0;
+    __syncthreads();
+    float a = a0 + lane * 1e-9f, b = a0;
+    if (wave < 4) {
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        float s = 0.f;
+        const unsigned long long t0 = clock64();
+        if (SHAPE == 0) {
+            f32x16 acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll 1
+            for (int it = 0; it < iters; ++it)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        if (ACC == 1) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+                        else acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+                        if (GAP == 1) __builtin_amdgcn_s_sleep(1);      // the wave yields for ~64 cycles instead of idling in s_nop
+                        if (GAP == 2) { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_s_sleep(1); __builtin_amdgcn_s_setprio(1); }
+                        if (GAP >= 16) asm volatile("s_nop 15");
+                        if (GAP >= 32) asm volatile("s_nop 15");
+                        if (GAP >= 48) asm volatile("s_nop 15");
+                        if (GAP >= 16 && GAP % 16) asm volatile("s_nop %0" ::"n"(GAP % 16 ? GAP % 16 - 1 : 0));
+                    }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[i][r];
+        } else if (SHAPE == 1) {
+            f32x4 acc[32];      // the same 128 accumulator registers
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+#pragma unroll 1
+            for (int it = 0; it < iters; ++it)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s += acc[i][r];
+        } else if (SHAPE == 2) {      // v_mfma_f32_32x32x16_bf16: 8 passes (32 cycles) on the dedicated low-precision matrix hardware
+            typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+            f32x16 acc[8];
+            bf16x8 pa, pb;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { pa[e] = (__bf16)a; pb[e] = (__bf16)b; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll 1
+            for (int it = 0; it < iters; ++it)
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, pb, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[i][r];
+        } else {
+#pragma unroll 1
+            for (int it = 0; it < iters; ++it) __builtin_amdgcn_s_sleep(32);      // 32 x 64 = 2048 cycles per iteration, like the MFMA loops
+        }
+        const unsigned long long t1 = clock64();
+        if (lane == 0) { done[wave] = 1; atomicAdd(&g_res[0], t1 - t0); atomicAdd(&g_res[1], 1ull); }
+        if (s == 123.456f) out[0] = s;
+    } else {
+        if (KIND == 0) return;
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = a + q;
+        unsigned long long n = 0;
+        const unsigned long long t0 = clock64();
+#pragma unroll 1
+        while (!done[wave - 4]) {         // one LDS read per 64 vector instructions
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (KIND == 1) v[q] = v[q] * 0.999f + 0.001f;                                 // full-rate FMA
+                    else if (KIND == 2) v[q] = __builtin_amdgcn_exp2f(v[q]);                       // transcendental
+                    else v[q] = (r & 3) == 3 ? __builtin_amdgcn_rcpf(v[q]) : v[q] * 0.999f + 0.001f;   // 1 in 4 transcendental (the cell's mix)
+                }
+            ++n;
+        }
+        const unsigned long long t1 = clock64();
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += v[q];
+        if (lane == 0) { atomicAdd(&g_res[2], t1 - t0); atomicAdd(&g_res[3], n); }
+        if (s == 123.456f) out[1] = s;
+    }
+}
+
+template <int SHAPE, int KIND, int PRIO, int ACC = 0, int GAP = 0, bool SWAP = false>
+void run(float *d) {
+    const int iters = 2000;
+    unsigned long long z[4] = {0, 0, 0, 0}, r[4];
+    for (int rep = 0; rep < 2; ++rep) {
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_res), z, sizeof z);
+        hipLaunchKernelGGL((k<SHAPE, KIND, PRIO, ACC, GAP, SWAP>), dim3(256), dim3(512), 0, 0, d, iters, 1e-30f);
+        (void)hipDeviceSynchronize();
+    }
+    (void)hipMemcpyFromSymbol(r, HIP_SYMBOL(g_res), sizeof r);
+    const double mf = (double)r[0] / r[1], ideal = (double)iters * 2048.0;
+    const char *kinds[] = {"none", "fma (full rate)", "v_exp (transcendental)", "3 fma : 1 v_rcp"};
+    const char *shapes[] = {"no MFMAs (sleep)", "32x32x2", "16x16x4", "32x32x16 bf16"};
+    printf("%s%-16s %-9s gap %2d prio %d  partner VALU: %-24s", SWAP ? "[VALU waves older] " : "", shapes[SHAPE + 1], ACC ? "acc VGPR" : "acc auto", GAP, PRIO, kinds[KIND]);
+    if (SHAPE >= 0) printf(" MFMA pipe efficiency %.3f", ideal / mf);
+    if (KIND) printf("   partner: %.2f cycles per VALU instruction", (double)r[2] / ((double)r[3] * 64));
+    printf("\n");
+}
+
+int main() {
+    float *d; (void)hipMalloc(&d, 8);
+    run<-1, 1, 1>(d); run<-1, 2, 1>(d); run<-1, 3, 1>(d);
+    run<0, 0, 1>(d); run<0, 1, 1>(d); run<0, 2, 1>(d); run<0, 3, 1>(d); run<0, 1, 0>(d); run<0, 3, 0>(d);
+    run<0, 1, 1, 1>(d); run<0, 3, 1, 1>(d); run<0, 3, 0, 1>(d);
+    run<0, 0, 1, 1, 16>(d); run<0, 3, 1, 1, 16>(d); run<0, 3, 1, 1, 32>(d); run<0, 3, 1, 1, 40>(d); run<0, 3, 1, 1, 48>(d); run<0, 3, 1, 1, 52>(d); run<0, 3, 1, 1, 56>(d); run<0, 3, 1, 1, 60>(d); run<0, 0, 1, 1, 56>(d);
+    run<0, 3, 0, 1, 48>(d); run<0, 1, 1, 1, 48>(d); run<0, 2, 1, 1, 48>(d);
+    run<0, 1, 1, 1, 0, true>(d); run<0, 2, 1, 1, 0, true>(d); run<0, 3, 1, 1, 0, true>(d); run<0, 3, 0, 1, 0, true>(d); run<-1, 3, 0, 1, 0, true>(d);
+    run<0, 0, 1, 1, 1>(d); run<0, 3, 1, 1, 1>(d); run<0, 1, 1, 1, 1>(d); run<0, 3, 0, 1, 1>(d); run<0, 3, 1, 1, 2>(d);
+    run<2, 0, 1>(d); run<2, 1, 1>(d); run<2, 2, 1>(d); run<2, 3, 1>(d); run<2, 3, 0>(d);
+    run<1, 0, 1>(d); run<1, 1, 1>(d); run<1, 2, 1>(d); run<1, 3, 1>(d); run<1, 3, 0>(d);
+    return 0;
+}

@@ -14,12 +14,15 @@ x = torch.rand((8192, 64, 128, 3), device="cuda")
 out = (C.c_ulonglong * 8)()
 span = (C.c_ulonglong * 4)()
 xcd = (C.c_ulonglong * 32)()
+sub = (C.c_ulonglong * 4)()
+lib.sdfa_debug_read_lstm_sub.argtypes = [C.c_void_p, C.c_int]
 lib.sdfa_debug_read_lstm_xcd.argtypes = [C.c_void_p, C.c_int]
 lib.sdfa_debug_read_lstm_span.argtypes = [C.c_void_p, C.c_int]
 for rep in range(2):
     lib.sdfa_debug_read_lstm_stamps(out, 1)
     lib.sdfa_debug_read_lstm_span(span, 1)
     lib.sdfa_debug_read_lstm_xcd(xcd, 1)
+    lib.sdfa_debug_read_lstm_sub(sub, 1)
     eng.profile(True)
     z, _ = eng.encoder(x, want_align=False); torch.cuda.synchronize()
     ms = eng.profile_ms("freq_lstm"); eng.profile(False)
@@ -30,6 +33,9 @@ print(f"freq_lstm_v2_kernel ({'ONE workgroup per CU' if os.environ.get('SDFA_LON
 for name, val in zip(("accumulator init + first operand reads", "K loop (24 k-blocks)", "barrier 1 (all waves done with K loop)", "x DMA + cell update + stores", "barrier 2 (h, x in LDS)"), v[:5]):
     print(f"  {name:44s} {val / n:9.0f}")
 print(f"  total {sum(v[:5]) / n:9.0f}")
+lib.sdfa_debug_read_lstm_sub(sub, 0)
+e0, e1, e2 = (int(x) / n for x in sub[:3])
+print(f"  inside the cell-update phase: x DMA issue {e0:.0f}, columns 0-31 (4 quads: math, LDS write, store) {e1:.0f}, columns 32-63 {e2:.0f}, final wait (DMA landed, LDS writes done) {v[3] / n - e0 - e1 - e2:.0f}")
 lib.sdfa_debug_read_lstm_span(span, 0)
 t0, t1, life_ticks, life_cyc = (int(x) for x in span)
 slots = 256 * (1 if os.environ.get("SDFA_LONE") else 2)
