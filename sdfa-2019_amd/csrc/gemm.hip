@@ -691,6 +691,162 @@ hipError_t launch_big(const GemmArgs &a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// "Fat wave" variant (gemm_variant 8): 256 x 256 tile, FOUR waves -- one per SIMD -- each a 128 x 128 output block
+// (4 x 4 MFMA tiles = 256 accumulator registers, in AGPRs), operands staged HBM/L2 -> LDS by LDS-DMA.
+// On this chip an MFMA in flight and every other vector / memory instruction of the SIMD exclude each other
+// (tools/mfma_cowave.hip, mfma_shadow.hip), so a GEMM's efficiency is set by how few non-MFMA
+// instructions it issues per MFMA, and a second wave per SIMD only fills stalls.  Per 32-deep stage a wave issues here
+// 256 MFMAs, 32 ds_read_b128 (1 per 8 MFMAs; 128 x 64 blocks: 1 per 5.3, 64 x 64: 1 per 4), 16 LDS-DMA requests, no
+// ds_write, no staging registers, one barrier.
+// ------------------------------------------------------------------------------------------------
+template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
+__global__ __launch_bounds__(256, 1) void gemm_fat_kernel(GemmArgs a) {
+    constexpr int BT = 256;
+    extern __shared__ float4 sFat[];   // [2 bufs][P | Q][KQ k-quad rows][256]: 128 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: LDS-DMA destinations (M0) and global bases stay in SGPRs
+    const int wp = wave >> 1, wq = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const int64_t ntp = a.Ppad / BT, bid = blockIdx.x;
+    const int64_t p0 = (bid % ntp) * BT, q0 = (bid / ntp) * BT;
+    if (a.q_limit && q0 >= *a.q_limit) return;
+
+    const float4 *__restrict__ P = reinterpret_cast<const float4 *>(a.P);
+    const float4 *__restrict__ Q = reinterpret_cast<const float4 *>(a.Q);
+    const int nstage = a.K / 32;
+    auto SP = [&](int buf) { return sFat + (size_t)buf * 2 * KQ * BT; };
+    auto SQ = [&](int buf) { return sFat + (size_t)buf * 2 * KQ * BT + KQ * BT; };
+
+    // LDS-DMA: one wave instruction moves 64 consecutive columns of one k-quad row (1 KiB); wave w moves column quarter w
+    // of all 8 rows of P and of Q.  Uniform running bases (scalar registers) + one loop-invariant byte offset per lane: the
+    // "saddr + voffset" form, no vector-ALU address arithmetic.
+    const int64_t qrow = a.q_tile_major ? 128 : a.ldq;
+    const char *pg = reinterpret_cast<const char *>(P + p0 + wave * 64);
+    const char *qg = reinterpret_cast<const char *>(a.q_tile_major ? Q + ((q0 >> 7) + (wave >> 1)) * (int64_t)a.q_slab_rows * 128 + (wave & 1) * 64
+                                                                    : Q + q0 + wave * 64);
+    const unsigned voff = (unsigned)lane * 16;
+#define FAT_DMA(buf)                                                                                             \
+    {                                                                                                            \
+        _Pragma("unroll") for (int r = 0; r < KQ; ++r) {                                                         \
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(pg + (int64_t)r * a.ldp * 16 + voff), \
+                                             (void __attribute__((address_space(3))) *)(SP(buf) + r * BT + wave * 64), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(qg + (int64_t)r * qrow * 16 + voff),  \
+                                             (void __attribute__((address_space(3))) *)(SQ(buf) + r * BT + wave * 64), 16, 0, 0); \
+        }                                                                                                        \
+        pg += (int64_t)KQ * a.ldp * 16;                                                                          \
+        qg += (int64_t)KQ * qrow * 16;                                                                           \
+    }
+#define FAT_READ(sp, sq, kb, FA, FB)                                                                             \
+    {                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) FA[i] = sp[(2 * (kb) + h) * BT + wp * 128 + i * 32 + l31]; \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) FB[j] = sq[(2 * (kb) + h) * BT + wq * 128 + j * 32 + l31]; \
+    }
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // Stage pipeline (one wave per SIMD: nothing else fills a stall, so none may be left).  A stage's operands -- four
+    // k-blocks, 32 ds_read_b128 -- are all read right behind the barrier that releases them, into five rotating register
+    // sets, while the LAST 64 MFMAs of the previous stage are still to be issued: LDS latency, the LDS-DMA requests of the
+    // tile two stages ahead and the barrier itself sit in the shadow of those 4,096 cycles.  (All LDS reads directly follow a
+    // barrier whose fence has drained the DMA anyway, so the compiler's conservative "LDS read after LDS-DMA" wait is free.)
+    float4 fa0[4], fb0[4], fa1[4], fb1[4], fa2[4], fb2[4], fa3[4], fb3[4], fa4[4], fb4[4];
+    FAT_DMA(0)
+    if (nstage > 1) { FAT_DMA(1) }
+    __syncthreads();
+    FAT_READ(SP(0), SQ(0), 0, fa0, fb0)
+    FAT_READ(SP(0), SQ(0), 1, fa1, fb1)
+    FAT_READ(SP(0), SQ(0), 2, fa2, fb2)
+    FAT_READ(SP(0), SQ(0), 3, fa3, fb3)
+    // one stage: k-blocks 0..2 of the current tile, barrier, k-block 3 with the next tile's 32 LDS reads spread between its
+    // MFMAs (8 per 16 MFMAs: a burst of 32 x 4 waves fills the CU's LDS queue and the in-order wave sits behind it), and
+    // the 16 DMA requests of the tile after that spread over k-block 0 in the same way
+#define FAT_Q(A, B, q)                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = MFMA(SDFA_OP(f4c(A[i], q)), SDFA_OP(f4c(B[j], q)), acc[i][j]);
+#define FAT_DMA_Q(buf, q)                                                                                        \
+    _Pragma("unroll") for (int r = 2 * (q); r < 2 * (q) + 2; ++r) {                                              \
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(pg + (int64_t)r * a.ldp * 16 + voff), \
+                                         (void __attribute__((address_space(3))) *)(SP(buf) + r * BT + wave * 64), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(qg + (int64_t)r * qrow * 16 + voff),  \
+                                         (void __attribute__((address_space(3))) *)(SQ(buf) + r * BT + wave * 64), 16, 0, 0); \
+    }
+#define FAT_STAGE(LAST_A, LAST_B, FREE_A, FREE_B)                                                                \
+    {                                                                                                            \
+        const int buf = st & 1;                                                                                  \
+        const bool dma = st > 0 && st + 1 < nstage;      /* stage st+1 goes into the buffer released by the previous barrier */ \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                          \
+            if (dma) { FAT_DMA_Q(buf ^ 1, q) }                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            FAT_Q(fa0, fb0, q)                                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+        }                                                                                                        \
+        if (dma) { pg += (int64_t)KQ * a.ldp * 16; qg += (int64_t)KQ * qrow * 16; }                              \
+        mfma_block<4, 4>(acc, fa1, fb1);                                                                         \
+        mfma_block<4, 4>(acc, fa2, fb2);                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        /* this wave's LDS-DMA of stage st+1 must have LANDED before the barrier lets the other waves read it: an explicit   \
+           vmcnt(0) (gfx9 encoding, expcnt 7 = no wait) -- the compiler's fence only covers this wave's own later LDS reads */   \
+        __builtin_amdgcn_s_waitcnt(0x0070);                                                                      \
+        __syncthreads();   /* every wave holds the rest of `buf` in registers */                                 \
+        {   /* (behind the last stage these reads fetch stale LDS contents that nobody uses: no branch around MFMAs) */  \
+            const float4 *sp = SP(buf ^ 1), *sq = SQ(buf ^ 1);                                                   \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) fa0[i] = sp[h * BT + wp * 128 + i * 32 + l31];         \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) fb0[j] = sq[h * BT + wq * 128 + j * 32 + l31];         \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            FAT_Q(LAST_A, LAST_B, 0)                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            FAT_READ(sp, sq, 1, fa1, fb1)                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            FAT_Q(LAST_A, LAST_B, 1)                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            FAT_READ(sp, sq, 2, fa2, fb2)                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            FAT_Q(LAST_A, LAST_B, 2)                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            FAT_READ(sp, sq, 3, FREE_A, FREE_B)                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            FAT_Q(LAST_A, LAST_B, 3)                                                                             \
+        }                                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+    }
+    int st = 0;
+    for (; st + 1 < nstage; st += 2) {
+        FAT_STAGE(fa3, fb3, fa4, fb4)
+        ++st;
+        FAT_STAGE(fa4, fb4, fa3, fb3)
+        --st;
+    }
+    if (st < nstage) { FAT_STAGE(fa3, fb3, fa4, fb4) }      // odd stage count
+#undef FAT_STAGE
+#undef FAT_Q
+#undef FAT_DMA_Q
+#undef FAT_DMA
+#undef FAT_READ
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            store_tile<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, acc[i][j], p0 + wp * 128 + i * 32, q0 + wq * 128 + j * 32 + l31, h);
+}
+
+template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
+hipError_t launch_fat(const GemmArgs &a, hipStream_t s) {
+    const size_t lds = 2 * 2 * KQ * 256 * sizeof(float4);   // 128 KiB
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_fat_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int64_t nblk = (a.Ppad / 256) * (a.Qpad / 256);
+    hipLaunchKernelGGL((gemm_fat_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>), dim3((unsigned)nblk), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Producer / consumer variant (gemm_variant 6): 4 MFMA waves + 2 loader waves per workgroup.  The in-kernel stamps
 // showed an MFMA wave losing ~3,900 of 10,600 cycles per stage just ISSUING its eight global loads (the CU's miss
 // path is latency-bound when an operand streams from HBM) -- an in-order wave issues no MFMAs meanwhile.  Here the
@@ -793,6 +949,8 @@ hipError_t launch_any(const GemmArgs &a, hipStream_t s) {
     }
     if (g_sdfa_gemm_variant == 4 && !a.q_tile_major) return launch_bf16<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 3>(a, s);
     if (g_sdfa_gemm_variant == 6) return launch_pc<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
+    if (g_sdfa_gemm_variant == 8 && a.Ppad % 256 == 0 && a.Qpad % 256 == 0 && a.seg_k == a.K && a.K % 32 == 0)
+        return launch_fat<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
     // 256 x 256 tile: on request (gemm_variant 5), and by default for the 8192-deep frequency projection, whose operand
     // stream (2 MB of hidden states per frame) is what the 128 x 128 tile waits for (40.3 vs 41.7 ms); the L2-resident
     // projections are faster on the small tile (two independent workgroups per CU)

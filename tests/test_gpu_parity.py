@@ -371,10 +371,11 @@ def test_freq_lstm_kernel_forms_are_bitwise_identical(synth_sd, golden):
     assert torch.equal(z, res[4][2][0]) and torch.equal(al, res[4][2][1])
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 8])
 def test_gemm_variants_agree(eng, golden, variant):
     """The alternative GEMM data paths (register-direct MT 4 / MT 2, LDS-DMA, split-bf16 x3, 256-tile,
-    producer/consumer) give the reference's numbers too."""
+    producer/consumer, one 128 x 128 block per wave) give the reference's numbers too; the fp32 LDS-tiled ones (5, 8)
+    contract k in the default kernel's order: bit-identical z."""
     from sdfa_amd import _lib
     g = golden["model_dgrad"]
     x = _t(g["audio_feat"])
@@ -387,3 +388,6 @@ def test_gemm_variants_agree(eng, golden, variant):
         _lib.set_option("gemm_variant", 0)
     assert np.abs(out[:, ::97] - g["dgrad_stride97"]).max() <= TOL_DGRAD
     assert np.abs(align.cpu().numpy() - g["align"][:, 0]).max() <= 1e-5
+    if variant in (5, 8):
+        z0 = eng.forward(x, spk)[1]
+        assert torch.equal(z, z0)
