@@ -706,34 +706,58 @@ __global__ __launch_bounds__(256, 1) void gemm_fat_kernel(GemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: LDS-DMA destinations (M0) and global bases stay in SGPRs
     const int wp = wave >> 1, wq = wave & 1, l31 = lane & 31, h = lane >> 5;
-    const int64_t ntp = a.Ppad / BT, bid = blockIdx.x;
-    const int64_t p0 = (bid % ntp) * BT, q0 = (bid / ntp) * BT;
-    if (a.q_limit && q0 >= *a.q_limit) return;
+    const int64_t ntp = a.Ppad / BT;
+    const int64_t q_end = a.q_limit ? std::min<int64_t>(*a.q_limit, a.Qpad) : a.Qpad;          // column sharing: tiles at or past the device-side limit are skipped
 
     const float4 *__restrict__ P = reinterpret_cast<const float4 *>(a.P);
     const float4 *__restrict__ Q = reinterpret_cast<const float4 *>(a.Q);
-    const int nstage = a.K / 32;
+    const int nstage = a.K / 32;                                    // even (launcher): buffer parity and the operand-set rotation carry over tile ends
     auto SP = [&](int buf) { return sFat + (size_t)buf * 2 * KQ * BT; };
     auto SQ = [&](int buf) { return sFat + (size_t)buf * 2 * KQ * BT + KQ * BT; };
 
-    // LDS-DMA: one wave instruction moves 64 consecutive columns of one k-quad row (1 KiB); wave w moves column quarter w
-    // of all 8 rows of P and of Q.  Uniform running bases (scalar registers) + one loop-invariant byte offset per lane: the
-    // "saddr + voffset" form, no vector-ALU address arithmetic.
+    // PERSISTENT: the grid is one workgroup per CU and workgroup b multiplies tiles b, b + grid, b + 2 grid, ... (tile t =
+    // (column block t / ntp, row block t % ntp): the row blocks of one column block run on neighbouring CUs at the same
+    // time).  The stages of consecutive tiles form ONE pipeline: the first tile's operands of the next tile are requested
+    // during the last stage of this one and read behind its last barrier, so a tile's start-up (an HBM round trip) and
+    // the re-dispatch of a workgroup never leave the matrix pipe empty; only the epilogue does.
     const int64_t qrow = a.q_tile_major ? 128 : a.ldq;
-    const char *pg = reinterpret_cast<const char *>(P + p0 + wave * 64);
-    const char *qg = reinterpret_cast<const char *>(a.q_tile_major ? Q + ((q0 >> 7) + (wave >> 1)) * (int64_t)a.q_slab_rows * 128 + (wave & 1) * 64
-                                                                    : Q + q0 + wave * 64);
     const unsigned voff = (unsigned)lane * 16;
-#define FAT_DMA(buf)                                                                                             \
+    // LDS-DMA: one wave instruction moves 64 consecutive columns of one k-quad row (1 KiB); wave w moves column quarter w
+    // of all 8 rows of P and of Q.  Uniform running bases (scalar registers) + one loop-invariant byte offset per lane.
+    // tiles as (row block tp, column block tq), stepped by the grid size without a division per tile
+    struct Tile { int tp, tq; };
+    const int g_tp = (int)(gridDim.x % ntp), g_tq = (int)(gridDim.x / ntp), ntp_i = (int)ntp;
+    auto advance = [&](Tile &x) { x.tp += g_tp; x.tq += g_tq; if (x.tp >= ntp_i) { x.tp -= ntp_i; ++x.tq; } };
+    auto p_base = [&](const Tile &x) { return reinterpret_cast<const char *>(P + (int64_t)x.tp * BT + wave * 64); };
+    auto q_base = [&](const Tile &x) {
+        const int64_t q0 = (int64_t)x.tq * BT;
+        return reinterpret_cast<const char *>(a.q_tile_major ? Q + ((q0 >> 7) + (wave >> 1)) * (int64_t)a.q_slab_rows * 128 + (wave & 1) * 64
+                                                             : Q + q0 + wave * 64);
+    };
+    auto live = [&](const Tile &x) { return (int64_t)x.tq * BT < q_end; };      // q_end <= Qpad; tq grows monotonically
+
+    Tile t{(int)(blockIdx.x % ntp), (int)(blockIdx.x / ntp)};      // tile being multiplied
+    if (!live(t)) return;
+    Tile tf = t;                       // tile being fetched (one stage ahead of the multiplication)
+    const char *pg = p_base(tf), *qg = q_base(tf);
+    int fetch_left = nstage;           // stages of tile tf not yet requested
+    bool fetching = true;
+#define FAT_DMA_ROWS(buf, r0, r1)                                                                                \
+    _Pragma("unroll") for (int r = (r0); r < (r1); ++r) {                                                        \
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(pg + (int64_t)r * a.ldp * 16 + voff), \
+                                         (void __attribute__((address_space(3))) *)(SP(buf) + r * BT + wave * 64), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(qg + (int64_t)r * qrow * 16 + voff),  \
+                                         (void __attribute__((address_space(3))) *)(SQ(buf) + r * BT + wave * 64), 16, 0, 0); \
+    }
+    // after a stage's requests: advance to the next stage of the tile being fetched, or to the next tile of this workgroup
+#define FAT_DMA_NEXT()                                                                                           \
     {                                                                                                            \
-        _Pragma("unroll") for (int r = 0; r < KQ; ++r) {                                                         \
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(pg + (int64_t)r * a.ldp * 16 + voff), \
-                                             (void __attribute__((address_space(3))) *)(SP(buf) + r * BT + wave * 64), 16, 0, 0); \
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(qg + (int64_t)r * qrow * 16 + voff),  \
-                                             (void __attribute__((address_space(3))) *)(SQ(buf) + r * BT + wave * 64), 16, 0, 0); \
+        if (--fetch_left > 0) { pg += (int64_t)KQ * a.ldp * 16; qg += (int64_t)KQ * qrow * 16; }                 \
+        else {                                                                                                   \
+            advance(tf);                                                                                         \
+            fetching = live(tf);                                                                                 \
+            if (fetching) { pg = p_base(tf); qg = q_base(tf); fetch_left = nstage; }                             \
         }                                                                                                        \
-        pg += (int64_t)KQ * a.ldp * 16;                                                                          \
-        qg += (int64_t)KQ * qrow * 16;                                                                           \
     }
 #define FAT_READ(sp, sq, kb, FA, FB)                                                                             \
     {                                                                                                            \
@@ -748,55 +772,44 @@ __global__ __launch_bounds__(256, 1) void gemm_fat_kernel(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // Stage pipeline (one wave per SIMD: nothing else fills a stall, so none may be left).  A stage's operands -- four
-    // k-blocks, 32 ds_read_b128 -- are all read right behind the barrier that releases them, into five rotating register
-    // sets, while the LAST 64 MFMAs of the previous stage are still to be issued: LDS latency, the LDS-DMA requests of the
-    // tile two stages ahead and the barrier itself sit in the shadow of those 4,096 cycles.  (All LDS reads directly follow a
-    // barrier whose fence has drained the DMA anyway, so the compiler's conservative "LDS read after LDS-DMA" wait is free.)
+    // Stage pipeline (one wave per SIMD: nothing else fills a stall, so none may be left).  Five rotating operand sets.  A
+    // stage = k-blocks 0..2, barrier, k-block 3; the LDS reads of the NEXT stage (32 ds_read_b128) are spread between the
+    // 64 MFMAs of k-block 3 (8 per 16 MFMAs: a burst of 32 x 4 waves fills the CU's LDS queue and the in-order wave sits
+    // behind it), the 16 LDS-DMA requests of the stage after that between the MFMAs of k-block 0 -- LDS latency, the HBM
+    // round trip and the barrier all sit in the shadow of MFMAs.  (Every LDS read directly follows a barrier whose fence
+    // has drained this wave's DMA anyway, so the compiler's conservative "LDS read after LDS-DMA" wait costs nothing.)
     float4 fa0[4], fb0[4], fa1[4], fb1[4], fa2[4], fb2[4], fa3[4], fb3[4], fa4[4], fb4[4];
-    FAT_DMA(0)
-    if (nstage > 1) { FAT_DMA(1) }
+    FAT_DMA_ROWS(0, 0, KQ)
+    FAT_DMA_NEXT()
+    __builtin_amdgcn_s_waitcnt(0x0070);
     __syncthreads();
     FAT_READ(SP(0), SQ(0), 0, fa0, fb0)
     FAT_READ(SP(0), SQ(0), 1, fa1, fb1)
     FAT_READ(SP(0), SQ(0), 2, fa2, fb2)
     FAT_READ(SP(0), SQ(0), 3, fa3, fb3)
-    // one stage: k-blocks 0..2 of the current tile, barrier, k-block 3 with the next tile's 32 LDS reads spread between its
-    // MFMAs (8 per 16 MFMAs: a burst of 32 x 4 waves fills the CU's LDS queue and the in-order wave sits behind it), and
-    // the 16 DMA requests of the tile after that spread over k-block 0 in the same way
 #define FAT_Q(A, B, q)                                                                                           \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = MFMA(SDFA_OP(f4c(A[i], q)), SDFA_OP(f4c(B[j], q)), acc[i][j]);
-#define FAT_DMA_Q(buf, q)                                                                                        \
-    _Pragma("unroll") for (int r = 2 * (q); r < 2 * (q) + 2; ++r) {                                              \
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(pg + (int64_t)r * a.ldp * 16 + voff), \
-                                         (void __attribute__((address_space(3))) *)(SP(buf) + r * BT + wave * 64), 16, 0, 0); \
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(qg + (int64_t)r * qrow * 16 + voff),  \
-                                         (void __attribute__((address_space(3))) *)(SQ(buf) + r * BT + wave * 64), 16, 0, 0); \
-    }
-#define FAT_STAGE(LAST_A, LAST_B, FREE_A, FREE_B)                                                                \
+#define FAT_STAGE(BUF, LAST_A, LAST_B, FREE_A, FREE_B)                                                           \
     {                                                                                                            \
-        const int buf = st & 1;                                                                                  \
-        const bool dma = st > 0 && st + 1 < nstage;      /* stage st+1 goes into the buffer released by the previous barrier */ \
         __builtin_amdgcn_sched_barrier(0);                                                                       \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                          \
-            if (dma) { FAT_DMA_Q(buf ^ 1, q) }                                                                   \
+            if (fetching) { FAT_DMA_ROWS((BUF) ^ 1, 2 * q, 2 * q + 2) }   /* the next stage, into the buffer the previous barrier released */ \
             __builtin_amdgcn_sched_barrier(0);                                                                   \
             FAT_Q(fa0, fb0, q)                                                                                   \
             __builtin_amdgcn_sched_barrier(0);                                                                   \
         }                                                                                                        \
-        if (dma) { pg += (int64_t)KQ * a.ldp * 16; qg += (int64_t)KQ * qrow * 16; }                              \
+        if (fetching) FAT_DMA_NEXT()                                                                             \
         mfma_block<4, 4>(acc, fa1, fb1);                                                                         \
         mfma_block<4, 4>(acc, fa2, fb2);                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                       \
-        /* this wave's LDS-DMA of stage st+1 must have LANDED before the barrier lets the other waves read it: an explicit   \
-           vmcnt(0) (gfx9 encoding, expcnt 7 = no wait) -- the compiler's fence only covers this wave's own later LDS reads */   \
+        /* this wave's LDS-DMA of the next stage must have LANDED before the barrier lets the other waves read it: an       \
+           explicit vmcnt(0) (gfx9 encoding, expcnt 7 = no wait) -- the compiler's fence only covers this wave's own reads */ \
         __builtin_amdgcn_s_waitcnt(0x0070);                                                                      \
-        __syncthreads();   /* every wave holds the rest of `buf` in registers */                                 \
-        {   /* (behind the last stage these reads fetch stale LDS contents that nobody uses: no branch around MFMAs) */  \
-            const float4 *sp = SP(buf ^ 1), *sq = SQ(buf ^ 1);                                                   \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) fa0[i] = sp[h * BT + wp * 128 + i * 32 + l31];         \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) fb0[j] = sq[h * BT + wq * 128 + j * 32 + l31];         \
+        __syncthreads();   /* every wave holds the rest of BUF in registers */                                   \
+        {   /* (behind the very last stage these reads fetch stale LDS contents that nobody uses: no branch around MFMAs) */ \
+            const float4 *sp = SP((BUF) ^ 1), *sq = SQ((BUF) ^ 1);                                               \
+            FAT_READ(sp, sq, 0, fa0, fb0)                                                                        \
             __builtin_amdgcn_sched_barrier(0);                                                                   \
             FAT_Q(LAST_A, LAST_B, 0)                                                                             \
             __builtin_amdgcn_sched_barrier(0);                                                                   \
@@ -814,25 +827,28 @@ __global__ __launch_bounds__(256, 1) void gemm_fat_kernel(GemmArgs a) {
         }                                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                       \
     }
-    int st = 0;
-    for (; st + 1 < nstage; st += 2) {
-        FAT_STAGE(fa3, fb3, fa4, fb4)
-        ++st;
-        FAT_STAGE(fa4, fb4, fa3, fb3)
-        --st;
+    for (;;) {
+        for (int st = 0; st < nstage; st += 2) {
+            FAT_STAGE(0, fa3, fb3, fa4, fb4)
+            FAT_STAGE(1, fa4, fb4, fa3, fb3)
+        }
+        const int64_t p0 = (int64_t)t.tp * BT, q0 = (int64_t)t.tq * BT;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                store_tile<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, acc[i][j], p0 + wp * 128 + i * 32, q0 + wq * 128 + j * 32 + l31, h);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            }
+        advance(t);
+        if (!live(t)) break;
     }
-    if (st < nstage) { FAT_STAGE(fa3, fb3, fa4, fb4) }      // odd stage count
 #undef FAT_STAGE
 #undef FAT_Q
-#undef FAT_DMA_Q
-#undef FAT_DMA
+#undef FAT_DMA_ROWS
+#undef FAT_DMA_NEXT
 #undef FAT_READ
-
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            store_tile<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, acc[i][j], p0 + wp * 128 + i * 32, q0 + wq * 128 + j * 32 + l31, h);
 }
 
 template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
@@ -841,8 +857,13 @@ hipError_t launch_fat(const GemmArgs &a, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_fat_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    const int64_t nblk = (a.Ppad / 256) * (a.Qpad / 256);
-    hipLaunchKernelGGL((gemm_fat_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>), dim3((unsigned)nblk), dim3(256), lds, s, a);
+    static const int64_t cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        return (int64_t)n;
+    }();
+    const int64_t ntiles = (a.Ppad / 256) * (a.Qpad / 256);
+    hipLaunchKernelGGL((gemm_fat_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>), dim3((unsigned)std::min(ntiles, cus)), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
@@ -949,12 +970,19 @@ hipError_t launch_any(const GemmArgs &a, hipStream_t s) {
     }
     if (g_sdfa_gemm_variant == 4 && !a.q_tile_major) return launch_bf16<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 3>(a, s);
     if (g_sdfa_gemm_variant == 6) return launch_pc<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
-    if (g_sdfa_gemm_variant == 8 && a.Ppad % 256 == 0 && a.Qpad % 256 == 0 && a.seg_k == a.K && a.K % 32 == 0)
-        return launch_fat<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
+    // one 128 x 128 block per wave, persistent (gemm_fat_kernel): by default wherever its 256 x 256 tiles fill the chip at least
+    // twice over -- the frequency projection (-5.6 %) and the BiLSTM input projections (-8 / -9.5 %); gemm_variant 8 forces it,
+    // 9 keeps the round-1/2 choice below
+    {
+        const bool fits = a.Ppad % 256 == 0 && a.Qpad % 256 == 0 && a.seg_k == a.K && a.K % 64 == 0 && OUT_MODE == OUT_K4;
+        const int64_t ntiles = (a.Ppad / 256) * (a.Qpad / 256);
+        if (fits && (g_sdfa_gemm_variant == 8 || (g_sdfa_gemm_variant == 0 && ntiles >= 512)))
+            return launch_fat<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
+    }
     // 256 x 256 tile: on request (gemm_variant 5), and by default for the 8192-deep frequency projection, whose operand
     // stream (2 MB of hidden states per frame) is what the 128 x 128 tile waits for (40.3 vs 41.7 ms); the L2-resident
     // projections are faster on the small tile (two independent workgroups per CU)
-    if ((g_sdfa_gemm_variant == 5 || (a.q_tile_major && g_sdfa_gemm_variant == 0)) && a.Ppad % 256 == 0 && a.Qpad % 256 == 0)
+    if ((g_sdfa_gemm_variant == 5 || (a.q_tile_major && (g_sdfa_gemm_variant == 0 || g_sdfa_gemm_variant == 9))) && a.Ppad % 256 == 0 && a.Qpad % 256 == 0)
         return launch_big<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
     if (a.q_tile_major) return launch<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);   // only the LDS-tiled kernels read that layout
     if (g_sdfa_gemm_variant == 1 && a.Ppad % 128 == 0) return launch_direct<4, OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
