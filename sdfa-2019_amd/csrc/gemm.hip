@@ -728,35 +728,40 @@ __global__ __launch_bounds__(256, 1) void gemm_fat_kernel(GemmArgs a) {
     struct Tile { int tp, tq; };
     const int g_tp = (int)(gridDim.x % ntp), g_tq = (int)(gridDim.x / ntp), ntp_i = (int)ntp;
     auto advance = [&](Tile &x) { x.tp += g_tp; x.tq += g_tq; if (x.tp >= ntp_i) { x.tp -= ntp_i; ++x.tq; } };
-    auto p_base = [&](const Tile &x) { return reinterpret_cast<const char *>(P + (int64_t)x.tp * BT + wave * 64); };
-    auto q_base = [&](const Tile &x) {
+    // LDS-DMA through BUFFER descriptors (buffer_load_dwordx4 ... lds): descriptor and row offset in scalar registers, one
+    // loop-invariant 32-bit lane offset -- a request costs no vector-ALU instruction (the global_load_lds form needed a 64-bit
+    // add per request).  P: one descriptor over the whole matrix, the tile as scalar offset.  Q can exceed 4 GB: a descriptor
+    // per tile, based at the tile's first element (the launcher checks that a tile's K extent stays below 2 GB).
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(P), 0, 0x7fffffff, 0x00020000);
+    auto p_off = [&](const Tile &x) { return (unsigned)(((int64_t)x.tp * BT + wave * 64) * 16); };
+    auto q_rsrc = [&](const Tile &x) {
         const int64_t q0 = (int64_t)x.tq * BT;
-        return reinterpret_cast<const char *>(a.q_tile_major ? Q + ((q0 >> 7) + (wave >> 1)) * (int64_t)a.q_slab_rows * 128 + (wave & 1) * 64
-                                                             : Q + q0 + wave * 64);
+        const float4 *b = a.q_tile_major ? Q + ((q0 >> 7) + (wave >> 1)) * (int64_t)a.q_slab_rows * 128 + (wave & 1) * 64 : Q + q0 + wave * 64;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(b), 0, 0x7fffffff, 0x00020000);
     };
     auto live = [&](const Tile &x) { return (int64_t)x.tq * BT < q_end; };      // q_end <= Qpad; tq grows monotonically
 
     Tile t{(int)(blockIdx.x % ntp), (int)(blockIdx.x / ntp)};      // tile being multiplied
     if (!live(t)) return;
     Tile tf = t;                       // tile being fetched (one stage ahead of the multiplication)
-    const char *pg = p_base(tf), *qg = q_base(tf);
+    unsigned po = p_off(tf), qo = 0;   // running byte offsets of the next stage to request
+    __amdgpu_buffer_rsrc_t qrs = q_rsrc(tf);
+    const unsigned p_row = (unsigned)(a.ldp * 16), q_row = (unsigned)(qrow * 16);
     int fetch_left = nstage;           // stages of tile tf not yet requested
     bool fetching = true;
 #define FAT_DMA_ROWS(buf, r0, r1)                                                                                \
     _Pragma("unroll") for (int r = (r0); r < (r1); ++r) {                                                        \
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(pg + (int64_t)r * a.ldp * 16 + voff), \
-                                         (void __attribute__((address_space(3))) *)(SP(buf) + r * BT + wave * 64), 16, 0, 0); \
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(qg + (int64_t)r * qrow * 16 + voff),  \
-                                         (void __attribute__((address_space(3))) *)(SQ(buf) + r * BT + wave * 64), 16, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(prs, (void __attribute__((address_space(3))) *)(SP(buf) + r * BT + wave * 64), 16, voff, po + r * p_row, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (void __attribute__((address_space(3))) *)(SQ(buf) + r * BT + wave * 64), 16, voff, qo + r * q_row, 0, 0); \
     }
     // after a stage's requests: advance to the next stage of the tile being fetched, or to the next tile of this workgroup
 #define FAT_DMA_NEXT()                                                                                           \
     {                                                                                                            \
-        if (--fetch_left > 0) { pg += (int64_t)KQ * a.ldp * 16; qg += (int64_t)KQ * qrow * 16; }                 \
+        if (--fetch_left > 0) { po += KQ * p_row; qo += KQ * q_row; }                                            \
         else {                                                                                                   \
             advance(tf);                                                                                         \
             fetching = live(tf);                                                                                 \
-            if (fetching) { pg = p_base(tf); qg = q_base(tf); fetch_left = nstage; }                             \
+            if (fetching) { po = p_off(tf); qo = 0; qrs = q_rsrc(tf); fetch_left = nstage; }                     \
         }                                                                                                        \
     }
 #define FAT_READ(sp, sq, kb, FA, FB)                                                                             \
@@ -787,64 +792,115 @@ __global__ __launch_bounds__(256, 1) void gemm_fat_kernel(GemmArgs a) {
     FAT_READ(SP(0), SQ(0), 1, fa1, fb1)
     FAT_READ(SP(0), SQ(0), 2, fa2, fb2)
     FAT_READ(SP(0), SQ(0), 3, fa3, fb3)
+#ifndef SDFA_FAT_RG
+#define SDFA_FAT_RG 4
+#endif
+#define FAT_RG SDFA_FAT_RG
+#ifndef SDFA_FAT_DG
+#define SDFA_FAT_DG 1
+#endif
+#define FAT_DG SDFA_FAT_DG   /* the 16 DMA requests of a stage in 4 / FAT_DG groups */
 #define FAT_Q(A, B, q)                                                                                           \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = MFMA(SDFA_OP(f4c(A[i], q)), SDFA_OP(f4c(B[j], q)), acc[i][j]);
+#ifdef SDFA_STAMPS
+    unsigned long long ft0 = 0, ft1 = 0, ft2 = 0, ft3 = 0, ft4 = 0, fs_k0 = 0, fs_k12 = 0, fs_bar = 0, fs_last = 0, fs_n = 0, fs_epi = 0, fs_tiles = 0;
+#define FSTAMP(t) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define FSTAMP_SUM() { fs_k0 += ft1 - ft0; fs_k12 += ft2 - ft1; fs_bar += ft3 - ft2; fs_last += ft4 - ft3; ++fs_n; }
+#else
+#define FSTAMP(t)
+#define FSTAMP_SUM()
+#endif
 #define FAT_STAGE(BUF, LAST_A, LAST_B, FREE_A, FREE_B)                                                           \
     {                                                                                                            \
+        FSTAMP(ft0)                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                       \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                          \
-            if (fetching) { FAT_DMA_ROWS((BUF) ^ 1, 2 * q, 2 * q + 2) }   /* the next stage, into the buffer the previous barrier released */ \
+            if (fetching && (q % FAT_DG) == 0) { FAT_DMA_ROWS((BUF) ^ 1, 2 * q, 2 * q + 2 * FAT_DG) }   /* the next stage, into the buffer the previous barrier released */ \
             __builtin_amdgcn_sched_barrier(0);                                                                   \
             FAT_Q(fa0, fb0, q)                                                                                   \
             __builtin_amdgcn_sched_barrier(0);                                                                   \
         }                                                                                                        \
         if (fetching) FAT_DMA_NEXT()                                                                             \
+        FSTAMP(ft1)                                                                                              \
         mfma_block<4, 4>(acc, fa1, fb1);                                                                         \
         mfma_block<4, 4>(acc, fa2, fb2);                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                       \
+        FSTAMP(ft2)                                                                                              \
         /* this wave's LDS-DMA of the next stage must have LANDED before the barrier lets the other waves read it: an       \
            explicit vmcnt(0) (gfx9 encoding, expcnt 7 = no wait) -- the compiler's fence only covers this wave's own reads */ \
         __builtin_amdgcn_s_waitcnt(0x0070);                                                                      \
         __syncthreads();   /* every wave holds the rest of BUF in registers */                                   \
-        {   /* (behind the very last stage these reads fetch stale LDS contents that nobody uses: no branch around MFMAs) */ \
+        FSTAMP(ft3)                                                                                              \
+        {   /* k-block 3 with the next stage's 32 LDS reads in groups of FAT_RG between its MFMAs.  (Behind the very last  \
+               stage the reads fetch stale LDS contents that nobody uses: no branch around MFMAs.) */            \
             const float4 *sp = SP((BUF) ^ 1), *sq = SQ((BUF) ^ 1);                                               \
             FAT_READ(sp, sq, 0, fa0, fb0)                                                                        \
-            __builtin_amdgcn_sched_barrier(0);                                                                   \
-            FAT_Q(LAST_A, LAST_B, 0)                                                                             \
-            __builtin_amdgcn_sched_barrier(0);                                                                   \
             FAT_READ(sp, sq, 1, fa1, fb1)                                                                        \
-            __builtin_amdgcn_sched_barrier(0);                                                                   \
-            FAT_Q(LAST_A, LAST_B, 1)                                                                             \
-            __builtin_amdgcn_sched_barrier(0);                                                                   \
             FAT_READ(sp, sq, 2, fa2, fb2)                                                                        \
-            __builtin_amdgcn_sched_barrier(0);                                                                   \
-            FAT_Q(LAST_A, LAST_B, 2)                                                                             \
-            __builtin_amdgcn_sched_barrier(0);                                                                   \
             FAT_READ(sp, sq, 3, FREE_A, FREE_B)                                                                  \
-            __builtin_amdgcn_sched_barrier(0);                                                                   \
-            FAT_Q(LAST_A, LAST_B, 3)                                                                             \
+            mfma_block<4, 4>(acc, LAST_A, LAST_B);                                                               \
+            _Pragma("unroll") for (int m = 0; m < 32 / FAT_RG; ++m) {                                            \
+                __builtin_amdgcn_sched_group_barrier(0x100, FAT_RG, 0);                                          \
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * FAT_RG, 0);                                      \
+            }                                                                                                    \
         }                                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                       \
+        FSTAMP(ft4)                                                                                              \
+        FSTAMP_SUM()                                                                                             \
     }
     for (;;) {
         for (int st = 0; st < nstage; st += 2) {
             FAT_STAGE(0, fa3, fb3, fa4, fb4)
             FAT_STAGE(1, fa4, fb4, fa3, fb3)
         }
-        const int64_t p0 = (int64_t)t.tp * BT, q0 = (int64_t)t.tq * BT;
+        // Epilogue (vector-ALU time the matrix pipe does not get back, so as few instructions as possible): the launcher only
+        // sends K4 outputs with whole 256-row blocks here, so there is no row predicate; bias quads are requested once per
+        // row group (16 loads per tile, not 64); store addresses are a uniform base (scalar) + one 32-bit lane offset.
+        {
+            const int64_t p0 = (int64_t)t.tp * BT, q0 = (int64_t)t.tq * BT;
+            char *dbase = reinterpret_cast<char *>(a.D) + (((p0 >> 2) + wp * 32) * a.ldd + q0 + wq * 128) * 16;     // uniform
+            const unsigned dlane = (unsigned)((h * a.ldd + l31) * 16);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
+                float4 b[4];
+                if (BIAS_P) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                store_tile<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, acc[i][j], p0 + wp * 128 + i * 32, q0 + wq * 128 + j * 32 + l31, h);
+                    for (int g = 0; g < 4; ++g) b[g] = ld4(a.bias + p0 + wp * 128 + i * 32 + 8 * g + 4 * h);
+                }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                        if (BIAS_P) { v[0] += b[g].x; v[1] += b[g].y; v[2] += b[g].z; v[3] += b[g].w; }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (ACT == ACT_LRELU) v[e] = lrelu02(v[e]);
+                            if (ACT == ACT_TANH) v[e] = tanhf_acc(v[e]);
+                        }
+                        *reinterpret_cast<float4 *>(dbase + ((int64_t)(i * 8 + 2 * g) * a.ldd + j * 32) * 16 + dlane) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                }
             }
+        }
+#ifdef SDFA_STAMPS
+        { unsigned long long te; FSTAMP(te) fs_epi += te - ft4; ++fs_tiles; }
+#endif
         advance(t);
         if (!live(t)) break;
     }
+#ifdef SDFA_STAMPS
+    if (lane == 0 && nstage <= 16) {
+        atomicAdd(&g_stamp[0], fs_k0); atomicAdd(&g_stamp[1], fs_k12); atomicAdd(&g_stamp[2], fs_bar); atomicAdd(&g_stamp[3], fs_last);
+        atomicAdd(&g_stamp[4], fs_n); atomicAdd(&g_stamp[5], fs_epi); atomicAdd(&g_stamp[6], fs_tiles);
+    }
+#endif
 #undef FAT_STAGE
+#undef FAT_RG
+#undef FAT_DG
 #undef FAT_Q
 #undef FAT_DMA_ROWS
 #undef FAT_DMA_NEXT
@@ -974,10 +1030,14 @@ hipError_t launch_any(const GemmArgs &a, hipStream_t s) {
     // twice over -- the frequency projection (-5.6 %) and the BiLSTM input projections (-8 / -9.5 %); gemm_variant 8 forces it,
     // 9 keeps the round-1/2 choice below
     {
-        const bool fits = a.Ppad % 256 == 0 && a.Qpad % 256 == 0 && a.seg_k == a.K && a.K % 64 == 0 && OUT_MODE == OUT_K4;
+        const bool fits = a.Ppad % 256 == 0 && a.Qpad % 256 == 0 && a.seg_k == a.K && a.K % 64 == 0 && OUT_MODE == OUT_K4 && !BIAS_Q && !COND &&
+                          a.Pstore == a.Ppad && a.ldd * 16 * 2 < (int64_t)1 << 32 &&
+                          (int64_t)(a.K / 4) * a.ldp * 16 < 0x7fffffff && (int64_t)(a.K / 4) * (a.q_tile_major ? 128 : a.ldq) * 16 < 0x7fffffff;   // buffer offsets
         const int64_t ntiles = (a.Ppad / 256) * (a.Qpad / 256);
-        if (fits && (g_sdfa_gemm_variant == 8 || (g_sdfa_gemm_variant == 0 && ntiles >= 512)))
-            return launch_fat<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
+        if constexpr (OUT_MODE == OUT_K4 && !BIAS_Q && !COND) {
+            if (fits && (g_sdfa_gemm_variant == 8 || (g_sdfa_gemm_variant == 0 && ntiles >= 512)))
+                return launch_fat<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
+        }
     }
     // 256 x 256 tile: on request (gemm_variant 5), and by default for the 8192-deep frequency projection, whose operand
     // stream (2 MB of hidden states per frame) is what the 128 x 128 tile waits for (40.3 vs 41.7 ms); the L2-resident

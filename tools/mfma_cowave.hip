@@ -19,7 +19,7 @@ __device__ unsigned long long g_res[4];   // MFMA waves: sum cycles, count; VALU
 // pipe works on the MFMA just issued (a 32x32x2 MFMA occupies the pipe for 64 cycles)
 // SWAP: the vector-ALU waves are the OLDER ones (waves 0-3), the MFMA waves the younger (4-7)
 template <int SHAPE, int KIND, int PRIO, int ACC, int GAP = 0, bool SWAP = false>
-__global__ __launch_bounds__(512) void k(float *out, int iters, float a0) {
+__global__ __launch_bounds__(512) void k(float *out, int iters, float a0, const float4 *gsrc) {
     __shared__ volatile int done[4];
     const int wave = SWAP ? ((threadIdx.x >> 6) ^ 4) : (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (threadIdx.x < 4) done[threadIdx.x] = 0;
@@ -104,6 +104,28 @@ __global__ __launch_bounds__(512) void k(float *out, int iters, float a0) {
         for (int q = 0; q < 8; ++q) v[q] = a + q;
         unsigned long long n = 0;
         const unsigned long long t0 = clock64();
+        if (KIND >= 4) {                  // memory instructions instead of vector-ALU ones: 16 per iteration
+            __shared__ float4 dst[4][16][64];
+            unsigned long long n4 = 0;
+            float4 keep = {0.f, 0.f, 0.f, 0.f};
+            const unsigned long long t0m = clock64();
+#pragma unroll 1
+            while (!done[wave - 4]) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (KIND == 4)
+                        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(gsrc + r * 64 + lane),
+                                                         (void __attribute__((address_space(3))) *)(&dst[wave - 4][r][0]), 16, 0, 0);
+                    else { const float4 x = dst[wave - 4][r][lane]; keep.x += x.x; }
+                }
+                if (KIND == 4) __builtin_amdgcn_s_waitcnt(0x0070);
+                ++n4;
+            }
+            const unsigned long long t1m = clock64();
+            if (lane == 0) { atomicAdd(&g_res[2], t1m - t0m); atomicAdd(&g_res[3], n4 * 4); }      // x 4: reported per instruction below (n * 64 / 16)
+            if (keep.x == 123.456f) out[1] = keep.x;
+            return;
+        }
 #pragma unroll 1
         while (!done[wave - 4]) {         // one LDS read per 64 vector instructions
 #pragma unroll
@@ -131,21 +153,21 @@ void run(float *d) {
     unsigned long long z[4] = {0, 0, 0, 0}, r[4];
     for (int rep = 0; rep < 2; ++rep) {
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_res), z, sizeof z);
-        hipLaunchKernelGGL((k<SHAPE, KIND, PRIO, ACC, GAP, SWAP>), dim3(256), dim3(512), 0, 0, d, iters, 1e-30f);
+        hipLaunchKernelGGL((k<SHAPE, KIND, PRIO, ACC, GAP, SWAP>), dim3(256), dim3(512), 0, 0, d, iters, 1e-30f, reinterpret_cast<const float4 *>(d + 64));
         (void)hipDeviceSynchronize();
     }
     (void)hipMemcpyFromSymbol(r, HIP_SYMBOL(g_res), sizeof r);
     const double mf = (double)r[0] / r[1], ideal = (double)iters * 2048.0;
-    const char *kinds[] = {"none", "fma (full rate)", "v_exp (transcendental)", "3 fma : 1 v_rcp"};
+    const char *kinds[] = {"none", "fma (full rate)", "v_exp (transcendental)", "3 fma : 1 v_rcp", "global_load_lds x4 (1 KiB)", "ds_read_b128"};
     const char *shapes[] = {"no MFMAs (sleep)", "32x32x2", "16x16x4", "32x32x16 bf16"};
     printf("%s%-16s %-9s gap %2d prio %d  partner VALU: %-24s", SWAP ? "[VALU waves older] " : "", shapes[SHAPE + 1], ACC ? "acc VGPR" : "acc auto", GAP, PRIO, kinds[KIND]);
     if (SHAPE >= 0) printf(" MFMA pipe efficiency %.3f", ideal / mf);
-    if (KIND) printf("   partner: %.2f cycles per VALU instruction", (double)r[2] / ((double)r[3] * 64));
+    if (KIND) printf("   partner: %.2f cycles per instruction", (double)r[2] / ((double)r[3] * 64));
     printf("\n");
 }
 
 int main() {
-    float *d; (void)hipMalloc(&d, 8);
+    float *d; (void)hipMalloc(&d, 8 + 64 * 4 + 16 * 64 * 16);
     run<-1, 1, 1>(d); run<-1, 2, 1>(d); run<-1, 3, 1>(d);
     run<0, 0, 1>(d); run<0, 1, 1>(d); run<0, 2, 1>(d); run<0, 3, 1>(d); run<0, 1, 0>(d); run<0, 3, 0>(d);
     run<0, 1, 1, 1>(d); run<0, 3, 1, 1>(d); run<0, 3, 0, 1>(d);
@@ -154,6 +176,7 @@ int main() {
     run<0, 1, 1, 1, 0, true>(d); run<0, 2, 1, 1, 0, true>(d); run<0, 3, 1, 1, 0, true>(d); run<0, 3, 0, 1, 0, true>(d); run<-1, 3, 0, 1, 0, true>(d);
     run<0, 0, 1, 1, 1>(d); run<0, 3, 1, 1, 1>(d); run<0, 1, 1, 1, 1>(d); run<0, 3, 0, 1, 1>(d); run<0, 3, 1, 1, 2>(d);
     run<2, 0, 1>(d); run<2, 1, 1>(d); run<2, 2, 1>(d); run<2, 3, 1>(d); run<2, 3, 0>(d);
+    run<-1, 4, 1>(d); run<0, 4, 1, 1>(d); run<-1, 5, 1>(d); run<0, 5, 1, 1>(d);
     run<1, 0, 1>(d); run<1, 1, 1>(d); run<1, 2, 1>(d); run<1, 3, 1>(d); run<1, 3, 0>(d);
     return 0;
 }
