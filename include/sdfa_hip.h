@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SDFA_ABI_VERSION 2   /* 2: + seek, resample, mesh correspondences, multi-destination regress (round 2); all of version 1 unchanged */
+#define SDFA_ABI_VERSION 2   /* 2: + seek, resample, mesh correspondences, multi-destination regress, expand_coef, autotune (round 2); all of version 1 unchanged */
 
 #define SDFA_OK            0
 #define SDFA_EINVAL       -1   /* bad argument (shape, size, null pointer, unsupported rate) */
