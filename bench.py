@@ -13,7 +13,7 @@ issued chunk by chunk so that it overlaps the next chunk's compute (`--gather dg
 coefficients followed by a local, bit-identical re-expansion of the peers' rows (`--gather expand`); the default `auto`
 times both before the measurement and uses the faster (reported in `config`).
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fused frequency-LSTM recurrence freq_lstm_v2_kernel,
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fused frequency-LSTM recurrence freq_lstm_v3_kernel,
 fp32 MFMA), measured live with HIP events on the launch stream; `cpu_baseline` times the CPU port of the reference
 path on the reference's own operator library (oracle/torch_oracle.py, torch CPU) on a bounded sample on rank 0 at N=1.
 """
@@ -353,7 +353,7 @@ def main():
                        "gather_auto_ms_per_step": None if auto is None else {k: round(v, 2) for k, v in auto.items()},
                        "gather_checksum_ok": gather_check, "weights": "synthetic seed 1234",
                        "mesh_stage": None if mesh is None else f"seek to 60 fps + mesh solve, {mesh[1].n_queries} video frames x {mesh[0].n_verts} vertices per GPU per step"},
-            "roofline": {"kernel": "freq_lstm_v2_kernel", "bound": "mfma", "achieved": round(achieved, 2),
+            "roofline": {"kernel": "freq_lstm_v3_kernel" if eng.freq_lstm_form in (None, 8, 9) else "freq_lstm_v2_kernel", "bound": "mfma", "achieved": round(achieved, 2),
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                          "traffic": traffic, "traffic_algorithmic": traffic_alg, "traffic_source": traffic_src,
                          "launch_ms": round(lstm_ms_per_launch, 3), "flop_per_launch": flop_per_launch},

@@ -138,8 +138,8 @@ int64_t     sdfa_model_coef_dim(const sdfa_model *m);         /* 265 (85 scale |
 int         sdfa_model_set_precision(sdfa_model *m, int mode);
 int         sdfa_model_precision(const sdfa_model *m);
 
-/* Optional, once per model and device: times the bit-identical launch forms of the fp32 frequency-LSTM recurrence (hardware-
- * dispatched or persistent workgroups, one or two per CU) on `n_frames` frames of zeros in the caller's workspace and keeps
+/* Optional, once per model and device: times the bit-identical kernels / launch forms of the fp32 frequency-LSTM recurrence (the
+ * one-workgroup-per-CU kernel and the two-per-CU kernel, hardware-dispatched or persistent) on `n_frames` frames of zeros in the caller's workspace and keeps
  * the fastest for all later forward calls.  Blocks until the measurement is done (about 10 launches of the kernel).  Returns
  * the form chosen (> 0) or a negative error code.  Results of the forward calls do not depend on it.  (New: the reference has
  * no counterpart; its PyTorch kernels are picked by cuDNN's own heuristics.) */

@@ -12,7 +12,7 @@ Rows are keyed by (kernel symbol, grid size).  Collect the passes with `bench.py
 --no-mixed-precision`: a column-sharing run launches the SAME symbol and grid for the projection GEMMs but most of its
 workgroups exit at once (q_limit), and the two would be averaged into one row (the round-1 summary did that).
 
---traffic-json writes the freq_lstm_kernel figures of the largest launch, which bench.py scales to its frames per launch
+--traffic-json writes the frequency-LSTM kernel's figures of the largest launch (a hardware-dispatched form: one workgroup per tile), which bench.py scales to its frames per launch
 for `roofline.traffic`.
 """
 import collections
@@ -43,7 +43,8 @@ def main():
         fk, wk = sum(f) / len(f), sum(w) / len(w)
         print(f"{k[0][:46]:46s} {k[1]:10d} {len(m):5d} {sum(m) / len(m):10.1f} {fk:14.0f} {fk * 1024 * FETCH_CORRECTION / 1e9:13.3f} {wk * 1024 / 1e9:10.3f}")
     if "--traffic-json" in sys.argv:
-        key = max((k for k in M if k[0].startswith(("freq_lstm_v2_kernel<false", "freq_lstm_kernel<false"))), key=lambda k: (k[0].startswith("freq_lstm_v2"), k[1]))
+        key = max((k for k in M if k[0].startswith(("freq_lstm_v3_kernel<false, false", "freq_lstm_v2_kernel<false, false", "freq_lstm_kernel<false"))),
+                  key=lambda k: (k[0].startswith("freq_lstm_v3"), k[0].startswith("freq_lstm_v2"), k[1]))      # hardware-dispatched forms: grid = tiles
         frames = key[1] // 256 // 2          # grid = (frames * 64 columns / 64 per workgroup) * 2 directions * 256 threads
         fk, wk = sum(F[key]) / len(F[key]), sum(W[key]) / len(W[key])
         read_b, write_b = fk * 1024 * FETCH_CORRECTION, wk * 1024

@@ -37,7 +37,7 @@ for r in seq:
     n = clean(r)
     if n.startswith("conv123_kernel"):
         want = True
-    elif want and n.startswith(("freq_lstm_v2_kernel", "freq_lstm_kernel", "freq_lstm_bf16_kernel")):
+    elif want and n.startswith(("freq_lstm_v3_kernel", "freq_lstm_v2_kernel", "freq_lstm_kernel", "freq_lstm_bf16_kernel")):
         in_step[n].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
         want = False
 print()

@@ -148,7 +148,7 @@ struct sdfa_model {
     int pca_n = 0;
     const float *pca_q[2], *pca_bias[2];
     int pca_K[2], pca_k0[2], pca_group[2], pca_off[2];
-    int freq_shape = 5;   // launch form of the fp32 frequency LSTM (kernels.h FreqLstmArgs::shape); sdfa_model_autotune measures and sets it
+    int freq_shape = 9;   // launch form of the fp32 frequency LSTM (kernels.h FreqLstmArgs::shape); sdfa_model_autotune measures and sets it
     int64_t pca_ld[2], pca_cols[2];
     int64_t out_dim, coef_dim;
     // profiling
@@ -780,8 +780,9 @@ int sdfa_model_set_precision(sdfa_model *m, int mode) {
 
 int sdfa_model_precision(const sdfa_model *m) { return m ? m->precision : SDFA_EINVAL; }
 
-// The four launch forms of the fp32 frequency LSTM are bit-identical and within 1-3 % of each other, in an order that is
-// a property of how the two resident workgroups of a CU happen to interleave: measure, don't guess.
+// The kernels / launch forms of the fp32 frequency LSTM are bit-identical and within 1-3 % of each other; for the forms with
+// two resident workgroups per CU the order is a property of how the two happen to interleave:
+// measure, don't guess.
 int sdfa_model_autotune(sdfa_model *m, int64_t n_frames, void *d_workspace, int64_t workspace_bytes, void *stream) {
     if (!m || !m->finalized) return fail(SDFA_ESTATE, "autotune: model not finalised");
     if (!d_workspace || n_frames <= 0 || ((uintptr_t)d_workspace & 15)) return fail(SDFA_EINVAL, "autotune: bad argument");
@@ -795,7 +796,7 @@ int sdfa_model_autotune(sdfa_model *m, int64_t n_frames, void *d_workspace, int6
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    static const int forms[] = {5, 3, 7, 6};
+    static const int forms[] = {9, 8, 5, 3};      // third form persistent / hardware-dispatched; second form persistent / hardware-dispatched (two per CU)
     float best_ms = 0.f;
     int best = m->freq_shape, rc = SDFA_OK;
     for (int form : forms) {

@@ -506,6 +506,217 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_v2_kernel(FreqLstmArgs a) {
 #undef FV_W1
 }
 
+// ------------------------------------------------------------------------------- frequency LSTM, third form
+// freq_lstm_v2_kernel rebuilt for ONE workgroup per CU (one wave per SIMD), after the finding that an MFMA in flight and
+// the other instructions of a SIMD exclude each other: a second resident workgroup only fills
+// stalls, so the design goal is a wave with no stalls and as few non-MFMA issue cycles as possible.
+//   * x_f and h live in ONE LDS buffer per step parity, [16 x rows | 32 h rows] (96 KiB for both parities): the operand row
+//     of k-block kb is base + kb * 2 KiB whatever it holds, so the K loop needs no per-k-block address arithmetic (the
+//     second form spent four vector instructions per two k-blocks on a select between two arrays), and h being double
+//     buffered makes the barrier between the K loop and the cell update unnecessary: ONE barrier per step;
+//   * the K loop runs in trips of 8 k-blocks with immediate offsets (the first step, x only, is one trip), and the six
+//     memory instructions that refill the other operand set sit one or two at a time in front of the four 8-MFMA groups
+//     of a k-block: each rides in the shadow of the MFMA in flight instead of six in a row outlasting it;
+//   * same arithmetic, same order of operations per accumulator: bit-identical.
+// (launch bounds as for two workgroups per CU although the LDS footprint allows one: with a 512-register budget the compiler
+// moves the accumulators into AGPRs and the cell update pays a v_accvgpr_read per value)
+template <bool SHARED, bool PERSIST>
+__global__ __launch_bounds__(256, 2) void freq_lstm_v3_kernel(FreqLstmArgs a) {
+    constexpr int NJ = 2, BT = 64, ROWS = 48;
+    extern __shared__ float4 sDyn3[];                                   // [2 parities][48 rows][64] + bias + queue slot
+    float4 (*sXH)[ROWS][BT] = reinterpret_cast<float4 (*)[ROWS][BT]>(sDyn3);
+    float *sBias = reinterpret_cast<float *>(sDyn3 + 2 * ROWS * BT);
+    int *sTile = reinterpret_cast<int *>(sBias + 512);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const float4 *__restrict__ X3 = reinterpret_cast<const float4 *>(a.X3);
+    float4 *__restrict__ HF = reinterpret_cast<float4 *>(a.HF);
+    const int n_tiles = (int)(a.Mc / BT) * 2;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  for (;;) {      // PERSIST: one pass per tile taken from the queue; otherwise a single pass
+    int dir;
+    int64_t m0;
+    if (PERSIST) {
+        if (tid == 0) *sTile = atomicAdd(a.tile_counter, 1);
+        __syncthreads();                       // (also: every wave has left the previous tile's last step)
+        const int t = __builtin_amdgcn_readfirstlane(*sTile);
+        if (t >= n_tiles) break;               // queue empty: every workgroup gets here
+        dir = t & 1;
+        m0 = (int64_t)(t >> 1) * BT;
+        if (SHARED && m0 >= *a.col_limit) break;
+    } else {
+        dir = (blockIdx.x >> 3) & 1;
+        m0 = (int64_t)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) * BT;
+        if (SHARED && m0 >= *a.col_limit) return;
+    }
+    const float4 *__restrict__ W = reinterpret_cast<const float4 *>(a.W) + (size_t)dir * 48 * 512;
+    sBias[tid] = a.bias[dir * 512 + tid];
+    sBias[256 + tid] = a.bias[dir * 512 + 256 + tid];
+
+    // x_f tile = 16 k-quad rows of 64 columns (1 KiB each): wave w moves rows w, w+4, w+8, w+12
+    const float4 *__restrict__ xsrc = X3 + (int64_t)wave * a.Mc + m0 + lane;
+#define XDMA3(f, par)                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                      \
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(xsrc + (int64_t)((f)*16 + 4 * i) * a.Mc), \
+                                         (void __attribute__((address_space(3))) *)(&sXH[par][4 * i + wave][0]), 16, 0, 0);
+    XDMA3(dir ? 31 : 0, 0)
+
+    f32x16 c[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[j][r] = 0.f;
+
+    // weight quads through a buffer descriptor, as in the second form
+    const unsigned long long wptr = (unsigned long long)(W + wave * 128);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)wptr, 0, 48 * 512 * 16, 0x00020000);
+    const unsigned woff = (unsigned)((l31 + h * 512) * 16);
+#define F3_W(so, g_) __builtin_bit_cast(float4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(wrs, woff + 512 * (g_), so, 0))
+#define F3_SB() __builtin_amdgcn_sched_barrier(0);
+#define F3_Q(W0, W1, W2, W3, B0, B1, q)                                                                      \
+    {                                                                                                        \
+        acc[0][0] = MFMA(SDFA_OP(f4c(W0, q)), SDFA_OP(f4c(B0, q)), acc[0][0]);                               \
+        acc[0][1] = MFMA(SDFA_OP(f4c(W0, q)), SDFA_OP(f4c(B1, q)), acc[0][1]);                               \
+        acc[1][0] = MFMA(SDFA_OP(f4c(W1, q)), SDFA_OP(f4c(B0, q)), acc[1][0]);                               \
+        acc[1][1] = MFMA(SDFA_OP(f4c(W1, q)), SDFA_OP(f4c(B1, q)), acc[1][1]);                               \
+        acc[2][0] = MFMA(SDFA_OP(f4c(W2, q)), SDFA_OP(f4c(B0, q)), acc[2][0]);                               \
+        acc[2][1] = MFMA(SDFA_OP(f4c(W2, q)), SDFA_OP(f4c(B1, q)), acc[2][1]);                               \
+        acc[3][0] = MFMA(SDFA_OP(f4c(W3, q)), SDFA_OP(f4c(B0, q)), acc[3][0]);                               \
+        acc[3][1] = MFMA(SDFA_OP(f4c(W3, q)), SDFA_OP(f4c(B1, q)), acc[3][1]);                               \
+    }
+    // one k-block on the operand set C* while the set N* is refilled for the next one: weights at scalar offset `so`,
+    // operand rows at `bp` (per-lane pointer to the row pair of the next k-block)
+#define F3_KB(CW0, CW1, CW2, CW3, CB0, CB1, NW0, NW1, NW2, NW3, NB0, NB1, so, bp)                            \
+    {                                                                                                        \
+        F3_SB() NW0 = F3_W(so, 0); NW1 = F3_W(so, 1); F3_SB()                                                \
+        F3_Q(CW0, CW1, CW2, CW3, CB0, CB1, 0)                                                                \
+        F3_SB() NW2 = F3_W(so, 2); NW3 = F3_W(so, 3); F3_SB()                                                \
+        F3_Q(CW0, CW1, CW2, CW3, CB0, CB1, 1)                                                                \
+        F3_SB() NB0 = (bp)[0]; F3_SB()                                                                       \
+        F3_Q(CW0, CW1, CW2, CW3, CB0, CB1, 2)                                                                \
+        F3_SB() NB1 = (bp)[32]; F3_SB()                                                                      \
+        F3_Q(CW0, CW1, CW2, CW3, CB0, CB1, 3)                                                                \
+    }
+    // the last k-block of a step: the same, with the four LDS-DMA requests of the next x tile behind its last two MFMA
+    // groups -- an LDS-DMA request takes ~100 cycles to issue (tools/stamp_fat.py), four in a row in front of the cell update
+    // cost 400; here most of that rides in the MFMAs' shadow.  They come AFTER this k-block's weight requests, so the next
+    // step's first weight wait (loads return in issue order) does not include the tile's HBM round trip.
+#define F3_KB_LAST(CW0, CW1, CW2, CW3, CB0, CB1, NW0, NW1, NW2, NW3, NB0, NB1, so, bp, dma, fnext, par)      \
+    {                                                                                                        \
+        F3_SB() NW0 = F3_W(so, 0); NW1 = F3_W(so, 1); F3_SB()                                                \
+        F3_Q(CW0, CW1, CW2, CW3, CB0, CB1, 0)                                                                \
+        F3_SB() NW2 = F3_W(so, 2); NW3 = F3_W(so, 3); F3_SB()                                                \
+        F3_Q(CW0, CW1, CW2, CW3, CB0, CB1, 1)                                                                \
+        F3_SB() NB0 = (bp)[0]; NB1 = (bp)[32];      /* both LDS reads BEFORE the first DMA request: the compiler puts a full  \
+                                                       vmcnt(0) in front of any LDS read that follows one */ \
+        if (dma) { XDMA3_HALF(fnext, par, 0) }                                                               \
+        F3_SB()                                                                                              \
+        F3_Q(CW0, CW1, CW2, CW3, CB0, CB1, 2)                                                                \
+        F3_SB()                                                                                              \
+        if (dma) { XDMA3_HALF(fnext, par, 2) }                                                               \
+        F3_SB()                                                                                              \
+        F3_Q(CW0, CW1, CW2, CW3, CB0, CB1, 3)                                                                \
+    }
+#define XDMA3_HALF(f, par, i0)                                                                                         \
+    _Pragma("unroll") for (int i = (i0); i < (i0) + 2; ++i)                                                            \
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(xsrc + (int64_t)((f)*16 + 4 * i) * a.Mc), \
+                                         (void __attribute__((address_space(3))) *)(&sXH[par][4 * i + wave][0]), 16, 0, 0);
+    float4 wa0, wa1, wa2, wa3, wb0, wb1, wb2, wb3, ba0, ba1, bb0, bb1;
+    wa0 = F3_W(0u, 0); wa1 = F3_W(0u, 1); wa2 = F3_W(0u, 2); wa3 = F3_W(0u, 3);
+#ifdef SDFA_STAMPS
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, v_init = 0, v_k = 0, v_ep = 0, v_b2 = 0;
+#endif
+    __syncthreads();   // bias and the first x tile are in LDS (the fence drains the DMA)
+
+    for (int s = 0; s < 32; ++s) {
+        const int f = dir ? 31 - s : s;
+        const int cur = s & 1;
+        f32x16 acc[4][NJ];
+        LSTAMP(t0)
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 b = *reinterpret_cast<const float4 *>(&sBias[wave * 128 + gt * 32 + 8 * g + 4 * h]);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    acc[gt][j][4 * g + 0] = b.x; acc[gt][j][4 * g + 1] = b.y;
+                    acc[gt][j][4 * g + 2] = b.z; acc[gt][j][4 * g + 3] = b.w;
+                }
+            }
+        const int trips = s > 0 ? 3 : 1;       // h_{-1} = 0: the first step contracts x_f only (8 of the 24 k-blocks)
+        const float4 *brow = &sXH[cur][h][l31];                 // row pair of k-block kb: brow + kb * 2 * BT
+        ba0 = brow[0]; ba1 = brow[32];
+        LSTAMP(t1)
+#pragma unroll 1
+        for (int t = 0; t < trips; ++t) {
+            const float4 *bt = brow + t * 16 * BT;
+            const float4 *bn = t + 1 < trips ? bt + 16 * BT : brow;      // behind the last trip: k-block 0 again (dropped)
+            const unsigned so = (unsigned)t * (8 * 1024 * 16);
+            const unsigned son = t + 1 < trips ? so + 8 * 1024 * 16 : 0u; // ... whose weights ARE k-block 0 of the next step
+            F3_KB(wa0, wa1, wa2, wa3, ba0, ba1, wb0, wb1, wb2, wb3, bb0, bb1, so + 1 * 1024 * 16, bt + 1 * 2 * BT)
+            F3_KB(wb0, wb1, wb2, wb3, bb0, bb1, wa0, wa1, wa2, wa3, ba0, ba1, so + 2 * 1024 * 16, bt + 2 * 2 * BT)
+            F3_KB(wa0, wa1, wa2, wa3, ba0, ba1, wb0, wb1, wb2, wb3, bb0, bb1, so + 3 * 1024 * 16, bt + 3 * 2 * BT)
+            F3_KB(wb0, wb1, wb2, wb3, bb0, bb1, wa0, wa1, wa2, wa3, ba0, ba1, so + 4 * 1024 * 16, bt + 4 * 2 * BT)
+            F3_KB(wa0, wa1, wa2, wa3, ba0, ba1, wb0, wb1, wb2, wb3, bb0, bb1, so + 5 * 1024 * 16, bt + 5 * 2 * BT)
+            F3_KB(wb0, wb1, wb2, wb3, bb0, bb1, wa0, wa1, wa2, wa3, ba0, ba1, so + 6 * 1024 * 16, bt + 6 * 2 * BT)
+            F3_KB(wa0, wa1, wa2, wa3, ba0, ba1, wb0, wb1, wb2, wb3, bb0, bb1, so + 7 * 1024 * 16, bt + 7 * 2 * BT)
+            F3_KB(wb0, wb1, wb2, wb3, bb0, bb1, wa0, wa1, wa2, wa3, ba0, ba1, son, bn)
+        }
+        F3_SB()
+#ifdef SDFA_STAMPS
+        asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]), "v"(acc[0][1]), "v"(acc[1][1]), "v"(acc[2][1]), "v"(acc[3][1]));   // all MFMAs done
+#endif
+        LSTAMP(t2)
+        // The next x tile: four plain 16-byte loads per lane into registers, requested here -- BEHIND the step's last weight
+        // requests, so that no weight wait includes their HBM round trip (loads return in issue order) -- and written to the
+        // OTHER parity's buffer after the cell update, which covers the round trip.  (An LDS-DMA request for these rows, 8 MB
+        // apart, took ~230 cycles to ISSUE: 930 per step, wherever it was placed; tools/stamp_lstm2.py.)  wa* now hold
+        // k-block 0 of the next step's weights.
+        float4 xr0, xr1, xr2, xr3;
+        {
+            const int fn = s + 1 < 32 ? (dir ? 30 - s : s + 1) : f;      // behind the last step: this step's rows again (never used)
+            const float4 *xs = xsrc + (int64_t)(fn * 16) * a.Mc;
+            xr0 = xs[0]; xr1 = xs[4 * a.Mc]; xr2 = xs[8 * a.Mc]; xr3 = xs[12 * a.Mc];
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 hq;
+                lstm_cell_quad(acc[0][j], acc[1][j], acc[2][j], acc[3][j], c[j], g, hq);
+                const int hq_idx = 8 * wave + 2 * g + h;
+                sXH[cur ^ 1][16 + hq_idx][j * 32 + l31] = hq;
+                HF[((m0 >> 7) * (int64_t)HF_SLAB_ROWS + (f * 64 + dir * 32 + hq_idx)) * 128 + (m0 & 127) + j * 32 + l31] = hq;
+            }
+        sXH[cur ^ 1][wave][lane] = xr0; sXH[cur ^ 1][4 + wave][lane] = xr1; sXH[cur ^ 1][8 + wave][lane] = xr2; sXH[cur ^ 1][12 + wave][lane] = xr3;
+        // h_s and the next x tile must be in LDS before anyone starts step s+1: this wave's LDS writes (lgkmcnt); the
+        // hidden-state stores need not be acknowledged (a bare barrier: __syncthreads() would add their vmcnt(0))
+        LSTAMP(t3)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef SDFA_STAMPS
+        LSTAMP(t4)
+        if (s > 0) { v_init += t1 - t0; v_k += t2 - t1; v_ep += t3 - t2; v_b2 += t4 - t3; }
+#endif
+    }
+#ifdef SDFA_STAMPS
+    if (lane == 0) {
+        atomicAdd(&g_lstamp[0], v_init); atomicAdd(&g_lstamp[1], v_k); atomicAdd(&g_lstamp[3], v_ep); atomicAdd(&g_lstamp[4], v_b2); atomicAdd(&g_lstamp[6], 31ull);
+    }
+#endif
+#undef XDMA3
+#undef XDMA3_HALF
+#undef F3_KB_LAST
+#undef F3_W
+#undef F3_SB
+#undef F3_Q
+#undef F3_KB
+    if (!PERSIST) break;
+  }
+}
+
 // --------------------------------------------------------------------- frequency LSTM on bf16 MFMA
 // Mixed-precision modes (BASELINE configs[3]; sdfa_model_set_precision): the same recurrence on
 // v_mfma_f32_32x32x16_bf16 with fp32 accumulation, fp32 cell state and fp32 gate math.
@@ -1014,7 +1225,24 @@ extern "C" int sdfa_debug_read_lstm_span(unsigned long long *out, int reset) {
 template <bool SHARED>
 static hipError_t launch_freq(const FreqLstmArgs &a, hipStream_t s) {
     const int shape = a.shape;
-    if (shape == 3 || shape >= 5) {      // the second form
+    if (shape == 8 || shape == 9) {      // the third form: one workgroup per CU by construction (96 KiB of LDS)
+        const size_t lds = 2 * 48 * 64 * sizeof(float4) + 512 * sizeof(float) + 16;
+        const void *fn = shape == 9 ? reinterpret_cast<const void *>(freq_lstm_v3_kernel<SHARED, true>) : reinterpret_cast<const void *>(freq_lstm_v3_kernel<SHARED, false>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        const unsigned n_tiles = (unsigned)(a.Mc / 64 * 2);
+        if (shape == 9) {
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+            e = hipMemsetAsync(a.tile_counter, 0, sizeof(int), s);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((freq_lstm_v3_kernel<SHARED, true>), dim3(n_tiles < (unsigned)cus ? n_tiles : (unsigned)cus), dim3(256), lds, s, a);
+        } else {
+            hipLaunchKernelGGL((freq_lstm_v3_kernel<SHARED, false>), dim3(n_tiles), dim3(256), lds, s, a);
+        }
+        return hipGetLastError();
+    }
+    if (shape == 3 || (shape >= 5 && shape <= 7)) {      // the second form
         const unsigned n_tiles = (unsigned)(a.Mc / 64 * 2);
         // one workgroup per CU: 32 KB of unused dynamic LDS per workgroup (66 KB static)
         if (shape == 5 || shape == 7) {      // persistent: workgroups pull tiles from a queue; 5: two per CU, 7: one per CU

@@ -104,7 +104,7 @@ class Engine(FrontendOnly):
         the frequency-LSTM recurrence on this device and keep the fastest (sdfa_model_autotune; about half a second, once)."""
         super().__init__(device)
         self._autotune_pending = bool(autotune)
-        self.freq_lstm_form = None          # set by autotune(): 3 / 5 / 6 / 7 (include/sdfa_hip.h)
+        self.freq_lstm_form = None          # set by autotune(): 9 / 8 / 5 / 3 (csrc/kernels.h FreqLstmArgs::shape)
         folded = fold_state_dict(state_dict)
         self.head = head_of(state_dict)
         if strict:

@@ -345,9 +345,10 @@ def test_time_lstm_workgroup_shapes_are_bitwise_identical(synth_sd, golden):
 
 def test_freq_lstm_kernel_forms_are_bitwise_identical(synth_sd, golden):
     """freq_lstm_kernel (4) and the launch forms of freq_lstm_v2_kernel -- one hardware-dispatched workgroup per tile, two (3) or
-    one (6) per CU; persistent workgroups pulling tiles from a queue, two (5, the default) or one (7) per CU -- accumulate every
+    one (6) per CU; persistent workgroups pulling tiles from a queue, two (5) or one (7) per CU -- and of freq_lstm_v3_kernel, the one-workgroup-
+    per-CU design (8 hardware-dispatched, 9 persistent), accumulate every
     gate in the same order: not a bit may differ, also through the column-sharing launch, and when a persistent workgroup works
-    through several tiles (1,100 frames = 2,304 tiles).  sdfa_model_autotune picks among 3 / 5 / 6 / 7."""
+    through several tiles (1,100 frames = 2,304 tiles).  sdfa_model_autotune picks among 9 / 8 / 5 / 3."""
     from sdfa_amd import _lib
     clips = [synth.make_pcm(0, 32000), synth.make_pcm(5, 9088 + 777, "speechlike")]
     eng = Engine(synth_sd["dgrad"], max_frames=8192)
@@ -355,18 +356,18 @@ def test_freq_lstm_kernel_forms_are_bitwise_identical(synth_sd, golden):
     fc, fs, hop = eng.last_frame_table
     res = {}
     big = torch.rand((1100, 64, 128, 3), device="cuda")
-    for shape in (4, 3, 5, 6, 7):
+    for shape in (4, 3, 5, 6, 7, 8, 9):
         try:
             _lib.set_option("freq_lstm_shape", shape)
             res[shape] = (eng.encoder(feat), eng.encoder(feat, frame_clip=fc, frame_start=fs, hop=hop), eng.encoder(big))
         finally:
             _lib.set_option("freq_lstm_shape", 0)
     for k in (0, 1, 2):
-        for shape in (3, 5, 6, 7):
+        for shape in (3, 5, 6, 7, 8, 9):
             assert torch.equal(res[4][k][0], res[shape][k][0]) and torch.equal(res[4][k][1], res[shape][k][1]), (k, shape)
     assert torch.equal(res[4][0][0], res[4][1][0])
     form = eng.autotune(1100)
-    assert form in (3, 5, 6, 7) and eng.freq_lstm_form == form
+    assert form in (3, 5, 8, 9) and eng.freq_lstm_form == form
     z, al = eng.encoder(big)
     assert torch.equal(z, res[4][2][0]) and torch.equal(al, res[4][2][1])
 

@@ -12,10 +12,10 @@ echo bench-done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o run -- python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
 echo trace-done
 # counters: headline path only (no column-sharing / mixed-precision passes, whose launches share symbols and grids with it),
-# frequency LSTM in its hardware-dispatched, one-workgroup-per-CU form 6 (one workgroup per tile: the grid size tells pmc_summary.py the frame count;
+# frequency LSTM in its hardware-dispatched form 8 (freq_lstm_v3_kernel, one workgroup per tile: the grid size tells pmc_summary.py the frame count;
 # the bytes moved are the same in all four launch forms)
 for C in MfmaUtil FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o run -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-mixed-precision --no-column-sharing --opt freq_lstm_shape=6 "$@" > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err
+  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o run -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-mixed-precision --no-column-sharing --opt freq_lstm_shape=8 "$@" > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err
   echo pmc-$C-done
 done
 mkdir -p $OUT/pmc

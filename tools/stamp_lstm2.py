@@ -9,6 +9,9 @@ from sdfa_amd import synth
 from sdfa_amd.engine import Engine
 lib = C.CDLL(os.environ["SDFA_HIP_LIB"])
 lib.sdfa_debug_read_lstm_stamps.argtypes = [C.c_void_p, C.c_int]
+from sdfa_amd import _lib
+if os.environ.get("SDFA_FORM"):
+    _lib.set_option("freq_lstm_shape", int(os.environ["SDFA_FORM"]))      # e.g. SDFA_FORM=8: freq_lstm_v3_kernel (no barrier-1 / sub-phase stamps there)
 eng = Engine(synth.make_state_dict("dgrad", 1234), max_frames=8192)
 x = torch.rand((8192, 64, 128, 3), device="cuda")
 out = (C.c_ulonglong * 8)()
