@@ -1,4 +1,4 @@
-"""Phase times of freq_lstm_v2_kernel from in-kernel s_memtime stamps (diagnostic build: make -C sdfa-2019_amd/csrc STAMPS=1).
+"""Phase times of freq_lstm_v2_kernel (or, with SDFA_FORM=8, freq_lstm_v3_kernel) from in-kernel s_memtime stamps (diagnostic build: make -C sdfa-2019_amd/csrc STAMPS=1).
 SDFA_LONE=1 in the environment launches one workgroup per CU (no partner on the SIMDs): what a step costs by itself."""
 import ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,7 +32,7 @@ for rep in range(2):
 lib.sdfa_debug_read_lstm_stamps(out, 0)
 v = [int(o) for o in out]
 n = v[6]
-print(f"freq_lstm_v2_kernel ({'ONE workgroup per CU' if os.environ.get('SDFA_LONE') else 'two workgroups per CU'}): launch {ms:.2f} ms; per step (steps 1..31) and wave, shader cycles; 768 MFMAs alone = 49,152")
+print(f"frequency LSTM, form {os.environ.get('SDFA_FORM', '3')} ({'ONE workgroup per CU' if os.environ.get('SDFA_LONE') else 'two workgroups per CU'}): launch {ms:.2f} ms; per step (steps 1..31) and wave, shader cycles; 768 MFMAs alone = 49,152")
 for name, val in zip(("accumulator init + first operand reads", "K loop (24 k-blocks)", "barrier 1 (all waves done with K loop)", "x DMA + cell update + stores", "barrier 2 (h, x in LDS)"), v[:5]):
     print(f"  {name:44s} {val / n:9.0f}")
 print(f"  total {sum(v[:5]) / n:9.0f}")
