@@ -936,7 +936,7 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
 // PCA expansion of N frames' coefficients (K4, 288 / 64 rows): out[n][o] = sum_k coef[k][n] * basis[k][o] + means[o]
 // (rows = frames), stored to every destination.  PcaInversion.forward, speech_anime/modules/output_module.py:94-116
 static hipError_t expand_rows(const sdfa_model *m, const float *coef, int64_t N, int64_t Nc, int64_t f0,
-                              float *const *h_d_outs, int n_outs, hipStream_t s) {
+                              float *const *h_d_outs, int n_outs, int *queue, hipStream_t s) {
     float *d_out = h_d_outs[0];
     if (m->pca_n == 2 && !g_sdfa_pca_unfused) {
         // dgrad head: both bases in one fp32 kernel (all precision modes) so that every output line is written
@@ -947,6 +947,9 @@ static hipError_t expand_rows(const sdfa_model *m, const float *coef, int64_t N,
         pa.n_extra = n_outs - 1;
         for (int x = 1; x < n_outs; ++x) pa.out_extra[x - 1] = h_d_outs[x] + f0 * m->out_dim;
         pa.ld_s = m->pca_ld[0]; pa.ld_r = m->pca_ld[1]; pa.cols_s = m->pca_cols[0]; pa.cols_r = m->pca_cols[1];
+        // default: basis slab resident in LDS, persistent work units (pca_dgrad_res_kernel); "pca_lds" option 4 = the register-
+        // direct form of rounds 1-2, 1 = the slab staged through LDS per k-block stage (both bit-identical, slower)
+        if ((g_sdfa_pca_lds == 0 || g_sdfa_pca_lds == 3) && queue) return sdfa_launch_pca_dgrad_res(pa, queue, s);
         return sdfa_launch_pca_dgrad(pa, s);
     }
     for (int b = 0; b < m->pca_n; ++b) {
@@ -1027,7 +1030,7 @@ int sdfa_regress_forward_multi(const sdfa_model *m, const float *d_z, const int6
         pf.end();
         if (d_out) {
             pf.begin("pca");
-            HIP_TRY(expand_rows(m, coef, N, Nc, f0, h_d_outs, n_outs, s));
+            HIP_TRY(expand_rows(m, coef, N, Nc, f0, h_d_outs, n_outs, reinterpret_cast<int *>(ws + w.CT) + 1, s));
             pf.end();
         }
     }
@@ -1061,7 +1064,7 @@ int sdfa_expand_coef(const sdfa_model *m, const float *d_coef, int64_t n_frames,
             HIP_TRY(sdfa_launch_rows_seg_to_k4(src, m->coef_dim, N, 0, SDFA_COEF_OFFSETS, coef, Nc, 0, 64, s));
         }
         float *outs[1] = {d_out};
-        HIP_TRY(expand_rows(m, coef, N, Nc, f0, outs, 1, s));
+        HIP_TRY(expand_rows(m, coef, N, Nc, f0, outs, 1, reinterpret_cast<int *>(ws + w.CT) + 1, s));
         pf.end();
     }
     return SDFA_OK;

@@ -54,6 +54,7 @@ struct PcaArgs {
     int n_extra;
 };
 hipError_t sdfa_launch_pca_dgrad(const PcaArgs &a, hipStream_t s);
+hipError_t sdfa_launch_pca_dgrad_res(const PcaArgs &a, int *queue, hipStream_t s);   // basis slab resident in LDS, persistent; queue: one int of workspace
 
 // ---- front end -----------------------------------------------------------------------------
 struct FrontendConsts {      // device pointers, built once per sample rate

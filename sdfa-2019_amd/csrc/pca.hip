@@ -171,15 +171,235 @@ __global__ __launch_bounds__(256, 2) void pca_dgrad_kernel(PcaArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Third form (round 2, after DESIGN.md section 4.2): ONE workgroup per CU, one wave per SIMD, and the basis slab of a
+// triangle block RESIDENT in LDS.  The expansion is a product of a tall matrix (frames x 265 coefficients) with a wide one
+// whose column block for 32 triangles is only 147 KiB: a persistent workgroup loads that block ONCE per work unit
+// (triangle block x 4-16 frame blocks, taken from a queue), after which its four waves run independently -- no barrier, no
+// staging -- through the unit's tiles: B operands from LDS one k-block ahead (1 read per 4 MFMAs, in the MFMAs' shadow),
+// the coefficient quads of a tile requested a whole part ahead (the rotat part's 24 during the scale part, the next tile's
+// scale part's 12 during the rotat part), so nothing in the K loops waits for memory.  The register-direct form above has
+// every wave fetch the slab itself through L1 for every tile and, alone on a CU, spends 174 k cycles per tile for 37 k of
+// MFMAs (two k-blocks of lookahead against an L2 round trip per k-block).  The epilogue transposes two frames at a time
+// (16 passes; the slab leaves 9 KiB of LDS).  Same k order per accumulator: bit-identical.
+// ------------------------------------------------------------------------------------------------
+constexpr int PR_KS = 11, PR_KR = 23;            // k-blocks that hold real coefficients (85 -> 88, 180 -> 184 of the padded 96 / 192)
+constexpr int PR_RS = 2 * PR_KS, PR_RR = 2 * PR_KR;   // their k-quad rows
+
+__global__ __launch_bounds__(256, 1) void pca_dgrad_res_kernel(PcaArgs a, int *queue, int fbu) {      // fbu: frame blocks (of 128 frames) per work unit
+    // Only the k-quad rows that hold real coefficients are kept: 85 scale coefficients = rows 0..21 (k-blocks 0..10; k-block 11
+    // of the padded K = 96 is all zeros and is skipped -- adding exact zeros changes nothing), 180 rotat coefficients = rows
+    // 0..45 (k-blocks 0..22 of 24).  That leaves room for TWO row pairs per wave, so a pass's LDS writes do not wait for the
+    // previous pass's reads.
+    extern __shared__ float4 sRes[];                       // [PR_RS][192] scale basis | [PR_RR][96] rotat basis | 4 x 2 x 2 x PCA_ROW floats | queue slot
+    float4 *sBs = sRes, *sBr = sRes + PR_RS * 192;
+    float *sOutAll = reinterpret_cast<float *>(sRes + PR_RS * 192 + PR_RR * 96);
+    int *sUnit = reinterpret_cast<int *>(sOutAll + 4 * 4 * PCA_ROW);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    float *sRow2 = sOutAll + wave * 4 * PCA_ROW;          // two row pairs, alternating by pass
+    const int64_t nfb = a.Nc / 128;
+    const int nfu = (int)((nfb + fbu - 1) / fbu);          // units per triangle block
+    const int ntb = (int)((a.cols_r + 95) / 96);
+    const int n_units = ntb * nfu;
+    const float4 *__restrict__ coef = reinterpret_cast<const float4 *>(a.coef);   // K4 [72][Nc]: k-quads 0..23 scale, 24..71 rotat
+
+    // per-lane constants of the epilogue: position of this lane's column of tile t inside the 288-float row segment, and the
+    // (row, float4) this lane moves in each of the three read-back / store rounds of a pass (2 rows x 72 float4 = 144)
+    int opos[9];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) { const int ql = 32 * t + l31; opos[t] = (ql / 6) * 9 + ql % 6; }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { const int ql = 32 * t + l31; opos[6 + t] = (ql / 3) * 9 + 6 + ql % 3; }
+
+    // read-back / store round i of a pass: lane moves float4 c4 of row r (2 rows x 72 float4 = 144 = 2.25 x 64 lanes)
+    unsigned rd_off[3], st_off[3];
+    int st_r[3];
+    bool st_ok[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int idx = i * 64 + lane, r = idx / 72, c4 = idx % 72;
+        st_r[i] = r;
+        rd_off[i] = (unsigned)((r * PCA_ROW + 4 * c4) * 4);
+        st_off[i] = (unsigned)((4 * r * a.out_dim + 4 * c4) * 4);
+        st_ok[i] = idx < 144;
+    }
+
+    for (;;) {
+        if (tid == 0) *sUnit = atomicAdd(queue, 1);
+        __syncthreads();                                   // (also: every wave is done with the previous unit's slab)
+        const int u = __builtin_amdgcn_readfirstlane(*sUnit);
+        if (u >= n_units) break;                           // queue empty: every workgroup gets here
+        const int tb = u / nfu, fu = u % nfu;
+        // the slab: 22 x 192 + 46 x 96 float4 = 135 KiB, HBM/L2 -> LDS by LDS-DMA in 1 KiB pieces (dense rows: a request costs
+        // ~40-100 cycles here; through registers, with a division per element, the load took 50 k cycles per unit): scale rows
+        // are three pieces, rotat rows one and a half (lanes 0..31 of the second)
+        {
+            const float4 *bs = reinterpret_cast<const float4 *>(a.basis_s) + (int64_t)tb * 192 + lane;
+            const float4 *br = reinterpret_cast<const float4 *>(a.basis_r) + (int64_t)tb * 96 + lane;
+            for (int c = wave; c < PR_RS * 3; c += 4) {
+                const int row = c / 3, part = c - 3 * row;
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(bs + (int64_t)row * a.ld_s + part * 64),
+                                                 (void __attribute__((address_space(3))) *)(sBs + row * 192 + part * 64), 16, 0, 0);
+            }
+            for (int c = wave; c < PR_RR * 2; c += 4) {
+                const int row = c >> 1, part = c & 1;
+                if (part == 0 || lane < 32)
+                    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(br + (int64_t)row * a.ld_r + part * 64),
+                                                     (void __attribute__((address_space(3))) *)(sBr + row * 96 + part * 64), 16, 0, 0);
+            }
+        }
+        float mean[9];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) { const int64_t q = (int64_t)tb * 192 + 32 * t + l31; mean[t] = q < a.cols_s ? a.mean_s[q] : 0.f; }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { const int64_t q = (int64_t)tb * 96 + 32 * t + l31; mean[6 + t] = q < a.cols_r ? a.mean_r[q] : 0.f; }
+        __builtin_amdgcn_s_waitcnt(0x0070);                // this wave's DMA pieces have landed (explicit vmcnt(0): see gemm_fat_kernel) ...
+        __syncthreads();                                   // ... and everyone's: slab complete
+
+        const int64_t fb0 = (int64_t)fu * fbu, fb1 = fb0 + fbu < nfb ? fb0 + fbu : nfb;
+        const int64_t ocol0 = (int64_t)tb * 288, orow_valid = a.out_dim - ocol0;      // floats of this triangle block that exist (216 in the last one)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) st_ok[i] = (i * 64 + lane) < 144 && 4 * ((i * 64 + lane) % 72) < orow_valid;
+        // coefficient quads of this lane's frame: sa = scale part (12 k-blocks), ra = rotat part (24)
+        float4 sa[12], ra[12], rb[12];     // 12 quads each: at most two of the three sets are live at a time
+#define PR_LOAD(A, fb, kq0) { const float4 *cp = coef + (int64_t)(kq0) * a.Nc + (fb) * 128 + wave * 32 + l31; _Pragma("unroll") for (int kb = 0; kb < 12; ++kb) A[kb] = cp[(int64_t)(2 * kb + h) * a.Nc]; }
+#define PR_LOAD_S(fb) PR_LOAD(sa, fb, 0)
+        PR_LOAD_S(fb0)
+        for (int64_t fb = fb0; fb < fb1; ++fb) {
+            const int64_t frame0 = fb * 128 + wave * 32;
+            f32x16 accs[1][6], accr[1][3];
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accs[0][t][r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accr[0][t][r] = 0.f;
+            PR_LOAD(ra, fb, 24)                            // first half of the rotat part: lands during the scale part (18 k cycles of MFMAs)
+            {   // scale part: 11 k-blocks x 24 MFMAs, B operands one k-block ahead in two alternating sets
+                float4 b0[6], b1[6];
+#define PR_BS(kb, B) _Pragma("unroll") for (int t = 0; t < 6; ++t) B[t] = sBs[(2 * (kb) + h) * 192 + 32 * t + l31];
+                PR_BS(0, b0)
+#pragma unroll
+                for (int kb = 0; kb < PR_KS; kb += 2) {
+                    if (kb + 1 < PR_KS) { PR_BS(kb + 1, b1) }
+                    __builtin_amdgcn_sched_barrier(0);
+                    { const float4 a1[1] = {sa[kb]}; mfma_block<1, 6>(accs, a1, b0); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kb + 2 < PR_KS) { PR_BS(kb + 2, b0) }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kb + 1 < PR_KS) { const float4 a1[1] = {sa[kb + 1]}; mfma_block<1, 6>(accs, a1, b1); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#undef PR_BS
+            }
+            PR_LOAD(rb, fb, 48)                            // second half of the rotat part: lands during its first half (9 k cycles)
+            {   // rotat part: 23 k-blocks x 12 MFMAs
+                float4 b0[3], b1[3];
+#define PR_BR(kb, B) _Pragma("unroll") for (int t = 0; t < 3; ++t) B[t] = sBr[(2 * (kb) + h) * 96 + 32 * t + l31];
+                PR_BR(0, b0)
+#pragma unroll
+                for (int kb = 0; kb < PR_KR; kb += 2) {
+                    if (kb == 12 && fb + 1 < fb1) { PR_LOAD_S(fb + 1) }      // the next tile's scale part: lands during the second half
+                    if (kb + 1 < PR_KR) { PR_BR(kb + 1, b1) }
+                    __builtin_amdgcn_sched_barrier(0);
+                    { const float4 a1[1] = {kb < 12 ? ra[kb] : rb[kb - 12]}; mfma_block<1, 3>(accr, a1, b0); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kb + 2 < PR_KR) { PR_BR(kb + 2, b0) }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kb + 1 < PR_KR) { const float4 a1[1] = {kb + 1 < 12 ? ra[kb + 1] : rb[kb + 1 - 12]}; mfma_block<1, 3>(accr, a1, b1); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#undef PR_BR
+            }
+#ifdef SDFA_PR_NOEPI   /* timing experiment only: how long do the K loops alone take? */
+            if (accs[0][0][0] + accr[0][0][0] != 123.456f) continue;
+#endif
+            if (frame0 >= a.N) continue;                   // a wave of padding frames (its MFMAs ran on zeros; nothing to store)
+            // epilogue: 16 passes of two frames (accumulator rows 8g + 4h + e): transpose through LDS, whole-row 16-byte stores,
+            // software-pipelined -- pass p's LDS writes (row pair p & 1) are issued while pass p-1's read-back (other pair) is in
+            // flight; ONE fence per pass covers both, then pass p-1 is stored and pass p read back.
+#define PR_WRITE(p)                                                                                              \
+            {                                                                                                    \
+                float *sRow = sRow2 + ((p) & 1) * 2 * PCA_ROW;                                                   \
+                _Pragma("unroll") for (int t = 0; t < 6; ++t) sRow[h * PCA_ROW + opos[t]] = accs[0][t][p] + mean[t];          \
+                _Pragma("unroll") for (int t = 0; t < 3; ++t) sRow[h * PCA_ROW + opos[6 + t]] = accr[0][t][p] + mean[6 + t];  \
+            }
+#define PR_READ1(p, i, RV) RV = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sRow2 + ((p) & 1) * 2 * PCA_ROW) + rd_off[i]);
+#define PR_READ(p) PR_READ1(p, 0, rv0) PR_READ1(p, 1, rv1) PR_READ1(p, 2, rv2)
+#define PR_STORE1(i, RV)                                                                                         \
+                if (st_ok[i] && nrow + 4 * st_r[i] < a.N) {                                                      \
+                    *reinterpret_cast<float4 *>(reinterpret_cast<char *>(a.out) + sbase + st_off[i]) = RV;       \
+                    for (int x = 0; x < a.n_extra; ++x) *reinterpret_cast<float4 *>(reinterpret_cast<char *>(a.out_extra[x]) + sbase + st_off[i]) = RV;   /* peers' gathered buffers */ \
+                }
+#define PR_STORE(p)                                                                                              \
+            {   /* accumulator register p = 4g + e holds frame rows 8g + 4h' + e */                             \
+                const int64_t nrow = frame0 + 8 * ((p) >> 2) + ((p) & 3);                                        \
+                const int64_t sbase = (nrow * a.out_dim + ocol0) * 4;     /* uniform part of the address: scalar registers */ \
+                if (plain) {          /* whole tile, one destination: no predicates, no destination loop */     \
+                    *reinterpret_cast<float4 *>(reinterpret_cast<char *>(a.out) + sbase + st_off[0]) = rv0;      \
+                    *reinterpret_cast<float4 *>(reinterpret_cast<char *>(a.out) + sbase + st_off[1]) = rv1;      \
+                    if (lane < 16) *reinterpret_cast<float4 *>(reinterpret_cast<char *>(a.out) + sbase + st_off[2]) = rv2; \
+                } else {                                                                                         \
+                    PR_STORE1(0, rv0) PR_STORE1(1, rv1) PR_STORE1(2, rv2)                                        \
+                }                                                                                                \
+            }
+            float4 rv0, rv1, rv2;      // (named: an array indexed inside the destination loop ends up in scratch memory)
+            const bool plain = frame0 + 32 <= a.N && orow_valid >= 288 && a.n_extra == 0;      // uniform
+            PR_WRITE(0)
+            WAVE_LDS_FENCE()
+            PR_READ(0)
+#pragma unroll
+            for (int p = 1; p < 16; ++p) {
+                PR_WRITE(p)
+                WAVE_LDS_FENCE()       // pass p's writes done AND pass p-1's read-back arrived
+                PR_STORE(p - 1)
+                PR_READ(p)
+            }
+            WAVE_LDS_FENCE()           // (also orders the last read-back before the next tile's first writes)
+            PR_STORE(15)
+#undef PR_WRITE
+#undef PR_READ
+#undef PR_READ1
+#undef PR_STORE
+#undef PR_STORE1
+        }
+#undef PR_LOAD_S
+#undef PR_LOAD
+    }
+}
+
 }  // namespace
 
-extern thread_local int g_sdfa_pca_lds;   // api.cpp ("pca_lds" option): 1 = basis staged through LDS
+extern thread_local int g_sdfa_pca_lds;   // api.cpp ("pca_lds" option): 0 / 3 = pca_dgrad_res_kernel (api.cpp picks it), 4 = register-direct, 1 = basis staged through LDS
+
+hipError_t sdfa_launch_pca_dgrad_res(const PcaArgs &a, int *queue, hipStream_t s) {
+    const int64_t ntb = (a.cols_r + 95) / 96;
+    if (a.Nc % 128 || a.ld_s < ntb * 192 || a.ld_r < ntb * 96 || a.cols_s != 2 * a.cols_r || !queue) return hipErrorInvalidValue;
+    const size_t lds = (PR_RS * 192 + PR_RR * 96) * sizeof(float4) + 4 * 4 * PCA_ROW * sizeof(float) + 16;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pca_dgrad_res_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(queue, 0, sizeof(int), s);
+    if (e != hipSuccess) return e;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    // work unit = one triangle block x `fbu` frame blocks: the slab is loaded once per unit, so large units are cheaper, but the
+    // queue should still hold several units per CU for balance
+    const int64_t nfb = a.Nc / 128;
+    const int fbu = ntb * ((nfb + 15) / 16) >= 4 * cus ? 16 : (ntb * ((nfb + 7) / 8) >= 4 * cus ? 8 : 4);
+    const int64_t units = ntb * ((nfb + fbu - 1) / fbu);
+    hipLaunchKernelGGL(pca_dgrad_res_kernel, dim3((unsigned)(units < cus ? units : cus)), dim3(256), lds, s, a, queue, fbu);
+    return hipGetLastError();
+}
 
 hipError_t sdfa_launch_pca_dgrad(const PcaArgs &a, hipStream_t s) {
     // 32 triangles per workgroup: 192 scale columns + 96 rotat columns; the padded leading dimensions must cover whole blocks
     const int64_t ntb = (a.cols_r + 95) / 96;
     if (a.Nc % 128 || a.ld_s < ntb * 192 || a.ld_r < ntb * 96 || a.cols_s != 2 * a.cols_r) return hipErrorInvalidValue;
-    if (g_sdfa_pca_lds) hipLaunchKernelGGL(pca_dgrad_kernel<true>, dim3((unsigned)(ntb * (a.Nc / 128))), dim3(256), 0, s, a);
+    if (g_sdfa_pca_lds == 1) hipLaunchKernelGGL(pca_dgrad_kernel<true>, dim3((unsigned)(ntb * (a.Nc / 128))), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(pca_dgrad_kernel<false>, dim3((unsigned)(ntb * (a.Nc / 128))), dim3(256), 0, s, a);
     return hipGetLastError();
 }

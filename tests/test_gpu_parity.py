@@ -284,22 +284,27 @@ def test_fused_conv_stack_is_bitwise_the_two_kernel_path(eng, synth_sd, golden):
 
 
 def test_pca_basis_through_lds_is_bitwise_identical(synth_sd):
-    """pca_dgrad_kernel<true> (basis slab staged through LDS once per workgroup) vs <false> (every wave fetches it): same k
-    order per accumulator -> identical dgrad rows, on a ragged batch (partial frame block, early-exit waves)."""
+    """The three forms of the dgrad PCA expansion -- pca_dgrad_res_kernel (default: basis slab resident in LDS, persistent work
+    units, padded k-blocks skipped), pca_dgrad_kernel<false> (every wave fetches the slab itself) and <true> (staged through LDS)
+    -- contract k in the same order per accumulator: identical dgrad rows, on ragged batches (partial frame blocks, early-exit
+    waves, several units per workgroup)."""
     from sdfa_amd import _lib
-    eng = Engine(synth_sd["dgrad"], max_frames=512)
+    eng = Engine(synth_sd["dgrad"], max_frames=2048)
     rs = np.random.RandomState(21)
-    for n in (1, 130, 700):
+    for n in (1, 130, 700, 1500):
         z = _t(rs.normal(0, 1, (n, 512)).astype(np.float32))
         spk = torch.from_numpy(rs.randint(0, 8, n))
         try:
-            _lib.set_option("pca_lds", 0)
+            _lib.set_option("pca_lds", 4)      # register-direct (rounds 1-2)
             _, a = eng.regress(z, spk)
-            _lib.set_option("pca_lds", 1)
+            _lib.set_option("pca_lds", 1)      # slab staged through LDS per stage
             _, b = eng.regress(z, spk)
+            _lib.set_option("pca_lds", 0)      # default: slab resident in LDS, persistent work units (pca_dgrad_res_kernel)
+            _, c = eng.regress(z, spk)
         finally:
             _lib.set_option("pca_lds", 0)
         assert torch.equal(a, b), n
+        assert torch.equal(a, c), n
 
 
 @pytest.mark.parametrize("head", ["dgrad", "offsets"])
