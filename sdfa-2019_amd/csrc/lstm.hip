@@ -941,28 +941,47 @@ __global__ __launch_bounds__(512, 2) void time_lstm_kernel(TimeLstmArgs a) {
 
         if (s > 0) {
             float4 wa0 = wn0, wa1 = wn1, wa2 = wn2, wa3 = wn3, wb0, wb1, wb2, wb3, ba[NT], bb[NT];
-#define TL_BLOAD(kb, B) _Pragma("unroll") for (int j = 0; j < NT; ++j) B[j] = sHc[(2 * (kb) + h) * BT + j * 32 + l31];
-#define TL_ROW(gt, Wg, B) _Pragma("unroll") for (int j = 0; j < NT; ++j) acc[gt][j] = MFMA(SDFA_OP(f4c(Wg, q)), SDFA_OP(f4c(B[j], q)), acc[gt][j]);
-            // component-major, weight operands by name (an array of them is built by copying); h operands one k-block ahead too
-#define TL_MFMA(W0, W1, W2, W3, B) _Pragma("unroll") for (int q = 0; q < 4; ++q) { TL_ROW(0, W0, B) TL_ROW(1, W1, B) TL_ROW(2, W2, B) TL_ROW(3, W3, B) }
-            TL_BLOAD(0, ba)
+            // K loop in trips of 8 k-blocks with immediate offsets, the memory instructions that refill the other operand set
+            // one or two at a time in front of the four MFMA groups of a k-block (freq_lstm_v3_kernel)
+#define TL_SB() __builtin_amdgcn_sched_barrier(0);
+#define TL_Q(W0, W1, W2, W3, B, q)                                                                               \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) acc[0][j] = MFMA(SDFA_OP(f4c(W0, q)), SDFA_OP(f4c(B[j], q)), acc[0][j]); \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) acc[1][j] = MFMA(SDFA_OP(f4c(W1, q)), SDFA_OP(f4c(B[j], q)), acc[1][j]); \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) acc[2][j] = MFMA(SDFA_OP(f4c(W2, q)), SDFA_OP(f4c(B[j], q)), acc[2][j]); \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) acc[3][j] = MFMA(SDFA_OP(f4c(W3, q)), SDFA_OP(f4c(B[j], q)), acc[3][j]);
+#define TL_KB(CW0, CW1, CW2, CW3, CB, NW0, NW1, NW2, NW3, NB, so, bp)                                            \
+    {                                                                                                            \
+        TL_SB() NW0 = TL_W1(so, 0); NW1 = TL_W1(so, 1); TL_SB()                                                  \
+        TL_Q(CW0, CW1, CW2, CW3, CB, 0)                                                                          \
+        TL_SB() NW2 = TL_W1(so, 2); NW3 = TL_W1(so, 3); TL_SB()                                                  \
+        TL_Q(CW0, CW1, CW2, CW3, CB, 1)                                                                          \
+        TL_SB() NB[0] = (bp)[0]; TL_SB()                                                                         \
+        TL_Q(CW0, CW1, CW2, CW3, CB, 2)                                                                          \
+        TL_SB() if (NT > 1) NB[NT - 1] = (bp)[32 * (NT - 1)]; TL_SB()                                            \
+        TL_Q(CW0, CW1, CW2, CW3, CB, 3)                                                                          \
+    }
+            const float4 *brow = sHc + h * BT + l31;          // row pair of k-block kb: brow + kb * 2 * BT
+#pragma unroll
+            for (int j = 0; j < NT; ++j) ba[j] = brow[j * 32];
 #pragma unroll 1
-            for (int kb = 0; kb < 32; kb += 2) {
-                TL_LOAD(kb + 1, wb0, wb1, wb2, wb3)
-                TL_BLOAD(kb + 1, bb)
-                __builtin_amdgcn_sched_barrier(0);
-                TL_MFMA(wa0, wa1, wa2, wa3, ba)
-                __builtin_amdgcn_sched_barrier(0);
-                const int kn = kb + 2 < 32 ? kb + 2 : 0;
-                TL_LOAD(kn, wa0, wa1, wa2, wa3)
-                TL_BLOAD(kn, ba)
-                __builtin_amdgcn_sched_barrier(0);
-                TL_MFMA(wb0, wb1, wb2, wb3, bb)
-                __builtin_amdgcn_sched_barrier(0);
+            for (int t = 0; t < 4; ++t) {
+                const float4 *bt = brow + t * 16 * BT;
+                const float4 *bn = t + 1 < 4 ? bt + 16 * BT : brow;         // behind the last trip: k-block 0 again (dropped) ...
+                const unsigned so = (unsigned)t * (8 * 2048 * 16);
+                const unsigned son = t + 1 < 4 ? so + 8 * 2048 * 16 : 0u;   // ... whose weights ARE k-block 0 of the next step
+                TL_KB(wa0, wa1, wa2, wa3, ba, wb0, wb1, wb2, wb3, bb, so + 1 * 2048 * 16, bt + 1 * 2 * BT)
+                TL_KB(wb0, wb1, wb2, wb3, bb, wa0, wa1, wa2, wa3, ba, so + 2 * 2048 * 16, bt + 2 * 2 * BT)
+                TL_KB(wa0, wa1, wa2, wa3, ba, wb0, wb1, wb2, wb3, bb, so + 3 * 2048 * 16, bt + 3 * 2 * BT)
+                TL_KB(wb0, wb1, wb2, wb3, bb, wa0, wa1, wa2, wa3, ba, so + 4 * 2048 * 16, bt + 4 * 2 * BT)
+                TL_KB(wa0, wa1, wa2, wa3, ba, wb0, wb1, wb2, wb3, bb, so + 5 * 2048 * 16, bt + 5 * 2 * BT)
+                TL_KB(wb0, wb1, wb2, wb3, bb, wa0, wa1, wa2, wa3, ba, so + 6 * 2048 * 16, bt + 6 * 2 * BT)
+                TL_KB(wa0, wa1, wa2, wa3, ba, wb0, wb1, wb2, wb3, bb, so + 7 * 2048 * 16, bt + 7 * 2 * BT)
+                TL_KB(wb0, wb1, wb2, wb3, bb, wa0, wa1, wa2, wa3, ba, son, bn)
             }
-#undef TL_MFMA
-#undef TL_ROW
-#undef TL_BLOAD
+            TL_SB()
+#undef TL_KB
+#undef TL_Q
+#undef TL_SB
             wn0 = wa0; wn1 = wa1; wn2 = wa2; wn3 = wa3;      // k-block 0 again: the next step's first operands
         }
 #pragma unroll
