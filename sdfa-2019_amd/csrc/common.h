@@ -90,7 +90,9 @@ __device__ __forceinline__ double dsub_exact(double a, double b) {
     return a - b;
 }
 
-__device__ __forceinline__ float lrelu02(float x) { return x >= 0.f ? x : 0.2f * x; }
+// max(x, 0.2 x) == (x >= 0 ? x : 0.2 x) for every finite x and both zeros; two vector instructions instead of three (compare,
+// multiply, select) -- vector instructions are matrix-pipe time on this chip
+__device__ __forceinline__ float lrelu02(float x) { return __builtin_fmaxf(x, 0.2f * x); }
 
 // v_exp_f32 / v_rcp_f32 based, branch-free (1-2 ulp each; absolute error ~1e-7, which is what the
 // 1e-4 dgrad tolerance needs -- gate values feed products, so absolute error is the one that matters)
