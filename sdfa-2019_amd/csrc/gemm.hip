@@ -1015,7 +1015,7 @@ extern "C" int sdfa_debug_read_stamps(unsigned long long *out, int reset) {
 }
 #endif
 
-thread_local int g_sdfa_gemm_variant = 0;   // 0 = LDS-tiled (default), 1/2 = register-direct (MT 4 / 2), 3 = LDS-tiled fed by LDS-DMA (all fp32, within 2 % of each other); 4 = split-bf16 x3 (opt-in, not exact fp32)
+thread_local int g_sdfa_gemm_variant = 0;   // 0 = default choice per shape (gemm_fat_kernel for the large projections, else LDS-tiled 128^2), 9 = the round-1/2 choice (no fat kernel), 8 = fat wherever it fits, 5 = 256^2 tile, 1/2 = register-direct (MT 4 / 2), 3 = LDS-tiled fed by LDS-DMA, 6 = producer/consumer (all fp32, bit-identical); 4 = split-bf16 x3 (opt-in, not exact fp32)
 
 template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
 hipError_t launch_any(const GemmArgs &a, hipStream_t s) {
@@ -1039,9 +1039,8 @@ hipError_t launch_any(const GemmArgs &a, hipStream_t s) {
                 return launch_fat<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
         }
     }
-    // 256 x 256 tile: on request (gemm_variant 5), and by default for the 8192-deep frequency projection, whose operand
-    // stream (2 MB of hidden states per frame) is what the 128 x 128 tile waits for (40.3 vs 41.7 ms); the L2-resident
-    // projections are faster on the small tile (two independent workgroups per CU)
+    // 256 x 256 tile, 8 waves: on request (gemm_variant 5), and in the round-1/2 choice (9) for the 8192-deep frequency projection,
+    // whose operand stream (2 MB of hidden states per frame) is what the 128 x 128 tile waits for (40.3 vs 41.7 ms)
     if ((g_sdfa_gemm_variant == 5 || (a.q_tile_major && (g_sdfa_gemm_variant == 0 || g_sdfa_gemm_variant == 9))) && a.Ppad % 256 == 0 && a.Qpad % 256 == 0)
         return launch_big<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
     if (a.q_tile_major) return launch<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);   // only the LDS-tiled kernels read that layout

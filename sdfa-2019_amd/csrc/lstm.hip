@@ -304,8 +304,9 @@ __global__ __launch_bounds__(256, WGS) void freq_lstm_kernel(FreqLstmArgs a) {
 // pairs from a queue head in the workspace until the queue is empty, instead of one hardware-dispatched workgroup per
 // pair.  Built because the stamps (tools/stamp_lstm2.py) show a CU slot empty 2.5-3 % of a launch between the end of one
 // 1.5 ms workgroup and the start of the next, plus +-2 % between XCDs under the static block-id -> XCD partition.
-// Bit-identical; measured 2.4-3.4 % SLOWER than hardware dispatch (48.3 -> 49.4 ms per 8192 frames), with or without an
-// initial phase offset between the two workgroups of a CU: kept as an option, not the default.
+// Bit-identical.  With the scalar cell update it measured 2.4-3.4 % SLOWER than hardware dispatch (48.3 -> 49.4 ms per 8192
+// frames), with the packed one 0.5 % faster (and hardware dispatch 2.5 % slower): how two starving partners interleave is
+// chaotic.  sdfa_model_autotune keeps both as fall-backs behind freq_lstm_v3_kernel.
 template <bool SHARED, bool PERSIST>
 __global__ __launch_bounds__(256, 2) void freq_lstm_v2_kernel(FreqLstmArgs a) {
     constexpr int NJ = 2, BT = 64;
