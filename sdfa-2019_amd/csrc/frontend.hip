@@ -343,8 +343,17 @@ __global__ __launch_bounds__(64 * MC_WAVES) void mel_columns_kernel(FrontendCons
     for (int64_t u = (int64_t)blockIdx.x * MC_WAVES + wave; u < nd; u += (int64_t)gridDim.x * MC_WAVES) {
         // (frame, window column) of this distinct column -> clip and absolute sample position
         const int row = col_src[u], n = row >> 6, t = row & 63, clip = frame_clip[n];
-        const float *x = pcm + clip_off[clip];
-        const int64_t len = clip_len[clip], p = frame_start[n] + (int64_t)t * HOP;
+        // The clip as a BUFFER: descriptor in scalar registers (a wave transforms one column, so the clip is wave-uniform) and the
+        // sample index as a 32-bit byte offset -- no 64-bit address arithmetic per request.  The zero padding on both sides of the
+        // clip stays explicit (index clamped for the request, value selected afterwards, all in 32-bit arithmetic: |index| < 2^29):
+        // the hardware's range check cannot do it -- an index in front of the clip wraps to a huge offset that is NOT refused,
+        // and the compiler merges neighbouring requests into 8-byte ones that are judged as a whole at the clip's end.
+        const int64_t len64 = clip_len[clip], p = frame_start[n] + (int64_t)t * HOP;
+        const int len = (int)(len64 > 0x1fffffff ? 0x1fffffff : len64);
+        const unsigned long long xb = (unsigned long long)(pcm + clip_off[clip]);
+        const unsigned long long xuni = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(xb >> 32)) << 32) |
+                                        (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xb);
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)xuni, 0, __builtin_amdgcn_readfirstlane(len * 4), 0x00020000);
         const bool raw0 = t == 0;                 // a window's very first sample is not pre-emphasised (misc.py:17)
         float2 v[NR4][4];
 #pragma unroll
@@ -353,17 +362,16 @@ __global__ __launch_bounds__(64 * MC_WAVES) void mel_columns_kernel(FrontendCons
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = 2 * (j + r * (M / 4));                       // even sample of z[j + r M/4]
-                const int64_t g = p + i;
-                // zero-padded clip; pre-emphasis with one rounding per op (misc.py:8-17).  The three samples are requested
-                // UNCONDITIONALLY at clamped addresses and zeroed afterwards: a load behind a divergent condition compiles to
-                // branch + load + wait, which serialised the 24 requests of a column into ~10 memory round trips
-                const int64_t last = len - 1;
-                const float rm = x[g - 1 < 0 ? 0 : (g - 1 > last ? last : g - 1)];
-                const float r0 = x[g < 0 ? 0 : (g > last ? last : g)];
-                const float r1 = x[g + 1 < 0 ? 0 : (g + 1 > last ? last : g + 1)];
-                const float xm = (g - 1 >= 0 && g - 1 < len) ? rm : 0.f;
-                const float x0 = (g >= 0 && g < len) ? r0 : 0.f;
-                const float x1 = (g + 1 >= 0 && g + 1 < len) ? r1 : 0.f;
+                // samples g-1, g, g+1 (indices relative to the clip); pre-emphasis with one rounding per op (misc.py:8-17).  All
+                // requests are unconditional, at clamped indices: a load behind a divergent condition compiles to branch + load +
+                // wait, which serialised the requests of a column into ~10 memory round trips
+                const int g0 = (int)(p + i), last = len - 1;
+#define MC_REQ(idx) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (unsigned)((idx) < 0 ? 0 : ((idx) > last ? last : (idx))) * 4u, 0, 0))
+                const float rm = MC_REQ(g0 - 1), r0 = MC_REQ(g0), r1 = MC_REQ(g0 + 1);
+#undef MC_REQ
+                const float xm = (unsigned)(g0 - 1) < (unsigned)len ? rm : 0.f;
+                const float x0 = (unsigned)g0 < (unsigned)len ? r0 : 0.f;
+                const float x1 = (unsigned)(g0 + 1) < (unsigned)len ? r1 : 0.f;
                 const float y0 = (raw0 && i == 0) ? x0 : __fsub_rn(x0, __fmul_rn(0.65f, xm));
                 const float y1 = __fsub_rn(x1, __fmul_rn(0.65f, x0));
                 v[b][r] = make_float2(sHamm[i] * y0, sHamm[i + 1] * y1);
