@@ -25,6 +25,10 @@ import time
 
 import numpy as np
 
+# dmabuf IPC (the only kind this pool's driver supports) must be selected BEFORE anything initialises HSA: torch.cuda.set_device()
+# below already does, so this cannot wait until the process group is created (VERDICT r2 / ADVICE r2)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "sdfa-2019_amd"))
 
@@ -64,7 +68,15 @@ def parse():
     ap.add_argument("--precision", choices=["fp32", "bf16_attention", "bf16x3", "bf16"], default="fp32",
                     help="matrix instruction of the headline run (fp32 = the reference's arithmetic; the others are BASELINE configs[3] modes)")
     ap.add_argument("--no-mixed-precision", action="store_true", help="skip the extra split-bf16 (configs[3]) measurement")
-    ap.add_argument("--opt", action="append", default=[], help="library tuning switch name=value (A/B runs)")
+    ap.add_argument("--opt", action="append", default=[], help="library tuning switch name=value (A/B runs; sdfa_debug_set_option is THREAD-LOCAL: "
+                                                               "it applies to launches made from this, the main, thread)")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="with --gpus 1: create the process group anyway (world size 1) and run the chosen --gather mode through the real "
+                         "backend -- RCCL all_gather_into_tensor(async_op=True) per chunk + Work.wait() -- to rehearse the N > 1 exchange "
+                         "and its overlap with the persistent kernels on one GPU")
+    ap.add_argument("--reserve-cus", type=int, default=0, help="CUs the persistent kernels leave to other streams (sdfa_model_set_reserved_cus)")
+    ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive twin (H2D of PCM + D2H of the rows inside the step)")
+    ap.add_argument("--no-surface", action="store_true", help="skip the speech_anime surface block (generate_animation frames/s)")
     ap.add_argument("--cpu-sample-seconds", type=float, default=10.0)
     return ap.parse_args()
 
@@ -117,6 +129,63 @@ def cpu_baseline(sr, seconds, eng, state_dict, head):
                        f"(fastest of a scan), nproc = logical CPUs the host exposes"), gpu_err
 
 
+def surface_block(sd, head, sr, dev):
+    """speech_anime.model.SaberSpeechDrivenAnimation.generate_animation (speech_anime/model/model.py:333-420 + 428-489) timed as a
+    caller sees it: wall clock around the call, so frame enumeration, H2D of the PCM, every kernel, the device -> host copy of the
+    rows into pinned memory and the Python around them are all inside.  Three workloads: one 10 s clip and one 2 s clip per call
+    (BASELINE configs[0] is the 2 s case), and 32 x 10 s through generate_animation_batch (one launch group)."""
+    import torch
+    from sdfa_amd import synth
+    from speech_anime.hparams import configure
+    from speech_anime.api import build_model
+    from speech_anime.datasets import DatasetSlidingWindow
+    hp = configure(dict(mode="evaluate", custom_hparams=head))
+    hp.audio.set_key("sample_rate", sr)
+    hp.set_key("device", str(dev))
+    DatasetSlidingWindow.hparams = None
+    model = build_model(hp, sd)
+    eng = model._model._engine
+    out = {"note": "wall-clock frames/s of generate_animation / generate_animation_batch calls (host work, H2D, kernels, D2H of the "
+                   "rows to pinned host memory all included); speaker m1; others['inputs'] not requested unless stated"}
+
+    def run(fn, frames, reps, warm=2):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        dt = time.perf_counter() - t0
+        return {"frames_per_s": round(frames * reps / dt, 1), "ms_per_call": round(dt / reps * 1e3, 3), "frames_per_call": frames, "calls": reps}
+
+    STAGES = ("conv23", "freq_lstm", "freq_proj", "gx0", "lstm0", "gx1", "lstm1", "attn_proj", "attn", "mlp", "pca", "share_map", "share_expand")
+    for name, seconds, reps in (("1x10s", 10.0, 10), ("1x2s", 2.0, 20)):
+        pcm = synth.make_pcm(0, int(seconds * sr))
+        frames = len(model.generate_animation(pcm, "m1", 0, 0, want_inputs=False)[0])
+        r = run(lambda: model.generate_animation(pcm, "m1", 0, 0, want_inputs=False), frames, reps)
+        eng.profile(True)
+        model.generate_animation(pcm, "m1", 0, 0, want_inputs=False)
+        torch.cuda.synchronize()
+        st = {}
+        for k in STAGES:
+            try:
+                st[k] = round(eng.profile_ms(k), 3)
+            except Exception:
+                pass
+        eng.profile(False)
+        r["kernel_ms_per_call"] = round(sum(st.values()), 3)
+        r["stage_ms"] = st
+        out[name] = r
+        if name == "1x10s":
+            out["1x10s_with_inputs"] = run(lambda: model.generate_animation(pcm, "m1", 0, 0), frames, 5)
+            out["1x10s_ensembling_20ms"] = run(lambda: model.generate_animation(pcm, "m1", 0, 0, ensembling_ms=20, want_inputs=False), frames, 5)
+    clips = [synth.make_pcm(c, int(10.0 * sr)) for c in range(32)]
+    frames = sum(len(r[0]) for r in model.generate_animation_batch(clips, "m1"))
+    out["32x10s_batch"] = run(lambda: model.generate_animation_batch(clips, "m1"), frames, 3, warm=1)
+    del model
+    return out
+
+
 def traffic_from_profile(frames_per_launch):
     """HBM bytes per freq_lstm_kernel launch from the newest committed rocprofv3 PMC passes (profiles/r*_pmc/
     freq_lstm_traffic.json, written by profiles/pmc_summary.py: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE
@@ -148,12 +217,16 @@ def main():
     local_dev = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist_on = world > 1 or a.force_gather          # the exchange runs: N > 1, or the one-GPU rehearsal of it
+    if dist_on:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(a.backend)
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
 
     from sdfa_amd import _lib
     for kv in a.opt:
@@ -162,6 +235,8 @@ def main():
     sr = a.sample_rate
     sd = synth.make_state_dict(a.head, 1234)
     eng = Engine(sd, device=dev, max_frames=a.chunk, precision=a.precision, autotune=not any(kv.startswith("freq_lstm_shape=") for kv in a.opt))
+    if a.reserve_cus:
+        eng.set_reserved_cus(a.reserve_cus)
 
     # ---- this rank's clips: global clip ids [rank*C, (rank+1)*C), PCM resident in HBM before timing
     C = a.clips_per_gpu
@@ -182,10 +257,12 @@ def main():
     spk = torch.full((F,), 2, dtype=torch.int64, device=dev)          # speaker "m1"
     eng.check_speaker_ids(spk)                                         # once, outside the timed region (a host sync)
     feat = torch.empty((F, 64, 128, 3), dtype=torch.float32, device=dev)
-    all_counts = sdist.frame_counts_all(F) if (world > 1 and a.ragged_seconds) else [F] * world
+    all_counts = sdist.frame_counts_all(F) if (dist_on and a.ragged_seconds) else [F] * world
     F_all = int(sum(all_counts))
     if world == 1 and a.gather == "direct":
         raise SystemExit("--gather direct needs N > 1 (it replaces the all-gather)")
+    if a.force_gather and world == 1 and a.gather == "auto":
+        a.gather = "dgrad"
 
     class Mode:          # how the rows are reassembled: set once (or, for auto, after the two candidates were timed)
         kind = gatherer = direct = out = None
@@ -193,9 +270,9 @@ def main():
     def set_mode(kind):
         Mode.kind, Mode.gatherer, Mode.direct, Mode.out = kind, None, None, None
         torch.cuda.empty_cache()
-        if world > 1 and kind in ("dgrad", "coef"):
+        if dist_on and kind in ("dgrad", "coef"):
             Mode.gatherer = sdist.FrameGatherer(all_counts, eng.out_dim if kind == "dgrad" else eng.coef_dim, torch.float32, dev, a.chunk)
-        if world > 1 and kind == "expand":
+        if dist_on and kind == "expand":
             Mode.gatherer = sdist.ExpandGatherer(all_counts, eng, dev, a.chunk)
             Mode.out = Mode.gatherer.own(0, F)                          # own rows are written in place
         elif kind == "direct":
@@ -204,7 +281,9 @@ def main():
         else:
             Mode.out = torch.empty((F, eng.out_dim), dtype=torch.float32, device=dev)
 
-    set_mode(a.gather if (world > 1 and a.gather != "auto") else "dgrad")
+    set_mode(a.gather if (dist_on and a.gather not in ("auto", "none")) else "dgrad")
+    if a.gather == "none":
+        Mode.gatherer = None
 
     # ---- optional post-path stage: saber.stream.seek to the video rate fused into the dgrad -> mesh solve
     mesh = None
@@ -219,7 +298,7 @@ def main():
         plan = SeekPlan(tslists, 60.0, device=dev)
         verts = torch.empty((plan.n_queries, solver.n_verts, 3), dtype=torch.float32, device=dev)
         vgather = None
-        if world > 1 and a.gather == "mesh":
+        if dist_on and a.gather == "mesh":
             q_all = sdist.frame_counts_all(plan.n_queries)
             vgather = sdist.FrameGatherer(q_all, solver.n_verts * 3, torch.float32, dev, max(q_all))
         mesh = (solver, plan, verts, vgather)
@@ -227,6 +306,8 @@ def main():
     hop = int(0.008 * sr)
 
     def step(share=False):
+        if Mode.direct is not None:
+            Mode.direct.begin_step()                                     # two alternating gathered buffers (sdfa_amd/dist.py DirectGatherer)
         eng.mel_frontend_device(pcm, clip_off, clip_len, frame_clip, frame_start, sr, out=feat, gather=(a.frontend == "gather"))
         def compute(f0, f1):
             if share:
@@ -243,7 +324,7 @@ def main():
         sdist.run_chunks(F, a.chunk, Mode.gatherer, compute)
         if mesh is not None:
             solver, plan, verts, vgather = mesh
-            solver.get_mesh_seek(Mode.out, plan, out=verts)
+            solver.get_mesh_seek(Mode.out if Mode.direct is None else Mode.direct.dests[0], plan, out=verts)
             if vgather is not None:
                 vgather.gather_chunk(verts.view(plan.n_queries, -1), 0)
                 vgather.finish()
@@ -251,7 +332,7 @@ def main():
             Mode.direct.finish()
 
     def fence():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -269,7 +350,7 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        if world > 1:
+        if dist_on:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         # per-kernel device times: HIP events recorded by the library on the launch stream inside the timed region
         st = {k: eng.profile_ms(k) / a.steps for k in STAGES + (("share_map", "share_expand") if share else ())}
@@ -295,11 +376,13 @@ def main():
 
     dt, stages = timed(False)
     gather_check = None
-    if world > 1 and Mode.kind in ("dgrad", "expand", "direct"):
+    if dist_on and (Mode.gatherer is not None or Mode.direct is not None) and Mode.kind in ("dgrad", "expand", "direct"):
         # every rank holds every rank's rows: order-independent integer checksum (bit patterns summed in int64) of each rank's
         # own rows against the same rows as they arrived here
         def cks(t):
             return t.contiguous().view(torch.int32).sum(dtype=torch.int64)
+        if Mode.direct is not None:
+            Mode.out = Mode.direct.dests[0]                             # the buffer the last step wrote
         mine = cks(Mode.out).view(1)
         sums = [torch.empty(1, dtype=torch.int64, device=dev) for _ in range(world)]
         dist.all_gather(sums, mine)
@@ -323,6 +406,49 @@ def main():
         dt_ms = None if a.no_column_sharing else timed(True)[0]
         eng.set_precision("fp32")
         mixed = (dt_m, st_m, dt_ms)
+    # ---- PCIe-inclusive twin (SURVEY 8(d) "report both"): the same K steps with the PCM arriving from pinned host memory inside
+    # the step (H2D) and every output row delivered to pinned host memory inside the step (D2H, 359 KB per frame): pieces of
+    # `chunk` frames, piece i's copy on a copy stream under piece i+1's kernels (Engine.forward_host), two alternating host
+    # output buffers so that a step's last copy overlaps the next step's first piece.  Never `value`.
+    host_io = None
+    if world == 1 and not dist_on and not a.no_host_io and mesh is None:
+        Mode.out = None
+        torch.cuda.empty_cache()
+        pcm_host = pcm.cpu().pin_memory()
+        outs_host = [torch.empty((F, eng.out_dim), dtype=torch.float32, pin_memory=True) for _ in range(2)]
+        table = (frame_clip, frame_start, hop)
+
+        def step_host(k, share):
+            pcm.copy_(pcm_host, non_blocking=True)                       # H2D of this step's PCM (1 KB per frame)
+            eng.mel_frontend_device(pcm, clip_off, clip_len, frame_clip, frame_start, sr, out=feat, gather=(a.frontend == "gather"))
+            eng.forward_host(feat, spk, out=outs_host[k & 1], tables=table if share else None, piece=a.chunk, wait=False)
+
+        host_io = {}
+        for name, share in (("fp32", False),) + ((("fp32_column_sharing", True),) if not a.no_column_sharing else ()):
+            for k in range(max(1, a.warmup)):
+                step_host(k, share)
+            eng.host_wait(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(a.steps):
+                step_host(k, share)
+            eng.host_wait(); torch.cuda.synchronize()
+            host_io[name] = time.perf_counter() - t0
+        # the rows that reached the host are the rows the device-resident step wrote (checked on the last step's buffer)
+        Mode.out = torch.empty((F, eng.out_dim), dtype=torch.float32, device=dev)
+        step(False); torch.cuda.synchronize()
+        last = outs_host[(a.steps - 1) & 1]
+        host_io["rows_identical_to_device_path"] = bool(torch.equal(last[:4096], Mode.out[:4096].cpu()) and torch.equal(last[-512:], Mode.out[-512:].cpu()))
+        # raw link rate for reference: one D2H of a full output buffer, nothing else running
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); outs_host[0].copy_(Mode.out, non_blocking=True); e1.record(); torch.cuda.synchronize()
+        host_io["d2h_alone_gbps"] = F * eng.out_dim * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del outs_host, pcm_host
+
+    # ---- the speech_anime surface: what a caller of generate_animation sees, wall clock, host work + copies included
+    surface = None
+    if world == 1 and not dist_on and not a.no_surface and a.precision == "fp32":
+        surface = surface_block(sd, a.head, sr, dev)
+
     # front end: timed separately (same stream, HIP events), outside the headline region
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record(); eng.mel_frontend_device(pcm, clip_off, clip_len, frame_clip, frame_start, sr, out=feat, gather=(a.frontend == "gather")); ev1.record()
@@ -349,7 +475,9 @@ def main():
                                     f"stream of {C} sentences, {a.ragged_seconds} s@{sr} Hz synthetic PCM per GPU -> {a.head} (BASELINE configs[4] rehearsal)"),
                        "clips_per_gpu": C, "frames_per_gpu": F, "head": a.head, "chunk_frames": a.chunk,
                        "freq_lstm_form": eng.freq_lstm_form,      # picked by sdfa_model_autotune in the first warm-up step (bit-identical forms)
-                       "gather": Mode.kind if world > 1 else "none (1 GPU)",
+                       "gather": (Mode.kind if Mode.gatherer is not None or Mode.direct is not None else "none") if dist_on else "none (1 GPU)",
+                       "force_gather_world1": bool(a.force_gather and world == 1), "backend": a.backend if dist_on else None,
+                       "reserved_cus": a.reserve_cus,
                        "gather_auto_ms_per_step": None if auto is None else {k: round(v, 2) for k, v in auto.items()},
                        "gather_checksum_ok": gather_check, "weights": "synthetic seed 1234",
                        "mesh_stage": None if mesh is None else f"seek to 60 fps + mesh solve, {mesh[1].n_queries} video frames x {mesh[0].n_verts} vertices per GPU per step"},
@@ -364,6 +492,20 @@ def main():
                          "frac_of_hbm_peak": round(F * FRONTEND_BYTES_PER_FRAME / (fe_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)},
             "stage_ms_per_step": {k: round(v, 3) for k, v in stages.items()},
         }
+        res["peak_device_memory_gb"] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 2)
+        if host_io is not None:
+            tw = host_io["fp32"]
+            res["with_h2d_d2h"] = {
+                "note": "PCIe-inclusive twin of `value` (SURVEY 8(d) 'report both'): the same steps with the PCM copied host -> device and ALL "
+                        "output rows (359 KB per frame) copied device -> pinned host inside the timed region, the copies of one piece "
+                        "running on a copy stream under the next piece's kernels (Engine.forward_host).  NOT the headline.",
+                "value": round(F * a.steps / tw, 1), "unit": "frames/s", "ms_per_step": round(tw / a.steps * 1e3, 3),
+                "d2h_gb_per_step": round(F * eng.out_dim * 4 / 1e9, 3),
+                "d2h_alone_gbps": round(host_io["d2h_alone_gbps"], 1),
+                "rows_identical_to_device_path": host_io["rows_identical_to_device_path"],
+                "with_column_sharing": None if "fp32_column_sharing" not in host_io else round(F * a.steps / host_io["fp32_column_sharing"], 1)}
+        if surface is not None:
+            res["surface"] = surface
         if shared is not None:
             dt_s, st_s, distinct = shared
             last = min(F - (n_chunks - 1) * a.chunk, a.chunk)
@@ -397,7 +539,7 @@ def main():
             finally:
                 eng.set_precision(a.precision)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

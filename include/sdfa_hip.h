@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define SDFA_ABI_VERSION 2   /* 2: + seek, resample, mesh correspondences, multi-destination regress, expand_coef, autotune (round 2); all of version 1 unchanged */
+#define SDFA_ABI_VERSION 3   /* 3: + sdfa_ensemble_mean, sdfa_model_set_reserved_cus (round 3); 2: + seek, resample, mesh correspondences,
+                                multi-destination regress, expand_coef, autotune (round 2); all earlier entry points unchanged */
 
 #define SDFA_OK            0
 #define SDFA_EINVAL       -1   /* bad argument (shape, size, null pointer, unsupported rate) */
@@ -145,6 +146,12 @@ int         sdfa_model_precision(const sdfa_model *m);
  * no counterpart; its PyTorch kernels are picked by cuDNN's own heuristics.) */
 int         sdfa_model_autotune(sdfa_model *m, int64_t n_frames, void *d_workspace, int64_t workspace_bytes, void *stream);
 
+/* The persistent / one-workgroup-per-CU kernels of the large stages (frequency LSTM, projection GEMMs, PCA expansion) launch
+ * one workgroup per CU.  With k > 0 they launch (CUs - k): kernels of OTHER streams -- RCCL's all-gather of the previous
+ * chunk's rows (sdfa_amd/dist.py), a copy kernel -- then find free CUs while a forward call runs.  0 (default) = all CUs.
+ * Results do not depend on it.  (New: no counterpart in the reference.) */
+int         sdfa_model_set_reserved_cus(sdfa_model *m, int k);
+
 /* Bytes of scratch device memory the forward calls need for up to `max_frames` frames per call. */
 int64_t sdfa_workspace_bytes(const sdfa_model *m, int64_t max_frames);
 
@@ -213,6 +220,11 @@ int sdfa_regress_forward_multi(const sdfa_model *m, const float *d_z, const int6
  *   d_coef  [n_frames][coef_dim]   d_out  [n_frames][out_dim]   alignment as for sdfa_regress_forward */
 int sdfa_expand_coef(const sdfa_model *m, const float *d_coef, int64_t n_frames, float *d_out, void *d_workspace,
                      int64_t workspace_bytes, void *stream);
+
+/* Test-time ensembling (speech_anime/model/model.py:369-403, `--ensembling_ms`): the mean of the two passes' output rows,
+ * d_out[i] = (d_a[i] + d_b[i]) / 2 with numpy's float32 roundings (`anime_sum += second; anime_sum / 2.0`), so that the
+ * averaged track never has to be formed on the host.  n = elements; all pointers 16-byte aligned; d_out may equal d_a. */
+int sdfa_ensemble_mean(const float *d_a, const float *d_b, int64_t n, float *d_out, void *stream);
 
 /* Debug / parity taps: copy an intermediate activation of the LAST sdfa_encoder_forward call out of
  * the workspace in the reference's layout.  what: 0 = pool1 (n,32,64,64)  1 = conv3 (n,64,32,64)

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -148,7 +149,9 @@ struct sdfa_model {
     int pca_n = 0;
     const float *pca_q[2], *pca_bias[2];
     int pca_K[2], pca_k0[2], pca_group[2], pca_off[2];
-    int freq_shape = 9;   // launch form of the fp32 frequency LSTM (kernels.h FreqLstmArgs::shape); sdfa_model_autotune measures and sets it
+    std::atomic<int> freq_shape{9};   // launch form of the fp32 frequency LSTM (kernels.h FreqLstmArgs::shape); sdfa_model_autotune measures and sets it
+                                      // (atomic: forwards on other threads may read it while an autotune call stores the winner)
+    std::atomic<int> reserved_cus{0}; // CUs the persistent kernels leave free (sdfa_model_set_reserved_cus)
     int64_t pca_ld[2], pca_cols[2];
     int64_t out_dim, coef_dim;
     // profiling
@@ -780,6 +783,16 @@ int sdfa_model_set_precision(sdfa_model *m, int mode) {
 
 int sdfa_model_precision(const sdfa_model *m) { return m ? m->precision : SDFA_EINVAL; }
 
+// The persistent / one-workgroup-per-CU kernels (frequency LSTM, the fat GEMMs, the PCA expansion) size their grids to the
+// device's CU count; with k reserved they launch (CUs - k) workgroups, so that kernels of another stream (an RCCL
+// all-gather, a copy kernel) find free CUs while they run.
+int sdfa_model_set_reserved_cus(sdfa_model *m, int k) {
+    if (!m) return fail(SDFA_EINVAL, "null model");
+    if (k < 0 || k > 128) return fail(SDFA_EINVAL, "reserved_cus must be in [0, 128], got %d", k);
+    m->reserved_cus.store(k);
+    return SDFA_OK;
+}
+
 // The kernels / launch forms of the fp32 frequency LSTM are bit-identical and within 1-3 % of each other; for the forms with
 // two resident workgroups per CU the order is a property of how the two happen to interleave:
 // measure, don't guess.
@@ -798,9 +811,9 @@ int sdfa_model_autotune(sdfa_model *m, int64_t n_frames, void *d_workspace, int6
     HIP_TRY(hipEventCreate(&e1));
     static const int forms[] = {9, 8, 5, 3};      // third form persistent / hardware-dispatched; second form persistent / hardware-dispatched (two per CU)
     float best_ms = 0.f;
-    int best = m->freq_shape, rc = SDFA_OK;
+    int best = m->freq_shape.load(), rc = SDFA_OK;
     for (int form : forms) {
-        FreqLstmArgs fa{ws + w.X3, m->fl_w, m->fl_b, ws + w.HF, Mc, nullptr, m->fl_wb, 0, reinterpret_cast<int *>(ws + w.CT), form};
+        FreqLstmArgs fa{ws + w.X3, m->fl_w, m->fl_b, ws + w.HF, Mc, nullptr, m->fl_wb, 0, reinterpret_cast<int *>(ws + w.CT), form, m->reserved_cus.load()};
         float ms = 0.f;
         for (int rep = 0; rep < 3 && rc == SDFA_OK; ++rep) {      // one warm launch, two timed
             if (rep == 1 && hipEventRecord(e0, s) != hipSuccess) rc = SDFA_EHIP;
@@ -813,7 +826,7 @@ int sdfa_model_autotune(sdfa_model *m, int64_t n_frames, void *d_workspace, int6
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (rc != SDFA_OK) return fail(rc, "autotune: a HIP call failed: %s", hipGetErrorString(hipGetLastError()));
-    m->freq_shape = best;
+    m->freq_shape.store(best);
     return best;
 }
 
@@ -876,7 +889,7 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
         }
 
         FreqLstmArgs fa{ws + w.X3, m->fl_w, m->fl_b, ws + w.HF, Mc, d_ulimit, m->fl_wb, stage_terms(m, STAGE_BODY), reinterpret_cast<int *>(ws + w.CT),
-                        g_sdfa_freq_lstm_shape ? g_sdfa_freq_lstm_shape : m->freq_shape};
+                        g_sdfa_freq_lstm_shape ? g_sdfa_freq_lstm_shape : m->freq_shape.load(), m->reserved_cus.load()};
         pf.begin("freq_lstm"); HIP_TRY(sdfa_launch_freq_lstm(fa, s)); pf.end();
 
         GemmArgs g{};   // FreqLstm._proj: Linear(8192 -> 256) + bias
@@ -884,6 +897,7 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
         g.ldp = 256; g.ldq = Mc; g.ldd = Mc; g.Ppad = 256; g.Qpad = Mc; g.Pstore = 256; g.Qreal = Mc;
         g.K = 8192; g.seg_k = 8192; g.act = ACT_NONE; g.out_mode = OUT_K4; g.q_tile_major = 1; g.q_slab_rows = HF_SLAB_ROWS;
         g.terms = stage_terms(m, STAGE_BODY);
+        g.reserve_cus = m->reserved_cus.load();
         if (share) { g.D = ws + w.ZU; g.q_limit = d_ulimit; }
         pf.begin("freq_proj"); HIP_TRY(sdfa_launch_gemm(g, s)); pf.end();
         if (share) {   // scatter every distinct column's 256 features to all the (t, n) columns that contain it
@@ -899,6 +913,7 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
             gi.ldp = 2048; gi.ldq = Mc; gi.ldd = Mc; gi.Ppad = 2048; gi.Qpad = Mc; gi.Pstore = 2048; gi.Qreal = Mc;
             gi.K = l == 0 ? 256 : 512; gi.seg_k = gi.K; gi.act = ACT_NONE; gi.out_mode = OUT_K4;
             gi.terms = stage_terms(m, STAGE_BODY);
+            gi.reserve_cus = m->reserved_cus.load();
             pf.begin(gxn[l]); HIP_TRY(sdfa_launch_gemm(gi, s)); pf.end();
             TimeLstmArgs ta{ws + w.GX, m->tl_w[l], hout[l], Nc, Mc, m->tl_wb[l], stage_terms(m, STAGE_BODY)};
             pf.begin(lsn[l]); HIP_TRY(sdfa_launch_time_lstm(ta, s)); pf.end();
@@ -945,6 +960,7 @@ static hipError_t expand_rows(const sdfa_model *m, const float *coef, int64_t N,
         pa.coef = coef; pa.basis_s = m->pca_q[0]; pa.basis_r = m->pca_q[1]; pa.mean_s = m->pca_bias[0]; pa.mean_r = m->pca_bias[1];
         pa.out = d_out + f0 * m->out_dim; pa.N = N; pa.Nc = Nc; pa.out_dim = m->out_dim;
         pa.n_extra = n_outs - 1;
+        pa.reserve_cus = m->reserved_cus.load();
         for (int x = 1; x < n_outs; ++x) pa.out_extra[x - 1] = h_d_outs[x] + f0 * m->out_dim;
         pa.ld_s = m->pca_ld[0]; pa.ld_r = m->pca_ld[1]; pa.cols_s = m->pca_cols[0]; pa.cols_r = m->pca_cols[1];
         // default: basis slab resident in LDS, persistent work units (pca_dgrad_res_kernel); "pca_lds" option 4 = the register-
@@ -1327,6 +1343,14 @@ int sdfa_seek_plan(const int32_t *d_tslist, const int64_t *d_clip_frame_off, con
     if (!d_tslist || !d_clip_frame_off || !d_clip_query_off || !d_seek_src || !d_seek_w || n_clips <= 0 || n_queries < 0 || !(fps > 0))
         return fail(SDFA_EINVAL, "seek_plan: bad argument");
     HIP_TRY(sdfa_launch_seek_plan(d_tslist, d_clip_frame_off, d_clip_query_off, n_clips, fps, n_queries, d_seek_src, d_seek_w, (hipStream_t)stream));
+    return SDFA_OK;
+}
+
+int sdfa_ensemble_mean(const float *d_a, const float *d_b, int64_t n, float *d_out, void *stream) {
+    if (n == 0) return SDFA_OK;
+    if (!d_a || !d_b || !d_out || n < 0) return fail(SDFA_EINVAL, "ensemble_mean: bad argument");
+    if (((uintptr_t)d_a | (uintptr_t)d_b | (uintptr_t)d_out) & 15) return fail(SDFA_EINVAL, "ensemble_mean: pointers must be 16-byte aligned");
+    HIP_TRY(sdfa_launch_ensemble_mean(d_a, d_b, n, d_out, (hipStream_t)stream));
     return SDFA_OK;
 }
 

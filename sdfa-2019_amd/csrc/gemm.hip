@@ -919,7 +919,8 @@ hipError_t launch_fat(const GemmArgs &a, hipStream_t s) {
         return (int64_t)n;
     }();
     const int64_t ntiles = (a.Ppad / 256) * (a.Qpad / 256);
-    hipLaunchKernelGGL((gemm_fat_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>), dim3((unsigned)std::min(ntiles, cus)), dim3(256), lds, s, a);
+    const int64_t wgs = std::max<int64_t>(1, cus - a.reserve_cus);      // CUs left to kernels of other streams (sdfa_model_set_reserved_cus)
+    hipLaunchKernelGGL((gemm_fat_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>), dim3((unsigned)std::min(ntiles, wgs)), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
@@ -1041,7 +1042,9 @@ hipError_t launch_any(const GemmArgs &a, hipStream_t s) {
     }
     // 256 x 256 tile, 8 waves: on request (gemm_variant 5), and in the round-1/2 choice (9) for the 8192-deep frequency projection,
     // whose operand stream (2 MB of hidden states per frame) is what the 128 x 128 tile waits for (40.3 vs 41.7 ms)
-    if ((g_sdfa_gemm_variant == 5 || (a.q_tile_major && (g_sdfa_gemm_variant == 0 || g_sdfa_gemm_variant == 9))) && a.Ppad % 256 == 0 && a.Qpad % 256 == 0)
+    // Small batches (a single 2 s / 10 s clip: 64 / 160 such tiles): the 128 x 128 tile instead, four times as many workgroups
+    const bool big_fills = (a.Ppad / 256) * (a.Qpad / 256) >= 256;
+    if ((g_sdfa_gemm_variant == 5 || (a.q_tile_major && ((g_sdfa_gemm_variant == 0 && big_fills) || g_sdfa_gemm_variant == 9))) && a.Ppad % 256 == 0 && a.Qpad % 256 == 0)
         return launch_big<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
     if (a.q_tile_major) return launch<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);   // only the LDS-tiled kernels read that layout
     if (g_sdfa_gemm_variant == 1 && a.Ppad % 128 == 0) return launch_direct<4, OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);

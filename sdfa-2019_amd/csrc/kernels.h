@@ -38,6 +38,7 @@ struct GemmArgs {
     int col_group, col_stride, col_off;   // OUT_ROW only: column q is stored at (q / group) * stride + off + q % group (group 0 = identity)
     float *D_extra[SDFA_MAX_DESTS - 1];   // OUT_ROW only: further destinations with D's layout (see PcaArgs::out_extra)
     int n_extra;
+    int reserve_cus;          // persistent kernel (gemm_fat_kernel): launch (CUs - reserve_cus) workgroups
 };
 hipError_t sdfa_launch_gemm(const GemmArgs &a, hipStream_t s);
 
@@ -52,6 +53,7 @@ struct PcaArgs {
     // this rank's slot in each peer GPU's gathered buffer, mapped over xGMI (or other buffers on this device)
     float *out_extra[SDFA_MAX_DESTS - 1];
     int n_extra;
+    int reserve_cus;                 // pca_dgrad_res_kernel: launch (CUs - reserve_cus) workgroups
 };
 hipError_t sdfa_launch_pca_dgrad(const PcaArgs &a, hipStream_t s);
 hipError_t sdfa_launch_pca_dgrad_res(const PcaArgs &a, int *queue, hipStream_t s);   // basis slab resident in LDS, persistent; queue: one int of workspace
@@ -109,6 +111,7 @@ struct FreqLstmArgs {
     int shape;           // fp32 kernel / launch form (all bit-identical): freq_lstm_v3_kernel 8 = one hardware-dispatched workgroup per tile,
                          // 9 = persistent (tile queue), one workgroup per CU by design; freq_lstm_v2_kernel 3 = hardware-dispatched, two per CU;
                          // 5 = persistent, two per CU; 6 / 7 = the same with one per CU; freq_lstm_kernel (round 1) 4, 1, 2
+    int reserve_cus;     // persistent forms: launch (CUs - reserve_cus) workgroups (sdfa_model_set_reserved_cus)
 };
 hipError_t sdfa_launch_freq_lstm(const FreqLstmArgs &a, hipStream_t s);
 
@@ -188,6 +191,8 @@ hipError_t sdfa_launch_mesh_scatter(const MeshArgs &a, hipStream_t s);
 hipError_t sdfa_launch_seek_plan(const int32_t *tslist, const int64_t *frame_off, const int64_t *query_off, int n_clips, double fps,
                                  int64_t n_queries, int64_t *src, float *w, hipStream_t s);
 hipError_t sdfa_launch_seek_rows(const float *rows, int64_t width, const int64_t *src, const float *w, int64_t nq, float *out, hipStream_t s);
+// test-time ensembling: out = (a + b) / 2, element-wise, float32 roundings of numpy's `sum += x; sum / 2.0` (16-byte aligned pointers)
+hipError_t sdfa_launch_ensemble_mean(const float *a, const float *b, int64_t n, float *out, hipStream_t s);
 
 // ---- audio ingest: kaiser_best resampling (resample.hip) --------------------------------------------------------
 struct ResampleArgs {

@@ -1256,6 +1256,7 @@ static hipError_t launch_freq(const FreqLstmArgs &a, hipStream_t s) {
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
             e = hipMemsetAsync(a.tile_counter, 0, sizeof(int), s);
             if (e != hipSuccess) return e;
+            cus = std::max(1, cus - a.reserve_cus);      // CUs left to kernels of other streams (sdfa_model_set_reserved_cus)
             hipLaunchKernelGGL((freq_lstm_v3_kernel<SHARED, true>), dim3(n_tiles < (unsigned)cus ? n_tiles : (unsigned)cus), dim3(256), lds, s, a);
         } else {
             hipLaunchKernelGGL((freq_lstm_v3_kernel<SHARED, false>), dim3(n_tiles), dim3(256), lds, s, a);

@@ -157,6 +157,21 @@ __global__ __launch_bounds__(256) void seek_rows_kernel(const float *__restrict_
     }
 }
 
+// Test-time ensembling (speech_anime/model/model.py:369-403): `anime_sum += second_pass; anime_sum / 2.0` on float32 arrays =
+// one rounded add and one (exact) division per element.  In place when out == a.
+__global__ __launch_bounds__(256) void ensemble_mean_kernel(const float *a, const float *__restrict__ b, int64_t n, float *out) {
+    const int64_t nq = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 x = ld4(a + 4 * i), y = ld4(b + 4 * i);
+        st4(out + 4 * i, make_float4(__fdiv_rn(fadd_exact(x.x, y.x), 2.0f), __fdiv_rn(fadd_exact(x.y, y.y), 2.0f),
+                                     __fdiv_rn(fadd_exact(x.z, y.z), 2.0f), __fdiv_rn(fadd_exact(x.w, y.w), 2.0f)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n % 4) {
+        const int64_t i = nq * 4 + threadIdx.x;
+        out[i] = __fdiv_rn(fadd_exact(a[i], b[i]), 2.0f);
+    }
+}
+
 __global__ __launch_bounds__(256) void mesh_scatter_kernel(MeshArgs a) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)a.n_verts * a.n_frames) return;
@@ -192,6 +207,12 @@ hipError_t sdfa_launch_seek_rows(const float *rows, int64_t width, const int64_t
     const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 256 * 32);
     if (vec) hipLaunchKernelGGL(seek_rows_kernel<4>, dim3(grid), dim3(256), 0, s, rows, width, src, w, nq, out);
     else hipLaunchKernelGGL(seek_rows_kernel<1>, dim3(grid), dim3(256), 0, s, rows, width, src, w, nq, out);
+    return hipGetLastError();
+}
+
+hipError_t sdfa_launch_ensemble_mean(const float *a, const float *b, int64_t n, float *out, hipStream_t s) {
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n / 4 + 255) / 256, 256 * 32));
+    hipLaunchKernelGGL(ensemble_mean_kernel, dim3(grid), dim3(256), 0, s, a, b, n, out);
     return hipGetLastError();
 }
 

@@ -391,6 +391,7 @@ hipError_t sdfa_launch_pca_dgrad_res(const PcaArgs &a, int *queue, hipStream_t s
     const int64_t nfb = a.Nc / 128;
     const int fbu = ntb * ((nfb + 15) / 16) >= 4 * cus ? 16 : (ntb * ((nfb + 7) / 8) >= 4 * cus ? 8 : 4);
     const int64_t units = ntb * ((nfb + fbu - 1) / fbu);
+    cus = std::max(1, cus - a.reserve_cus);      // CUs left to kernels of other streams (sdfa_model_set_reserved_cus)
     hipLaunchKernelGGL(pca_dgrad_res_kernel, dim3((unsigned)(units < cus ? units : cus)), dim3(256), lds, s, a, queue, fbu);
     return hipGetLastError();
 }

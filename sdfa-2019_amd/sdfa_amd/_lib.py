@@ -32,6 +32,8 @@ SYMBOLS = {
     "sdfa_model_finalize": (C.c_int, [_p, _p]),
     "sdfa_model_set_precision": (C.c_int, [_p, C.c_int]),
     "sdfa_model_precision": (C.c_int, [_p]),
+    "sdfa_model_set_reserved_cus": (C.c_int, [_p, C.c_int]),
+    "sdfa_ensemble_mean": (C.c_int, [_p, _p, _i64, _p, _p]),
     "sdfa_model_head": (C.c_int, [_p]),
     "sdfa_model_out_dim": (_i64, [_p]),
     "sdfa_model_coef_dim": (_i64, [_p]),

@@ -178,8 +178,19 @@ class DirectGatherer:
     (Engine.regress_multi -> sdfa_regress_forward_multi).  One shard crosses each link once; there is no staging copy and no
     collective in the data path -- `finish()` is a device synchronise plus a barrier, after which every rank holds all rows.
 
+    Cross-step hazard and how it is closed: `finish()` only says that THIS step's rows have arrived; a peer's kernels that
+    still READ the gathered rows of step k (enqueued after finish(k)) must not be overtaken by step k+1's stores into the same
+    memory.  So there are TWO gathered buffers, used alternately (`begin_step()` switches): step k+1 writes the other buffer,
+    and the buffer of step k is written again only in step k+2 -- after finish(k+1), whose device synchronise on every rank
+    has drained every consumer of step k that was enqueued before it, and whose barrier has told everyone so.  Contract for
+    callers: enqueue the consumers of a step's rows on this device before calling the next finish().
+
     Works with any control backend ("nccl" or "gloo"): the data moves by peer stores, not through the process group.
+    Every rank must see every peer's device (no per-rank HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES mask): checked here.
+    Opt-in only (`bench.py --gather direct`); never a default until a run on more than one physical GPU has passed.
     """
+
+    N_BUFFERS = 2
 
     def __init__(self, counts, row_width, device, group=None):
         from torch.multiprocessing.reductions import reduce_tensor
@@ -192,20 +203,44 @@ class DirectGatherer:
         for c in self.counts:
             self.offsets.append(self.offsets[-1] + c)
         self.device = torch.device(device)
-        self.buf = torch.empty((self.offsets[-1], self.width), dtype=torch.float32, device=self.device)
+        # peer mappings are rebuilt by device INDEX: every rank's device must be visible here under the same index
+        mine = (self.device.index if self.device.index is not None else torch.cuda.current_device(), torch.cuda.device_count())
+        seen = [None] * self.world
+        dist.all_gather_object(seen, mine, group=group)
+        for r, (idx, _) in enumerate(seen):
+            if idx >= torch.cuda.device_count():
+                raise RuntimeError(f"direct gather: rank {r} computes on device {idx}, which rank {self.rank} cannot see "
+                                   f"({torch.cuda.device_count()} visible): launch without a per-rank *_VISIBLE_DEVICES mask")
+        self.bufs = [torch.empty((self.offsets[-1], self.width), dtype=torch.float32, device=self.device) for _ in range(self.N_BUFFERS)]
         handles = [None] * self.world
-        dist.all_gather_object(handles, reduce_tensor(self.buf), group=group)      # (rebuild function, IPC handle + geometry)
+        dist.all_gather_object(handles, [reduce_tensor(b) for b in self.bufs], group=group)      # (rebuild function, IPC handle + geometry)
         self._peers = []                                                            # keeps the mappings alive
         lo, hi = self.offsets[self.rank], self.offsets[self.rank + 1]
-        self.dests = []                                                             # my slot in every rank's buffer; own buffer first
-        for r in [self.rank] + [r for r in range(self.world) if r != self.rank]:
-            if r == self.rank:
-                t = self.buf
-            else:
-                fn, args = handles[r]
-                t = fn(*args)
-                self._peers.append(t)
-            self.dests.append(t[lo:hi])
+        self._dests = []                                                            # per buffer: my slot in every rank's buffer; own buffer first
+        for b in range(self.N_BUFFERS):
+            dests = []
+            for r in [self.rank] + [r for r in range(self.world) if r != self.rank]:
+                if r == self.rank:
+                    t = self.bufs[b]
+                else:
+                    fn, args = handles[r][b]
+                    t = fn(*args)
+                    self._peers.append(t)
+                dests.append(t[lo:hi])
+            self._dests.append(dests)
+        self.cur = 0
+
+    @property
+    def buf(self):
+        return self.bufs[self.cur]
+
+    @property
+    def dests(self):
+        return self._dests[self.cur]
+
+    def begin_step(self):
+        """Call before the first store of a step: switches to the other gathered buffer (see the class docstring)."""
+        self.cur = (self.cur + 1) % self.N_BUFFERS
 
     def dest_views(self, f0, f1):
         """Destinations of this rank's frames [f0, f1): one (f1 - f0, width) view per rank, the local one first."""

@@ -49,23 +49,31 @@ class FrontendOnly:
         torch.cuda.set_device(self.device)
 
     # ------------------------------------------------------------------ front end
-    def mel_frontend(self, clips, sr, gather=True):
+    def mel_frontend(self, clips, sr, gather=True, tables=None):
         """clips: list of 1-D float32 arrays/tensors in [-1,1].  Returns (audio_feat (F_total,64,128,3) cuda,
-        per-clip tslists, per-clip frame counts)."""
+        per-clip tslists, per-clip frame counts).  `tables`: per-clip (starts, tslist) from `frame_index`, when the caller
+        already has them (one enumeration per clip)."""
         offs, lens, fclip, fstart, tslists, counts = [], [], [], [], [], []
         pos = 0
         for ci, c in enumerate(clips):
             n = int(c.shape[0])
-            starts, ts = frame_index(n, sr)
+            starts, ts = tables[ci] if tables is not None else frame_index(n, sr)
             offs.append(pos); lens.append(n); pos += n
             fclip.append(np.full(len(starts), ci, np.int32)); fstart.append(starts)
-            tslists.append([int(t) for t in ts]); counts.append(len(starts))
+            tslists.append(ts.tolist()); counts.append(len(starts))
         dev = self.device
-        pcm = torch.cat([torch.as_tensor(c, dtype=torch.float32).reshape(-1) for c in clips]).to(dev, non_blocking=True)
-        d_off = torch.tensor(offs, dtype=torch.int64, device=dev)
-        d_len = torch.tensor(lens, dtype=torch.int64, device=dev)
-        d_fc = torch.from_numpy(np.concatenate(fclip)).to(dev)
-        d_fs = torch.from_numpy(np.concatenate(fstart)).to(dev)
+        # one staging buffer for everything the kernels index by: [clip offsets | clip lengths | frame starts] int64 + frame clips
+        # int32 + PCM -> three host-to-device copies per call instead of five
+        nf, nc = int(sum(counts)), len(clips)
+        meta = np.empty(2 * nc + nf, np.int64)
+        meta[:nc] = offs; meta[nc:2 * nc] = lens; meta[2 * nc:] = np.concatenate(fstart)
+        d_meta = torch.from_numpy(meta).to(dev, non_blocking=True)
+        d_fc = torch.from_numpy(np.concatenate(fclip)).to(dev, non_blocking=True)
+        if len(clips) == 1:
+            pcm = torch.as_tensor(clips[0], dtype=torch.float32).reshape(-1).to(dev, non_blocking=True)
+        else:
+            pcm = torch.cat([torch.as_tensor(c, dtype=torch.float32).reshape(-1) for c in clips]).to(dev, non_blocking=True)
+        d_off, d_len, d_fs = d_meta[:nc], d_meta[nc:2 * nc], d_meta[2 * nc:]
         feat = self.mel_frontend_device(pcm, d_off, d_len, d_fc, d_fs, sr, gather=gather)
         self.last_frame_table = (d_fc, d_fs, frame_geometry(sr)[1])      # (clip, start, hop) for encoder(share)
         return feat, tslists, counts
@@ -121,7 +129,15 @@ class Engine(FrontendOnly):
         self.coef_dim = int(lib.sdfa_model_coef_dim(self._m))
         self.max_frames = int(max_frames)
         self._ws = None
+        self._id_checks = []            # (pinned [min, max], event) of device-resident speaker-id tensors not yet looked at
+        self._host = None               # HostPipeline, created by the first forward_host call
         self.set_precision(precision)
+
+    def set_reserved_cus(self, k):
+        """The persistent kernels launch (CUs - k) workgroups, leaving k CUs to kernels of other streams (RCCL's all-gather
+        of the previous chunk); 0 = all CUs.  Outputs do not depend on it."""
+        check(lib.sdfa_model_set_reserved_cus(self._m, int(k)))
+        self.reserved_cus = int(k)
 
     def set_precision(self, precision):
         """Matrix instruction of the dense contractions (BASELINE configs[3]); "fp32" is the reference's arithmetic."""
@@ -178,8 +194,7 @@ class Engine(FrontendOnly):
     @staticmethod
     def check_speaker_ids(speaker_id):
         """Raises what the reference's one_hot scatter_ raises for an id outside [0, 8) (saber/nn/functions.py:375-378).
-        The kernels take the ids as validated: call this (one aminmax, a host sync for a device tensor) on every id
-        tensor that reaches `regress`, or pass `check_ids=True` (the default)."""
+        One aminmax -- and a host sync when the tensor lives on the device."""
         if torch.is_tensor(speaker_id):
             if speaker_id.numel() == 0:
                 return
@@ -189,11 +204,46 @@ class Engine(FrontendOnly):
         if lo < 0 or hi >= 8:
             raise RuntimeError(f"index {hi if hi >= 8 else lo} is out of bounds for dimension 1 with size 8")
 
-    def regress(self, z, speaker_id, want_coef=False, want_out=True, out=None, check_ids=True):
+    def _validate_ids(self, speaker_id, check_ids):
+        """check_ids None (default): ids that arrive on the host (ints, CPU tensors) are validated at once; ids that are already
+        on the device are validated WITHOUT draining the stream -- their min / max go to a pinned slot asynchronously and an
+        out-of-range id raises at the next call that finds the result ready, or in `check_pending()` (the kernels clamp, so
+        nothing reads out of bounds meanwhile; the reference on a GPU reports a bad scatter_ index at its next
+        synchronisation in the same way).  True: validate now (a host sync for a device tensor).  False: the caller did."""
+        self.check_pending(block=False)
+        if check_ids is False:
+            return
+        if check_ids or not (torch.is_tensor(speaker_id) and speaker_id.is_cuda):
+            self.check_speaker_ids(speaker_id)
+            return
+        if speaker_id.numel() == 0:
+            return
+        lo, hi = torch.aminmax(speaker_id)
+        slot = torch.empty(2, dtype=torch.int64, pin_memory=True)
+        slot.copy_(torch.stack((lo, hi)), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._id_checks.append((slot, ev))
+
+    def check_pending(self, block=True):
+        """Raises for any device-resident speaker-id tensor of an earlier call that held an id outside [0, 8)."""
+        keep = []
+        for slot, ev in self._id_checks:
+            if block:
+                ev.synchronize()
+            elif not ev.query():
+                keep.append((slot, ev))
+                continue
+            lo, hi = int(slot[0]), int(slot[1])
+            if lo < 0 or hi >= 8:
+                self._id_checks = []
+                raise RuntimeError(f"index {hi if hi >= 8 else lo} is out of bounds for dimension 1 with size 8")
+        self._id_checks = keep
+
+    def regress(self, z, speaker_id, want_coef=False, want_out=True, out=None, check_ids=None):
         n = z.shape[0]
         z = z.contiguous()
-        if check_ids:
-            self.check_speaker_ids(speaker_id)
+        self._validate_ids(speaker_id, check_ids)
         spk = speaker_id.to(device=self.device, dtype=torch.int64).contiguous()
         assert spk.numel() == n
         coef = torch.empty((n, self.coef_dim), dtype=torch.float32, device=self.device) if want_coef else None
@@ -206,13 +256,12 @@ class Engine(FrontendOnly):
                                        _ptr(ws), ws.numel(), _stream()))
         return coef, out
 
-    def regress_multi(self, z, speaker_id, outs, want_coef=False, check_ids=True):
+    def regress_multi(self, z, speaker_id, outs, want_coef=False, check_ids=None):
         """`outs`: 1..8 float32 (n, out_dim) destination tensors (or raw device pointers as ints): every one receives the
         same rows, written by the regressor's epilogue itself (sdfa_regress_forward_multi -- the direct all-gather path)."""
         n = z.shape[0]
         z = z.contiguous()
-        if check_ids:
-            self.check_speaker_ids(speaker_id)
+        self._validate_ids(speaker_id, check_ids)
         spk = speaker_id.to(device=self.device, dtype=torch.int64).contiguous()
         coef = torch.empty((n, self.coef_dim), dtype=torch.float32, device=self.device) if want_coef else None
         if n == 0:
@@ -242,6 +291,69 @@ class Engine(FrontendOnly):
             check(lib.sdfa_expand_coef(self._m, _ptr(coef), n, _ptr(out), _ptr(ws), ws.numel(), _stream()))
         return out
 
+    def ensemble_mean(self, a, b, out=None):
+        """(a + b) / 2 element-wise with numpy's float32 roundings (model.py:369-403 test-time ensembling); in place by default."""
+        assert a.is_cuda and b.is_cuda and a.dtype == b.dtype == torch.float32 and a.shape == b.shape and a.is_contiguous() and b.is_contiguous()
+        out = a if out is None else out
+        assert out.is_cuda and out.is_contiguous() and out.shape == a.shape and out.dtype == torch.float32
+        check(lib.sdfa_ensemble_mean(_ptr(a), _ptr(b), a.numel(), _ptr(out), _stream()))
+        return out
+
+    def forward_host(self, feats, speaker_id, out=None, tables=None, piece=None, wait=True, want_z=False, ops_key=None):
+        """The whole model for `n` frames with the output rows delivered to PINNED HOST memory: rows (n, out_dim) as a CPU
+        tensor (`.numpy()` is a view).  Frames are processed in pieces of `piece` (default max_frames) frames; piece i's rows
+        are copied device -> host on a copy stream while piece i+1 computes (two device staging buffers), so for more than one
+        piece the PCIe transfer hides behind the kernels.  This is what SaberSpeechDrivenAnimation._feature_to_anime
+        (speech_anime/model/model.py:428-489) does with `.cpu().numpy()` per batch of 100 frames.
+
+          feats       audio_feat (n,64,128,3) cuda, or a list of two such tensors: the two passes of test-time ensembling
+                      (model.py:369-403), whose rows are averaged on the device before the copy
+          speaker_id  (n,) int64 tensor (any device) or one int
+          tables      per pass (frame_clip int32 (n,), frame_start int64 (n,), hop): run the per-column stages once per
+                      distinct column (bitwise identical, sdfa_encoder_forward_shared)
+          out         pinned float32 CPU tensor (n, out_dim) to fill (allocated from PyTorch's pinned-memory cache otherwise)
+          wait        False: return as soon as everything is enqueued; call `host_wait()` before reading `out`
+          ops_key     key of this engine in sdfa_amd.ops' registry: the kernels are then called through the dispatcher-visible
+                      PyTorch-ROCm custom operators torch.ops.sdfa.{encoder, encoder_shared, regress_into} (same C ABI calls)"""
+        feats = list(feats) if isinstance(feats, (list, tuple)) else [feats]
+        assert 1 <= len(feats) <= 2
+        n = int(feats[0].shape[0])
+        if tables is not None and not isinstance(tables, list):
+            tables = [tables] * len(feats)
+        self._validate_ids(speaker_id, None)
+        if not torch.is_tensor(speaker_id):
+            speaker_id = torch.full((n,), int(speaker_id), dtype=torch.int64, device=self.device)
+        else:
+            speaker_id = speaker_id.to(device=self.device, dtype=torch.int64)
+            assert speaker_id.numel() == n
+        if out is None:
+            out = torch.empty((n, self.out_dim), dtype=torch.float32, pin_memory=True)
+        assert (not out.is_cuda) and out.is_pinned() and out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (n, self.out_dim)
+        if self._host is None:
+            self._host = HostPipeline(self)
+        zs = self._host.run(feats, speaker_id, out, tables, int(piece or self.max_frames), want_z, ops_key)
+        if wait:
+            self.host_wait()
+        return (out, zs) if want_z else out
+
+    def to_host_async(self, t):
+        """Copy of a device tensor in pinned host memory, enqueued on the copy stream behind the work already queued on the
+        current stream (so it overlaps what is launched next); valid after `host_wait()`."""
+        if self._host is None:
+            self._host = HostPipeline(self)
+        return self._host.stage_out(t)
+
+    def host_wait(self):
+        """Blocks until every device -> host copy enqueued by forward_host has landed."""
+        if self._host is not None:
+            self._host.wait()
+        self.check_pending(block=False)
+
+    def last_device_rows(self, n):
+        """The device copy of the rows the LAST forward_host call produced, when all `n` of them went through one piece (a
+        view into a staging buffer: valid until the next forward_host call); None otherwise."""
+        return None if self._host is None else self._host.last_rows(n)
+
     def forward(self, audio_feat, speaker_id, want_coef=False):
         z, align = self.encoder(audio_feat)
         coef, out = self.regress(z, speaker_id, want_coef=want_coef)
@@ -266,3 +378,101 @@ class Engine(FrontendOnly):
         if v < 0:
             check(int(v))
         return float(v)
+
+
+class HostPipeline:
+    """Pinned-output staging of Engine.forward_host: two device row buffers, one copy stream.
+
+    compute stream:  [piece 0: encoder + regress -> buf 0] [piece 1 -> buf 1] [piece 2 -> buf 0, after copy 0] ...
+    copy stream:                                  [buf 0 -> host rows 0..p)  ] [buf 1 -> host ...]
+    The device -> host copies are plain hipMemcpyAsync to pinned memory (SDMA engines): they take no CU from the kernels."""
+
+    def __init__(self, engine):
+        self.eng = engine
+        self.copy_stream = torch.cuda.Stream(device=engine.device)
+        self.bufs = [None, None]
+        self.tmp = None                 # second pass of test-time ensembling
+        self.done = [None, None]        # copy-done event of the last copy out of each buffer
+        self.extra = []                 # copy-done events of stage_out copies
+        self._last = None
+
+    def _buf(self, slot, rows):
+        b = self.bufs[slot]
+        if b is None or b.shape[0] < rows:
+            self.bufs[slot] = None
+            self.bufs[slot] = b = torch.empty((rows, self.eng.out_dim), dtype=torch.float32, device=self.eng.device)
+        return b
+
+    def run(self, feats, spk, out, tables, piece, want_z, ops_key=None):
+        eng = self.eng
+        n = int(feats[0].shape[0])
+        cur = torch.cuda.current_stream(eng.device)
+        zs = []
+        self._last = None
+        for i, f0 in enumerate(range(0, n, piece)):
+            f1 = min(n, f0 + piece)
+            slot = i & 1
+            if self.done[slot] is not None:
+                cur.wait_event(self.done[slot])         # the copy that last read this buffer
+            rows = self._buf(slot, min(piece, n))[: f1 - f0]
+            for p, feat in enumerate(feats):
+                t = tables[p] if tables is not None else None
+                dst = rows
+                if p:
+                    if self.tmp is None or self.tmp.shape[0] < f1 - f0:
+                        self.tmp = None
+                        self.tmp = torch.empty((min(piece, n), eng.out_dim), dtype=torch.float32, device=eng.device)
+                    dst = self.tmp[: f1 - f0]
+                if ops_key is not None:         # through the dispatcher (torch.ops.sdfa.*): same Engine methods underneath
+                    if t is None:
+                        z, _ = torch.ops.sdfa.encoder(feat[f0:f1], ops_key)
+                    else:
+                        z, _ = torch.ops.sdfa.encoder_shared(feat[f0:f1], t[0][f0:f1], t[1][f0:f1], int(t[2]), ops_key)
+                    torch.ops.sdfa.regress_into(z, spk[f0:f1], dst, ops_key)
+                else:
+                    if t is None:
+                        z, _ = eng.encoder(feat[f0:f1], want_align=False)
+                    else:
+                        z, _ = eng.encoder(feat[f0:f1], want_align=False, frame_clip=t[0][f0:f1], frame_start=t[1][f0:f1], hop=t[2])
+                    eng.regress(z, spk[f0:f1], out=dst, check_ids=False)
+                if p:
+                    eng.ensemble_mean(rows, dst)
+                elif want_z:
+                    zs.append(z)
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            self.copy_stream.wait_event(ready)
+            with torch.cuda.stream(self.copy_stream):
+                out[f0:f1].copy_(rows, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(self.copy_stream)
+            self.done[slot] = done
+            if f0 == 0 and f1 == n:
+                self._last = (slot, n)
+        return torch.cat(zs) if want_z and len(zs) != 1 else (zs[0] if want_z else None)
+
+    def stage_out(self, t):
+        cur = torch.cuda.current_stream(self.eng.device)
+        t = t.contiguous()                                  # layout change (if any) on the compute stream
+        host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        self.copy_stream.wait_event(ready)
+        with torch.cuda.stream(self.copy_stream):
+            host.copy_(t, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        t.record_stream(self.copy_stream)                   # the caching allocator must not hand `t` out again before the copy ran
+        self.extra.append(ev)
+        return host
+
+    def wait(self):
+        for ev in self.done + self.extra:
+            if ev is not None:
+                ev.synchronize()
+        self.extra = []
+
+    def last_rows(self, n):
+        if self._last is None or self._last[1] != n:
+            return None
+        return self.bufs[self._last[0]][:n]

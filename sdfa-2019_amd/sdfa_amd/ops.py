@@ -4,7 +4,10 @@ host through PyTorch-ROCm custom ops"; SURVEY.md section 8(b) names them).
     torch.ops.sdfa.frame_index(n_samples, sample_rate, fps, ts_delta)                    -> (starts int64[F], tslist int32[F])   (host)
     torch.ops.sdfa.mel_frontend(pcm, clip_off, clip_len, frame_clip, frame_start, sr)     -> audio_feat f32[F,64,128,3]
     torch.ops.sdfa.encoder(audio_feat, model)                                             -> (z f32[N,512], align f32[N,64])
+    torch.ops.sdfa.encoder_shared(audio_feat, frame_clip, frame_start, hop, model)        -> the same, bitwise, with the per-column stages
+                                                                                             run once per distinct column of the frame table
     torch.ops.sdfa.regress(z, speaker_id, model)                                          -> dgrad f32[N,89784] | offsets f32[N,15069]
+    torch.ops.sdfa.regress_into(z, speaker_id, out, model)                                -> None (rows written into `out`; ids must be validated)
     torch.ops.sdfa.regress_coef(z, speaker_id, model)                                     -> PCA coefficients f32[N,265 | 59]
 
 Thin by design: each op is the matching `Engine` method (ctypes call into libsdfa_hip.so on the current stream), registered
@@ -14,7 +17,9 @@ process' registry (`register_model` / `load_model`); a key that is the path of a
 is what lets a module traced by `speech_anime.api.jit_trace` run in a fresh process.  No CPU kernels are registered: calling a
 device op with CPU tensors raises (the product path has no CPU fallback).
 """
+import itertools
 import os
+import weakref
 from typing import Tuple
 
 import numpy as np
@@ -22,13 +27,29 @@ import torch
 from torch import Tensor
 from torch.library import custom_op
 
-_MODELS = {}
+_MODELS = {}               # key -> Engine, for models loaded BY this module (load_model: the registry owns them)
+_WEAK = {}                 # key -> weakref to an Engine owned by someone else (register_model): dropped with its owner
+_ANON = itertools.count(1)
 
 
-def register_model(key, engine):
-    """`engine`: a sdfa_amd.engine.Engine (anything with encoder / regress / out_dim / coef_dim)."""
-    _MODELS[str(key)] = engine
-    return str(key)
+def register_model(key, engine, own=False):
+    """`engine`: a sdfa_amd.engine.Engine (anything with encoder / regress / out_dim / coef_dim).  The registry keeps a WEAK
+    reference unless `own` is set: an Engine holds the weights and a multi-GB workspace, and a model object that is dropped
+    (SpeechDrivenAnimation re-loaded in a long-lived process) must free them, as a dropped module does in the reference.
+    `key` None: a fresh key from a monotonically increasing counter (never reused, unlike id())."""
+    key = f"sdfa-model-{next(_ANON)}" if key is None else str(key)
+    _MODELS.pop(key, None)
+    _WEAK.pop(key, None)
+    if own:
+        _MODELS[key] = engine
+    else:
+        _WEAK[key] = weakref.ref(engine, lambda _r, k=key: _WEAK.pop(k, None) if _WEAK.get(k) is _r else None)
+    return key
+
+
+def unregister_model(key):
+    _MODELS.pop(str(key), None)
+    _WEAK.pop(str(key), None)
 
 
 def load_model(key, state_dict=None, **engine_kwargs):
@@ -41,11 +62,13 @@ def load_model(key, state_dict=None, **engine_kwargs):
         if "hamm" in ckpt["state"]:
             ckpt = ckpt_backward_compatible_preprocess(ckpt)
         state_dict = ckpt["state"]
-    return register_model(key, Engine(state_dict, **engine_kwargs))
+    return register_model(key, Engine(state_dict, **engine_kwargs), own=True)
 
 
 def _model(key):
     m = _MODELS.get(key)
+    if m is None and key in _WEAK:
+        m = _WEAK[key]()
     if m is None:
         if os.path.isfile(os.path.expanduser(key)):
             load_model(key)
@@ -107,6 +130,21 @@ def _(audio_feat, model):
     return audio_feat.new_empty((n, 512)), audio_feat.new_empty((n, 64))
 
 
+@custom_op("sdfa::encoder_shared", mutates_args=(), device_types="cuda")
+def encoder_shared(audio_feat: Tensor, frame_clip: Tensor, frame_start: Tensor, hop: int, model: str) -> Tuple[Tensor, Tensor]:
+    """sdfa_encoder_forward_shared: `audio_feat` must be what mel_frontend produced for exactly this frame table
+    (frame_clip int32 [N], frame_start int64 [N], hop = int(0.008 * sr)); bitwise the result of sdfa::encoder."""
+    assert frame_clip.dtype == torch.int32 and frame_start.dtype == torch.int64
+    z, align = _model(model).encoder(audio_feat, want_align=True, frame_clip=frame_clip, frame_start=frame_start, hop=hop)
+    return z, align
+
+
+@encoder_shared.register_fake
+def _(audio_feat, frame_clip, frame_start, hop, model):
+    n = audio_feat.shape[0]
+    return audio_feat.new_empty((n, 512)), audio_feat.new_empty((n, 64))
+
+
 @custom_op("sdfa::regress", mutates_args=(), device_types="cuda")
 def regress(z: Tensor, speaker_id: Tensor, model: str) -> Tensor:
     return _model(model).regress(z, speaker_id)[1]
@@ -115,6 +153,17 @@ def regress(z: Tensor, speaker_id: Tensor, model: str) -> Tensor:
 @regress.register_fake
 def _(z, speaker_id, model):
     return z.new_empty((z.shape[0], _model(model).out_dim))
+
+
+@custom_op("sdfa::regress_into", mutates_args=("out",), device_types="cuda")
+def regress_into(z: Tensor, speaker_id: Tensor, out: Tensor, model: str) -> None:
+    """sdfa::regress writing into caller-owned rows (n, out_dim) -- the staging buffers of the pinned-output pipeline."""
+    _model(model).regress(z, speaker_id, out=out, check_ids=False)
+
+
+@regress_into.register_fake
+def _(z, speaker_id, out, model):
+    return None
 
 
 @custom_op("sdfa::regress_coef", mutates_args=(), device_types="cuda")

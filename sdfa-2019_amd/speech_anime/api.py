@@ -71,6 +71,7 @@ def jit_trace(args):
     ckpt = _load_checkpoint(path)
     hparams.set_key("model_key", path)
     model = build_model(hparams, ckpt["state"])
+    ops.register_model(path, model._model._engine, own=True)       # the traced module outlives `model`: the registry owns the engine
     head = "dgrad" if hparams.model.face_data_type == "dgrad_3d" else "offsets"
     mod = ops.TraceableSpeechDrivenAnimation(path, head).eval()
     dev = model._model._engine.device

@@ -52,8 +52,9 @@ class DatasetSlidingWindow:
         assert -1.0 <= signal.min() and signal.max() <= 1.0                      # :330
         sr = hp.audio.sample_rate
         fe = cls._frontend_engine()
-        feat, tslists, _ = fe.mel_frontend([signal], sr)
-        energy = cls._energy(signal, sr)
+        table = _engine.frame_index(len(signal), sr)                             # ONE enumeration per clip: front end and energy share it
+        feat, tslists, _ = fe.mel_frontend([signal], sr, tables=[table])
+        energy = cls._energy(signal, sr, table[0])
         return dict(tslist=tslists[0], energy=energy,
                     audio_feat=feat.cpu().numpy() if as_numpy else feat)
 
@@ -64,11 +65,12 @@ class DatasetSlidingWindow:
         return cls._engine
 
     @staticmethod
-    def _energy(signal, sr):
+    def _energy(signal, sr, starts=None):
         """librosa.feature.rms(frame_length=win, hop_length=hop, center=False) per window (sliding_window.py:365).
         Carried in the result for interface parity; no model consumes it (model.py:443,487)."""
         win, hop, sliding = _engine.frame_geometry(sr)
-        starts, _ = _engine.frame_index(len(signal), sr)
+        if starts is None:
+            starts, _ = _engine.frame_index(len(signal), sr)
         L = len(signal)
         csum = np.concatenate([[0.0], np.cumsum(signal.astype(np.float64) ** 2)])
         a = starts[:, None] + hop * np.arange(64)[None, :]

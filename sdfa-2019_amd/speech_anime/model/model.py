@@ -33,7 +33,8 @@ class SpeechDrivenAnimation:
             raise RuntimeError(f"checkpoint holds a '{head}' output module but hparams.model.face_data_type = {self._face_type}")
         self._engine = Engine(state_dict, device=self.hp.get("device", "cuda:0") or "cuda:0",
                               precision=self.hp.get("precision", "fp32") or "fp32", strict=strict)
-        self._key = _ops.register_model(self.hp.get("model_key") or f"speech_anime@{id(self):x}", self._engine)
+        # weakly registered: dropping this object frees the engine (weights + workspace); anonymous keys come from a counter
+        self._key = _ops.register_model(self.hp.get("model_key") or None, self._engine)
         return self
 
     def eval(self):
@@ -112,8 +113,9 @@ class SaberSpeechDrivenAnimation:
         return tensor_dict[self._face_type]
 
     # ---- model.py:333-420 ---------------------------------------------------------------------
-    @torch.no_grad()
-    def generate_animation(self, signal, speaker, emotion, frame_id, ensembling_ms=None, dataset_class=None, **kwargs):
+    @staticmethod
+    def _check_signal(signal):
+        """The input checks of generate_animation (model.py:339-349)."""
         if torch.is_tensor(signal):
             if signal.dim() > 1:
                 assert signal.dim() == 2
@@ -124,7 +126,17 @@ class SaberSpeechDrivenAnimation:
         assert np.prod(signal.shape) == np.max(signal.shape)
         assert signal.min() >= -1
         assert signal.max() <= 1
-        signal = signal.flatten()
+        return np.asarray(signal.flatten(), np.float32)
+
+    @torch.no_grad()
+    def generate_animation(self, signal, speaker, emotion, frame_id, ensembling_ms=None, dataset_class=None, **kwargs):
+        """(tslist, animes (F, 9976, 9) | (F, 15069) float32 numpy, others) for ONE clip -- the reference's signature and result.
+
+        The default dataset class takes the device pipeline of `generate_animation_batch` (one front-end call, column-sharing
+        encoder, ensembling mean on the device, one pinned device -> host copy); a caller-supplied `dataset_class` keeps the
+        reference's two-step route through its `fetch_audio_features` and `_feature_to_anime`.  `animes` is a view of pinned host
+        memory owned by the returned array.  kwargs: want_inputs (default True, as the reference returns others["inputs"])."""
+        signal = self._check_signal(signal)
         if dataset_class is None:
             dataset_class = DatasetSlidingWindow
         if isinstance(speaker, str):
@@ -133,33 +145,91 @@ class SaberSpeechDrivenAnimation:
             emotion = self._emotions_dict[emotion]
         if ensembling_ms is None:
             ensembling_ms = self.hp.ensembling_ms
+        if dataset_class is DatasetSlidingWindow:
+            return self._animate([signal], [speaker], ensembling_ms, kwargs.get("want_inputs", True))[0]
 
         passes = [signal]
         if ensembling_ms is not None and ensembling_ms > 0:            # model.py:373-384: second pass on a delayed copy
             pad = ensembling_ms * self.hp.audio.sample_rate // 1000
             passes.append(np.pad(signal[:-pad], [[pad, 0]], "constant"))
-        feats = [dataset_class.fetch_audio_features(p, self.hp, as_numpy=False) for p in passes]
+        feats = [dataset_class.fetch_audio_features(p, self.hp) for p in passes]
         anime_sum, others = self._feature_to_anime(feats[0]["audio_feat"], feats[0]["energy"], speaker, emotion, frame_id,
                                                    want_inputs=kwargs.get("want_inputs", True))
         for f in feats[1:]:
             anime_sum += self._feature_to_anime(f["audio_feat"], f["energy"], speaker, emotion, frame_id, want_inputs=False)[0]
-        return feats[0]["tslist"], anime_sum / float(len(feats)), others
+        if len(feats) > 1:
+            anime_sum = anime_sum / float(len(feats))
+        return feats[0]["tslist"], anime_sum, others
+
+    @torch.no_grad()
+    def generate_animation_batch(self, signals, speakers, emotions=0, frame_id=0, ensembling_ms=None, want_inputs=False):
+        """Several utterances through ONE launch group: [(tslist, animes, others)] in the order of `signals`, each exactly
+        what `generate_animation` returns for that clip alone (frames are independent and a column's features do not depend
+        on the batch, so the rows are bitwise the single-clip rows).  `speakers`: one name / id, or one per clip."""
+        signals = [self._check_signal(s) for s in signals]
+        if isinstance(speakers, (str, int, np.integer)):
+            speakers = [speakers] * len(signals)
+        assert len(speakers) == len(signals)
+        speakers = [self._speakers_dict[s] if isinstance(s, str) else s for s in speakers]
+        if ensembling_ms is None:
+            ensembling_ms = self.hp.ensembling_ms
+        return self._animate(signals, speakers, ensembling_ms, want_inputs)
+
+    def _animate(self, signals, speakers, ensembling_ms, want_inputs):
+        from sdfa_amd.engine import frame_index
+        eng = self._model._engine
+        if eng is None:
+            raise RuntimeError("no weights loaded: call load_state_dict first")
+        sr = self.hp.audio.sample_rate
+        for spk in speakers:
+            assert isinstance(spk, (int, np.integer)), f"given index is {spk}, {type(spk)}"
+            eng.check_speaker_ids(int(spk))
+        tables = [frame_index(len(s), sr) for s in signals]             # ONE enumeration per clip (starts, tslist)
+        passes = [signals]
+        if ensembling_ms is not None and ensembling_ms > 0:            # model.py:373-384: second pass on a delayed copy
+            pad = ensembling_ms * sr // 1000
+            passes.append([np.pad(s[:-pad], [[pad, 0]], "constant") for s in signals])
+        feats, share = [], []
+        for clips in passes:
+            feat, tslists, counts = eng.mel_frontend(clips, sr, tables=tables)
+            feats.append(feat)
+            share.append(eng.last_frame_table)                          # (clip, start, hop): the per-column stages run once per distinct column
+        n = int(sum(counts))
+        spk = torch.from_numpy(np.repeat(np.asarray(speakers, np.int64), counts)).to(eng.device, non_blocking=True)
+        inputs_host = None
+        if want_inputs:                                                 # others["inputs"] = audio_feat.permute(0, 3, 2, 1), model.py:463-466
+            inputs_host = eng.to_host_async(feats[0].permute(0, 3, 2, 1))
+        rows = eng.forward_host(feats, spk, tables=share, ops_key=self._model._key, wait=True)
+        shape = (-1, 9) if self._face_type == "dgrad_3d" else ()
+        out, f0 = [], 0
+        rows_np = rows.numpy()
+        inputs_np = inputs_host.numpy() if inputs_host is not None else None
+        for ci, c in enumerate(counts):
+            animes = rows_np[f0:f0 + c].reshape((c,) + shape) if shape else rows_np[f0:f0 + c]
+            others = {"inputs": inputs_np[f0:f0 + c] if inputs_np is not None else None,
+                      "phones": None, "latent": None, "latent_align": None, "formants": None}
+            out.append((tslists[ci], animes, others))
+            f0 += c
+        return out
 
     # ---- model.py:428-489 ---------------------------------------------------------------------
     @torch.no_grad()
     def _feature_to_anime(self, feat_list, energy_list, speaker_id, emotion_id, frame_id, bs=100, want_inputs=True):
-        """`bs` is accepted for signature parity; frames are independent, so the engine batches by its own chunk size."""
+        """audio_feat (F,64,128,3) (numpy or tensor, any device) -> (animes (F, 9976, 9) | (F, 15069) float32 numpy, others).
+        `bs` is accepted for signature parity; frames are independent, so the engine batches by its own chunk size and the rows
+        reach the host through pinned memory while the next piece computes (Engine.forward_host)."""
         assert isinstance(speaker_id, (int, np.integer)), f"given index is {speaker_id}, {type(speaker_id)}"
         eng = self._model._engine
         eng.check_speaker_ids(int(speaker_id))      # before any device work: ids >= num_speakers raise like one_hot's scatter_
         feat = feat_list if torch.is_tensor(feat_list) else torch.from_numpy(np.asarray(feat_list, np.float32))
-        feat = feat.to(eng.device)
+        feat = feat.to(eng.device, dtype=torch.float32).contiguous()
         n = feat.shape[0]
-        spk = torch.full((n,), int(speaker_id), dtype=torch.int64, device=eng.device)
-        res = self.forward({"audio_feat": feat, "speaker_id": spk})
-        animes = self.data_to_anime_feat(res["prediction"], is_prediction=True).squeeze(1)   # (n, 9976, 9) / (n, 15069)
-        animes = np.asarray(animes.cpu().numpy(), dtype=np.float32)
-        others = {"inputs": feat.permute(0, 3, 2, 1).cpu().numpy() if want_inputs else None,
+        inputs_host = eng.to_host_async(feat.permute(0, 3, 2, 1)) if want_inputs else None
+        rows = eng.forward_host(feat, int(speaker_id), ops_key=self._model._key, wait=True)
+        animes = rows.numpy()
+        if self._face_type == "dgrad_3d":
+            animes = animes.reshape(n, -1, 9)
+        others = {"inputs": inputs_host.numpy() if inputs_host is not None else None,
                   "phones": None, "latent": None, "latent_align": None, "formants": None}
         return animes, others
 
@@ -197,7 +267,9 @@ class SaberSpeechDrivenAnimation:
                     # materialised for the NNNNNN_dgrad.npy dump the reference also writes)
                     eng = self._model._engine
                     plan = SeekPlan([tslist], fps, device=eng.device)
-                    track = torch.from_numpy(np.ascontiguousarray(animes, dtype=np.float32)).to(eng.device).reshape(len(tslist), -1)
+                    track = eng.last_device_rows(len(tslist))           # the rows are still on the device: no re-upload (model.py:200)
+                    if track is None:
+                        track = torch.from_numpy(np.ascontiguousarray(animes, dtype=np.float32)).to(eng.device).reshape(len(tslist), -1)
                     frames = plan.rows(track).cpu().numpy().reshape((plan.n_queries,) + animes.shape[1:])
                     for i_frame, data_frame in enumerate(frames):
                         np.save(os.path.join(out_dir, f"{i_frame:06d}_dgrad.npy"), data_frame)

@@ -39,11 +39,16 @@ N_MODEL_TRIS = 9976      # triangles of the model's FLAME-topology dgrad rows (f
 
 
 def set_dgrad_static(verts, faces, c_indices=None, corres=None):
-    """frame.py:27-46: template state + deformation.set_target(verts, faces, cnsts, corrs=corr_count)."""
+    """frame.py:27-46: template state + deformation.set_target(verts, faces, cnsts, corrs=corr_count).  Without `c_indices` the
+    reference pins `non_face.non_face_verts` (frame.py:33) -- 3,762 FLAME vertex indices -- and so does this; a template with
+    fewer vertices than those indices address fails here like the reference's native module does on them."""
     global _template_verts, _template_faces, _template_c_indices, _template_corres, _solver
     _template_verts = np.asarray(verts, np.float32).reshape(-1, 3)
     _template_faces = np.asarray(faces, np.uint32).reshape(-1, 3)
-    _template_c_indices = [] if c_indices is None else list(c_indices)
+    if c_indices is None:
+        from .datasets.vocaset_mask import non_face_verts
+        c_indices = non_face_verts()
+    _template_c_indices = [int(i) for i in c_indices]
     _template_corres = None if corres is None else {k: list(corres[k]) for k in ("corr_count", "corr_faces")}
     if _template_corres is None:
         _solver = MeshSolver(_template_verts, _template_faces, _template_c_indices)

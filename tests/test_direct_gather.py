@@ -53,10 +53,18 @@ def _rank(rank, world, port, q):
     z = torch.from_numpy(rs.normal(0, 1, (n, 512)).astype(np.float32)).cuda()
     spk = torch.from_numpy(rs.randint(0, 8, n)).cuda()
     g = sd.DirectGatherer(counts, eng.out_dim, "cuda:0")
-    for step in range(2):
-        sd.run_chunks(n, 64, None, lambda f0, f1: eng.regress_multi(z[f0:f1], spk[f0:f1], g.dest_views(f0, f1), check_ids=False))
+    held = []
+    for step in range(3):                                                   # step-varying rows: a stale or overwritten buffer would show
+        zs = z * float(step + 1)
+        g.begin_step()
+        sd.run_chunks(n, 64, None, lambda f0, f1: eng.regress_multi(zs[f0:f1], spk[f0:f1], g.dest_views(f0, f1), check_ids=False))
         g.finish()
-    _, mine = eng.regress(z, spk)
+        held.append(g.gathered())                                           # a consumer that still holds step k's rows during step k+1
+        if step >= 1:                                                       # the previous step's gathered rows are still intact
+            _, prev = eng.regress(z * float(step), spk)
+            lo = sum(counts[:rank])
+            assert torch.equal(held[step - 1][lo: lo + n], prev)
+    _, mine = eng.regress(z * 3.0, spk)
     q.put((rank, mine.cpu().numpy(), g.gathered().cpu().numpy()))
     dist.barrier()
     dist.destroy_process_group()

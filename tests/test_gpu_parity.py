@@ -238,8 +238,9 @@ def test_error_paths(eng, synth_sd):
     buf = torch.empty(2 * eng.out_dim + 1, device="cuda")
     with pytest.raises(SdfaError, match="16-byte aligned"):
         eng.regress(z, torch.tensor([0, 1]), out=buf[1:].view(2, eng.out_dim))
-    with pytest.raises(RuntimeError, match="out of bounds"):            # CUDA id tensors are validated too
-        eng.regress(z, torch.tensor([0, 9], device="cuda"))
+    with pytest.raises(RuntimeError, match="out of bounds"):            # CUDA id tensors are validated too: without draining the stream,
+        eng.regress(z, torch.tensor([0, 9], device="cuda"))             # so the error surfaces at the next synchronisation point
+        eng.check_pending()
 
 
 def test_gather_front_end_matches_the_per_window_front_end(eng):

@@ -105,6 +105,27 @@ def test_gpu_mesh_at_flame_size_vs_reference_module(golden):
     assert np.array_equal(out[:, cn], np.broadcast_to(g["verts"][cn], out[:, cn].shape))
 
 
+def test_default_constraints_are_the_references_non_face_vertices(golden):
+    """speech_anime/viewer/frame.py:33: no --mesh_constraints file -> non_face.non_face_verts.  The FLAME fixture was made by the
+    reference with exactly that list (oracle/gen_golden_next.py), so it pins the product's generated table."""
+    from speech_anime.datasets.vocaset_mask import non_face_verts
+    assert np.array_equal(non_face_verts(), np.asarray(golden["mesh_flame"]["cnsts"], np.int64))
+
+
+@pytest.mark.gpu
+def test_viewer_without_constraints_file_solves_the_references_default_system(golden):
+    """set_dgrad_static(verts, faces) with c_indices=None must pin the non-face vertices like the reference does --
+    the .obj vertices then equal what the reference module produced with its default constraints."""
+    import torch
+    from speech_anime import viewer
+    g = golden["mesh_flame"]
+    viewer.set_dgrad_static(g["verts"], g["faces"])                                 # no constraints given
+    verts, _ = viewer.frames_to_mesh(torch.from_numpy(flame_rows(g)).cuda().reshape(5, -1), "dgrad_3d")
+    assert np.abs(verts - g["mesh"]).max() <= 2e-6
+    cn = g["cnsts"]
+    assert np.array_equal(verts[:, cn], np.broadcast_to(g["verts"][cn], verts[:, cn].shape))
+
+
 @pytest.mark.gpu
 def test_seek_fused_into_mesh_solve(golden):
     """One post-path stage: uniform query -> binary search -> lerp of two dgrad rows -> rhs / GEMM / scatter, the blended

@@ -17,6 +17,8 @@ class _Stub:
 def test_ops_are_registered_with_schemas():
     assert str(torch.ops.sdfa.encoder.default._schema) == "sdfa::encoder(Tensor audio_feat, str model) -> (Tensor, Tensor)"
     assert str(torch.ops.sdfa.regress.default._schema) == "sdfa::regress(Tensor z, Tensor speaker_id, str model) -> Tensor"
+    assert str(torch.ops.sdfa.encoder_shared.default._schema) == ("sdfa::encoder_shared(Tensor audio_feat, Tensor frame_clip, Tensor frame_start, "
+                                                                   "SymInt hop, str model) -> (Tensor, Tensor)")
     assert "sdfa::mel_frontend(Tensor pcm, Tensor clip_off, Tensor clip_len, Tensor frame_clip, Tensor frame_start" in str(torch.ops.sdfa.mel_frontend.default._schema)
     assert "sdfa::regress_coef" in str(torch.ops.sdfa.regress_coef.default._schema)
 
@@ -32,12 +34,15 @@ def test_frame_index_op_is_the_bit_exact_host_enumeration(golden):
 
 def test_fake_tensor_shapes_without_a_gpu():
     from torch._subclasses.fake_tensor import FakeTensorMode
-    ops.register_model("stub-dgrad", _Stub())
+    stub = _Stub()                                         # the registry holds weak references (an Engine is freed with its owner)
+    ops.register_model("stub-dgrad", stub)
     with FakeTensorMode():
         x = torch.empty((7, 64, 128, 3), device="cuda")
         spk = torch.empty(7, dtype=torch.int64, device="cuda")
         z, al = torch.ops.sdfa.encoder(x, "stub-dgrad")
         assert z.shape == (7, 512) and al.shape == (7, 64) and z.device.type == "cuda"
+        z2, al2 = torch.ops.sdfa.encoder_shared(x, torch.empty(7, dtype=torch.int32, device="cuda"), torch.empty(7, dtype=torch.int64, device="cuda"), 128, "stub-dgrad")
+        assert z2.shape == (7, 512) and al2.shape == (7, 64)
         assert torch.ops.sdfa.regress(z, spk, "stub-dgrad").shape == (7, 89784)
         assert torch.ops.sdfa.regress_coef(z, spk, "stub-dgrad").shape == (7, 265)
         feat = torch.ops.sdfa.mel_frontend(torch.empty(1000, device="cuda"), torch.empty(1, dtype=torch.int64, device="cuda"),
@@ -49,11 +54,33 @@ def test_fake_tensor_shapes_without_a_gpu():
 
 
 def test_device_ops_have_no_cpu_kernel():
-    ops.register_model("stub-dgrad", _Stub())
+    stub = _Stub()
+    ops.register_model("stub-dgrad", stub)
     with pytest.raises(NotImplementedError):
         torch.ops.sdfa.encoder(torch.zeros(1, 64, 128, 3), "stub-dgrad")
     with pytest.raises(KeyError):
         ops._model("never-registered")
+
+
+def test_registry_does_not_keep_dropped_models_alive():
+    """a model object that is dropped frees its Engine (weights + workspace); keys of anonymous models are never reused."""
+    import gc
+    a, b = _Stub(), _Stub()
+    ka, kb = ops.register_model(None, a), ops.register_model(None, b)
+    assert ka != kb and ops._model(ka) is a and ops._model(kb) is b
+    del a
+    gc.collect()
+    with pytest.raises(KeyError):
+        ops._model(ka)
+    assert ops._model(kb) is b
+    kc = ops.register_model(None, b)
+    assert kc not in (ka, kb)
+    owned = ops.register_model("owned-stub", _Stub(), own=True)      # load_model's case: the registry is the owner
+    gc.collect()
+    assert ops._model(owned) is not None
+    ops.unregister_model(owned)
+    with pytest.raises(KeyError):
+        ops._model(owned)
 
 
 @pytest.mark.gpu
@@ -79,6 +106,10 @@ def test_ops_match_engine_and_compose(synth_sd, golden):
                                      torch.tensor([len(pcm)], dtype=torch.int64, device="cuda"),
                                      torch.zeros(len(starts), dtype=torch.int32, device="cuda"), starts.cuda(), 16000)
     assert torch.equal(feat, f2) and ts.tolist() == tslists[0]
+    fc, fs, hop = eng.last_frame_table
+    zs, als = torch.ops.sdfa.encoder_shared(feat, fc, fs, hop, key)
+    zp, alp = torch.ops.sdfa.encoder(feat, key)
+    assert torch.equal(zs, zp) and torch.equal(als, alp)              # column sharing is bitwise the plain encoder
     # dispatcher-visible: torch.compile traces through the fake-tensor shape functions (aot_eager: no code generation needed)
     mod = ops.TraceableSpeechDrivenAnimation(key, "dgrad")
     (s0, r0), z0 = mod(x, spk)

@@ -1,0 +1,152 @@
+"""Round 3: the fast surface -- pinned, overlapped device -> host staging (Engine.forward_host), column sharing and the ensembling
+mean inside generate_animation, multi-clip generate_animation_batch, small-batch kernel selection, reserved CUs.  Everything here
+is a BITWISE statement against the synchronous / single-clip / large-batch forms of the same C-ABI calls, whose parity with the
+reference fixtures tests/test_surface_gpu.py and tests/test_gpu_parity.py hold."""
+import numpy as np
+import pytest
+import torch
+
+from speech_anime.hparams import configure
+from speech_anime.api import build_model
+from speech_anime.datasets import DatasetSlidingWindow
+from sdfa_amd import synth
+from sdfa_amd.engine import Engine
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(sd, sr, head="dgrad"):
+    hp = configure(dict(mode="evaluate", custom_hparams=head))
+    hp.audio.set_key("sample_rate", sr)
+    DatasetSlidingWindow.hparams = None
+    return hp, build_model(hp, sd)
+
+
+@pytest.fixture(scope="module")
+def eng(synth_sd):
+    return Engine(synth_sd["dgrad"], max_frames=512)
+
+
+def test_forward_host_overlapped_is_bitwise_the_synchronous_path(eng):
+    """Pieces of 128 frames, two staging buffers, copies on the copy stream under the next piece's kernels."""
+    sr = 16000
+    feat, _, counts = eng.mel_frontend([synth.make_pcm(3, 3 * sr), synth.make_pcm(4, 2 * sr)], sr)
+    n = feat.shape[0]
+    spk = torch.from_numpy(np.repeat(np.asarray([2, 5], np.int64), counts))
+    ref, z_ref, _, _ = eng.forward(feat, spk)
+    ref = ref.cpu()
+    host = eng.forward_host(feat, spk, piece=128)
+    assert (not host.is_cuda) and host.is_pinned() and torch.equal(host, ref)
+    assert n > 3 * 128                                                    # buffers were reused: at least four pieces
+    # column sharing inside the pipeline: same bits
+    host2, z = eng.forward_host(feat, spk, tables=eng.last_frame_table, piece=128, want_z=True)
+    assert torch.equal(host2, ref) and torch.equal(z, z_ref)
+    # caller-owned pinned output, deferred wait
+    out = torch.empty((n, eng.out_dim), dtype=torch.float32, pin_memory=True)
+    r = eng.forward_host(feat, spk, out=out, piece=256, wait=False)
+    eng.host_wait()
+    assert r is out and torch.equal(out, ref)
+    # one piece: the device copy of the rows stays available (evaluate() seeks on it instead of re-uploading)
+    eng.forward_host(feat[:100], spk[:100], piece=512)
+    assert torch.equal(eng.last_device_rows(100).cpu(), ref[:100])
+    assert eng.last_device_rows(99) is None
+    with pytest.raises(AssertionError):                                   # pageable output: refused (the copy would not be asynchronous)
+        eng.forward_host(feat, spk, out=torch.empty((n, eng.out_dim)))
+
+
+def test_ensemble_mean_has_numpy_float32_roundings(eng):
+    rs = np.random.RandomState(0)
+    for n in (1, 3, 4, 89784 * 3 + 2):
+        a = (rs.standard_normal(n) * 10.0 ** rs.uniform(-20, 3, n)).astype(np.float32)
+        b = (rs.standard_normal(n) * 10.0 ** rs.uniform(-20, 3, n)).astype(np.float32)
+        want = a.copy()
+        want += b
+        want = want / float(2)                                            # model.py:398-403
+        ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+        out = torch.empty_like(ta)
+        eng.ensemble_mean(ta, tb, out=out)
+        assert np.array_equal(out.cpu().numpy(), want)
+        eng.ensemble_mean(ta, tb)                                         # in place
+        assert np.array_equal(ta.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("ens", [0, 20])
+def test_fast_generate_animation_is_bitwise_the_two_step_route(synth_sd, ens):
+    """Default dataset class = device pipeline (shared columns, device ensembling mean, pinned copy); a caller-supplied dataset
+    class = the reference's route (fetch_audio_features to numpy, _feature_to_anime per pass, numpy mean)."""
+    sr = 16000
+    hp, model = _model(synth_sd["dgrad"], sr)
+
+    class Custom(DatasetSlidingWindow):
+        pass
+
+    pcm = synth.make_pcm(7, int(1.3 * sr))
+    ts_a, a, oa = model.generate_animation(pcm, "m1", 0, 0, ensembling_ms=ens)
+    ts_b, b, ob = model.generate_animation(pcm, "m1", 0, 0, ensembling_ms=ens, dataset_class=Custom)
+    assert ts_a == ts_b and a.shape == b.shape == (len(ts_a), 9976, 9) and a.dtype == b.dtype == np.float32
+    assert np.array_equal(a, b)
+    assert np.array_equal(oa["inputs"], ob["inputs"]) and oa["inputs"].shape == (len(ts_a), 3, 128, 64)
+    assert set(oa) == {"inputs", "phones", "latent", "latent_align", "formants"}
+    # results stay valid when the next call reuses the pipeline (fresh pinned block per result)
+    keep = a.copy()
+    model.generate_animation(synth.make_pcm(8, sr), "m1", 0, 0, ensembling_ms=ens)
+    assert np.array_equal(a, keep)
+
+
+def test_generate_animation_batch_equals_clip_by_clip_across_the_kernel_size_switch(synth_sd):
+    """One 2 s clip alone takes the small-batch kernels (128^2-tile frequency projection, 32-frame time-LSTM tiles, few persistent
+    workgroups); inside a batch of 4,608 frames it takes the 256^2 persistent GEMM and full grids.  Same bits."""
+    sr = 16000
+    hp, model = _model(synth_sd["dgrad"], sr)
+    lens = [2.0, 10.0, 10.0, 1.1, 10.0, 10.0, 10.0, 10.0, 10.0, 3.7]
+    clips = [synth.make_pcm(20 + i, int(s * sr), "speechlike" if i % 3 == 0 else "uniform") for i, s in enumerate(lens)]
+    spks = ["m1", 0, 7, "f0", 3, 3, "m0", 5, 1, 2]
+    res = model.generate_animation_batch(clips, spks)
+    assert len(res) == len(clips) and sum(len(r[0]) for r in res) > 4096
+    for i in (0, 3, 9, 1):
+        ts, a, _ = model.generate_animation(clips[i], spks[i], 0, 0, want_inputs=False)
+        assert ts == res[i][0] and np.array_equal(a, res[i][1]), i
+    # ensembling in a batch
+    res2 = model.generate_animation_batch(clips[:4], spks[:4], ensembling_ms=20, want_inputs=True)
+    ts, a, o = model.generate_animation(clips[3], spks[3], 0, 0, ensembling_ms=20)
+    assert ts == res2[3][0] and np.array_equal(a, res2[3][1]) and np.array_equal(o["inputs"], res2[3][2]["inputs"])
+    with pytest.raises(RuntimeError, match="out of bounds"):
+        model.generate_animation_batch(clips[:2], [0, 8])
+
+
+def test_offsets_head_fast_path(synth_sd):
+    sr = 8000
+    hp, model = _model(synth_sd["offsets"], sr, "offsets")
+    pcm = synth.make_pcm(2, 2 * sr)
+    ts, a, _ = model.generate_animation(pcm, 2, 0, 0)
+    assert a.shape == (len(ts), 15069)
+    eng = model._model._engine
+    feat, _, _ = eng.mel_frontend([pcm], sr)
+    ref, *_ = eng.forward(feat, torch.full((len(ts),), 2, dtype=torch.int64))
+    assert np.array_equal(a, ref.cpu().numpy())
+
+
+def test_device_speaker_ids_are_validated_without_a_sync(eng):
+    z = torch.zeros((2, 512), device="cuda")
+    eng.regress(z, torch.tensor([0, 7], device="cuda"))
+    eng.check_pending()                                                   # in range: nothing
+    eng.regress(z, torch.tensor([0, 9], device="cuda"))                   # clamped on the device, flagged asynchronously
+    with pytest.raises(RuntimeError, match="out of bounds"):
+        eng.check_pending()
+    eng.check_pending()                                                   # reported once
+    with pytest.raises(RuntimeError, match="out of bounds"):             # asked for: checked at once
+        eng.regress(z, torch.tensor([-1, 3], device="cuda"), check_ids=True)
+
+
+def test_reserved_cus_do_not_change_results(synth_sd):
+    sr = 16000
+    e = Engine(synth_sd["dgrad"], max_frames=2048)
+    feat, _, _ = e.mel_frontend([synth.make_pcm(i, 10 * sr) for i in range(3)], sr)
+    spk = torch.full((feat.shape[0],), 2, dtype=torch.int64)
+    ref, z, *_ = e.forward(feat, spk)
+    e.set_reserved_cus(24)
+    out, z2, *_ = e.forward(feat, spk)
+    assert torch.equal(out, ref) and torch.equal(z, z2)
+    from sdfa_amd._lib import SdfaError
+    with pytest.raises(SdfaError):
+        e.set_reserved_cus(200)
