@@ -28,6 +28,12 @@ import numpy as np
 # dmabuf IPC (the only kind this pool's driver supports) must be selected BEFORE anything initialises HSA: torch.cuda.set_device()
 # below already does, so this cannot wait until the process group is created (VERDICT r2 / ADVICE r2)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# HIP maps streams onto a few hardware queues (4 by default) and two streams that share a queue run one after the other.  Measured
+# on MI355X (profiles/r03_overlap_env.txt): with the defaults the stream torch's RCCL process group communicates on lands on the
+# SAME queue as the default stream -- the per-chunk asynchronous all-gather then ran 0 % under the compute kernels; with more
+# hardware queues, or a high-priority communication stream, 85 %.  Both must be in the environment before the runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "sdfa-2019_amd"))
@@ -77,6 +83,9 @@ def parse():
     ap.add_argument("--reserve-cus", type=int, default=0, help="CUs the persistent kernels leave to other streams (sdfa_model_set_reserved_cus)")
     ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive twin (H2D of PCM + D2H of the rows inside the step)")
     ap.add_argument("--no-surface", action="store_true", help="skip the speech_anime surface block (generate_animation frames/s)")
+    ap.add_argument("--compute-stream", choices=["default", "side"], default="default",
+                    help="side = run everything on a freshly created HIP stream instead of the default stream (HIP maps streams onto a "
+                         "few hardware queues; two streams on one queue serialise -- see DESIGN.md section 5)")
     ap.add_argument("--cpu-sample-seconds", type=float, default=10.0)
     return ap.parse_args()
 
@@ -216,6 +225,8 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     local_dev = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_dev)
+    if a.compute_stream == "side":
+        torch.cuda.set_stream(torch.cuda.Stream(device=local_dev))
     dev = torch.device("cuda", local_dev)
     dist_on = world > 1 or a.force_gather          # the exchange runs: N > 1, or the one-GPU rehearsal of it
     if dist_on:
@@ -421,7 +432,7 @@ def main():
         def step_host(k, share):
             pcm.copy_(pcm_host, non_blocking=True)                       # H2D of this step's PCM (1 KB per frame)
             eng.mel_frontend_device(pcm, clip_off, clip_len, frame_clip, frame_start, sr, out=feat, gather=(a.frontend == "gather"))
-            eng.forward_host(feat, spk, out=outs_host[k & 1], tables=table if share else None, piece=a.chunk, wait=False)
+            eng.forward_host(feat, spk, out=outs_host[k & 1], table=table if share else None, piece=a.chunk, wait=False)
 
         host_io = {}
         for name, share in (("fp32", False),) + ((("fp32_column_sharing", True),) if not a.no_column_sharing else ()):

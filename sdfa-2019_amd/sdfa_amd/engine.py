@@ -299,27 +299,25 @@ class Engine(FrontendOnly):
         check(lib.sdfa_ensemble_mean(_ptr(a), _ptr(b), a.numel(), _ptr(out), _stream()))
         return out
 
-    def forward_host(self, feats, speaker_id, out=None, tables=None, piece=None, wait=True, want_z=False, ops_key=None):
+    def forward_host(self, feat, speaker_id, out=None, table=None, piece=None, wait=True, want_z=False, ops_key=None, ensemble=False):
         """The whole model for `n` frames with the output rows delivered to PINNED HOST memory: rows (n, out_dim) as a CPU
         tensor (`.numpy()` is a view).  Frames are processed in pieces of `piece` (default max_frames) frames; piece i's rows
         are copied device -> host on a copy stream while piece i+1 computes (two device staging buffers), so for more than one
         piece the PCIe transfer hides behind the kernels.  This is what SaberSpeechDrivenAnimation._feature_to_anime
         (speech_anime/model/model.py:428-489) does with `.cpu().numpy()` per batch of 100 frames.
 
-          feats       audio_feat (n,64,128,3) cuda, or a list of two such tensors: the two passes of test-time ensembling
-                      (model.py:369-403), whose rows are averaged on the device before the copy
+          feat        audio_feat (n,64,128,3) cuda -- or, with `ensemble`, (2n,64,128,3): the frames of the two passes of
+                      test-time ensembling (model.py:369-403) one after the other; both passes run in ONE launch group and
+                      their rows are averaged on the device before the copy
           speaker_id  (n,) int64 tensor (any device) or one int
-          tables      per pass (frame_clip int32 (n,), frame_start int64 (n,), hop): run the per-column stages once per
+          table       (frame_clip int32, frame_start int64, hop) of `feat`'s frames: run the per-column stages once per
                       distinct column (bitwise identical, sdfa_encoder_forward_shared)
           out         pinned float32 CPU tensor (n, out_dim) to fill (allocated from PyTorch's pinned-memory cache otherwise)
           wait        False: return as soon as everything is enqueued; call `host_wait()` before reading `out`
           ops_key     key of this engine in sdfa_amd.ops' registry: the kernels are then called through the dispatcher-visible
                       PyTorch-ROCm custom operators torch.ops.sdfa.{encoder, encoder_shared, regress_into} (same C ABI calls)"""
-        feats = list(feats) if isinstance(feats, (list, tuple)) else [feats]
-        assert 1 <= len(feats) <= 2
-        n = int(feats[0].shape[0])
-        if tables is not None and not isinstance(tables, list):
-            tables = [tables] * len(feats)
+        n = int(feat.shape[0]) // (2 if ensemble else 1)
+        assert feat.shape[0] == (2 * n if ensemble else n)
         self._validate_ids(speaker_id, None)
         if not torch.is_tensor(speaker_id):
             speaker_id = torch.full((n,), int(speaker_id), dtype=torch.int64, device=self.device)
@@ -331,7 +329,10 @@ class Engine(FrontendOnly):
         assert (not out.is_cuda) and out.is_pinned() and out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (n, self.out_dim)
         if self._host is None:
             self._host = HostPipeline(self)
-        zs = self._host.run(feats, speaker_id, out, tables, int(piece or self.max_frames), want_z, ops_key)
+        piece = int(piece or self.max_frames)
+        if ensemble:
+            piece = max(1, piece // 2)                  # a piece holds both passes of its frames
+        zs = self._host.run(feat, speaker_id, out, table, piece, want_z, ops_key, ensemble)
         if wait:
             self.host_wait()
         return (out, zs) if want_z else out
@@ -383,8 +384,8 @@ class Engine(FrontendOnly):
 class HostPipeline:
     """Pinned-output staging of Engine.forward_host: two device row buffers, one copy stream.
 
-    compute stream:  [piece 0: encoder + regress -> buf 0] [piece 1 -> buf 1] [piece 2 -> buf 0, after copy 0] ...
-    copy stream:                                  [buf 0 -> host rows 0..p)  ] [buf 1 -> host ...]
+    compute stream:  [piece 0: encoder | regress -> buf 0] [piece 1: encoder | regress -> buf 1] [piece 2: encoder | wait copy 0 | regress -> buf 0] ...
+    copy stream:                                          [buf 0 -> host rows 0..p)             ] [buf 1 -> host ...]
     The device -> host copies are plain hipMemcpyAsync to pinned memory (SDMA engines): they take no CU from the kernels."""
 
     def __init__(self, engine):
@@ -395,6 +396,7 @@ class HostPipeline:
         self.done = [None, None]        # copy-done event of the last copy out of each buffer
         self.extra = []                 # copy-done events of stage_out copies
         self._last = None
+        self._next = 0                  # running piece counter: staging buffer = parity
 
     def _buf(self, slot, rows):
         b = self.bufs[slot]
@@ -403,42 +405,52 @@ class HostPipeline:
             self.bufs[slot] = b = torch.empty((rows, self.eng.out_dim), dtype=torch.float32, device=self.eng.device)
         return b
 
-    def run(self, feats, spk, out, tables, piece, want_z, ops_key=None):
+    def run(self, feat, spk, out, table, piece, want_z, ops_key=None, ensemble=False):
         eng = self.eng
-        n = int(feats[0].shape[0])
+        n = int(out.shape[0])
         cur = torch.cuda.current_stream(eng.device)
         zs = []
         self._last = None
-        for i, f0 in enumerate(range(0, n, piece)):
+        for f0 in range(0, n, piece):
             f1 = min(n, f0 + piece)
-            slot = i & 1
-            if self.done[slot] is not None:
-                cur.wait_event(self.done[slot])         # the copy that last read this buffer
-            rows = self._buf(slot, min(piece, n))[: f1 - f0]
-            for p, feat in enumerate(feats):
-                t = tables[p] if tables is not None else None
-                dst = rows
-                if p:
-                    if self.tmp is None or self.tmp.shape[0] < f1 - f0:
-                        self.tmp = None
-                        self.tmp = torch.empty((min(piece, n), eng.out_dim), dtype=torch.float32, device=eng.device)
-                    dst = self.tmp[: f1 - f0]
-                if ops_key is not None:         # through the dispatcher (torch.ops.sdfa.*): same Engine methods underneath
-                    if t is None:
-                        z, _ = torch.ops.sdfa.encoder(feat[f0:f1], ops_key)
-                    else:
-                        z, _ = torch.ops.sdfa.encoder_shared(feat[f0:f1], t[0][f0:f1], t[1][f0:f1], int(t[2]), ops_key)
-                    torch.ops.sdfa.regress_into(z, spk[f0:f1], dst, ops_key)
+            m = f1 - f0
+            slot = self._next & 1                       # alternates across calls too: a call's last copy overlaps the next call's first piece
+            self._next += 1
+            rows = self._buf(slot, min(piece, n))[:m]
+            if ensemble:                                # pass 1 = frames [f0, f1), pass 2 = frames [n + f0, n + f1): ONE launch group for both
+                x = torch.cat((feat[f0:f1], feat[n + f0:n + f1]))
+                t = None if table is None else (torch.cat((table[0][f0:f1], table[0][n + f0:n + f1])), torch.cat((table[1][f0:f1], table[1][n + f0:n + f1])), table[2])
+                ids = torch.cat((spk[f0:f1], spk[f0:f1]))
+                if self.tmp is None or self.tmp.shape[0] < 2 * m:
+                    self.tmp = None
+                    self.tmp = torch.empty((2 * min(piece, n), eng.out_dim), dtype=torch.float32, device=eng.device)
+                dst = self.tmp[:2 * m]
+            else:
+                x, ids, dst = feat[f0:f1], spk[f0:f1], rows
+                t = None if table is None else (table[0][f0:f1], table[1][f0:f1], table[2])
+            if ops_key is not None:                     # through the dispatcher (torch.ops.sdfa.*): same Engine methods underneath
+                if t is None:
+                    z, _ = torch.ops.sdfa.encoder(x, ops_key)
                 else:
-                    if t is None:
-                        z, _ = eng.encoder(feat[f0:f1], want_align=False)
-                    else:
-                        z, _ = eng.encoder(feat[f0:f1], want_align=False, frame_clip=t[0][f0:f1], frame_start=t[1][f0:f1], hop=t[2])
-                    eng.regress(z, spk[f0:f1], out=dst, check_ids=False)
-                if p:
-                    eng.ensemble_mean(rows, dst)
-                elif want_z:
-                    zs.append(z)
+                    z, _ = torch.ops.sdfa.encoder_shared(x, t[0], t[1], int(t[2]), ops_key)
+            elif t is None:
+                z, _ = eng.encoder(x, want_align=False)
+            else:
+                z, _ = eng.encoder(x, want_align=False, frame_clip=t[0], frame_start=t[1], hop=t[2])
+            # the first kernel that WRITES the staging rows: only now wait for the copy that last read them (it has had the
+            # whole encoder of this piece to finish)
+            if self.done[slot] is not None and not ensemble:
+                cur.wait_event(self.done[slot])
+            if ops_key is not None:
+                torch.ops.sdfa.regress_into(z, ids, dst, ops_key)
+            else:
+                eng.regress(z, ids, out=dst, check_ids=False)
+            if ensemble:
+                if self.done[slot] is not None:
+                    cur.wait_event(self.done[slot])
+                eng.ensemble_mean(dst[:m], dst[m:], out=rows)
+            if want_z:
+                zs.append(z[:m])
             ready = torch.cuda.Event()
             ready.record(cur)
             self.copy_stream.wait_event(ready)

@@ -185,21 +185,21 @@ class SaberSpeechDrivenAnimation:
             assert isinstance(spk, (int, np.integer)), f"given index is {spk}, {type(spk)}"
             eng.check_speaker_ids(int(spk))
         tables = [frame_index(len(s), sr) for s in signals]             # ONE enumeration per clip (starts, tslist)
-        passes = [signals]
-        if ensembling_ms is not None and ensembling_ms > 0:            # model.py:373-384: second pass on a delayed copy
-            pad = ensembling_ms * sr // 1000
-            passes.append([np.pad(s[:-pad], [[pad, 0]], "constant") for s in signals])
-        feats, share = [], []
-        for clips in passes:
-            feat, tslists, counts = eng.mel_frontend(clips, sr, tables=tables)
-            feats.append(feat)
-            share.append(eng.last_frame_table)                          # (clip, start, hop): the per-column stages run once per distinct column
+        clips = list(signals)
+        ensemble = ensembling_ms is not None and ensembling_ms > 0
+        if ensemble:                                                    # model.py:373-384: second pass on a delayed copy --
+            pad = ensembling_ms * sr // 1000                            # here as further clips of the same launch group
+            clips += [np.pad(s[:-pad], [[pad, 0]], "constant") for s in signals]
+            tables = tables + tables
+        feat, tslists, counts = eng.mel_frontend(clips, sr, tables=tables)
+        share = eng.last_frame_table                                    # (clip, start, hop): the per-column stages run once per distinct column
+        tslists, counts = tslists[:len(signals)], counts[:len(signals)]
         n = int(sum(counts))
         spk = torch.from_numpy(np.repeat(np.asarray(speakers, np.int64), counts)).to(eng.device, non_blocking=True)
         inputs_host = None
         if want_inputs:                                                 # others["inputs"] = audio_feat.permute(0, 3, 2, 1), model.py:463-466
-            inputs_host = eng.to_host_async(feats[0].permute(0, 3, 2, 1))
-        rows = eng.forward_host(feats, spk, tables=share, ops_key=self._model._key, wait=True)
+            inputs_host = eng.to_host_async(feat[:n].permute(0, 3, 2, 1))
+        rows = eng.forward_host(feat, spk, table=share, ops_key=self._model._key, wait=True, ensemble=ensemble)
         shape = (-1, 9) if self._face_type == "dgrad_3d" else ()
         out, f0 = [], 0
         rows_np = rows.numpy()

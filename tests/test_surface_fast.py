@@ -28,18 +28,18 @@ def eng(synth_sd):
 
 
 def test_forward_host_overlapped_is_bitwise_the_synchronous_path(eng):
-    """Pieces of 128 frames, two staging buffers, copies on the copy stream under the next piece's kernels."""
+    """Pieces of 64 frames, two staging buffers, copies on the copy stream under the next piece's kernels."""
     sr = 16000
     feat, _, counts = eng.mel_frontend([synth.make_pcm(3, 3 * sr), synth.make_pcm(4, 2 * sr)], sr)
     n = feat.shape[0]
     spk = torch.from_numpy(np.repeat(np.asarray([2, 5], np.int64), counts))
     ref, z_ref, _, _ = eng.forward(feat, spk)
     ref = ref.cpu()
-    host = eng.forward_host(feat, spk, piece=128)
+    host = eng.forward_host(feat, spk, piece=64)
     assert (not host.is_cuda) and host.is_pinned() and torch.equal(host, ref)
-    assert n > 3 * 128                                                    # buffers were reused: at least four pieces
+    assert n > 3 * 64                                                     # buffers were reused: at least four pieces
     # column sharing inside the pipeline: same bits
-    host2, z = eng.forward_host(feat, spk, tables=eng.last_frame_table, piece=128, want_z=True)
+    host2, z = eng.forward_host(feat, spk, table=eng.last_frame_table, piece=64, want_z=True)
     assert torch.equal(host2, ref) and torch.equal(z, z_ref)
     # caller-owned pinned output, deferred wait
     out = torch.empty((n, eng.out_dim), dtype=torch.float32, pin_memory=True)
