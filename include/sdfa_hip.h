@@ -229,8 +229,22 @@ int sdfa_ensemble_mean(const float *d_a, const float *d_b, int64_t n, float *d_o
 /* Debug / parity taps: copy an intermediate activation of the LAST sdfa_encoder_forward call out of
  * the workspace in the reference's layout.  what: 0 = pool1 (n,32,64,64)  1 = conv3 (n,64,32,64)
  * 2 = freq-lstm (n,256,64)  3 = bilstm (n,64,512).  Used by tests only. */
-int sdfa_debug_set_option(const char *name, int value);     /* tuning switches for A/B runs, e.g. "gemm_variant";
-                                                                THREAD-LOCAL: affects the calling thread's launches only */
+/* Tuning switches for A/B runs.  THREAD-LOCAL: a switch affects the launches made by the calling thread only (so a thread that
+ * flips one cannot change what concurrent callers launch; bench.py --opt and the tests set them on the thread that calls the
+ * forward).  Every choice of a switch gives bit-identical results unless stated.  Unknown names return SDFA_EINVAL.
+ *   name               values
+ *   "freq_lstm_shape"  0 = the model's form (9 unless sdfa_model_autotune picked another); 9 = freq_lstm_v3_kernel persistent, one
+ *                      workgroup per CU; 8 = the same kernel, one hardware-dispatched workgroup per tile; 5 = freq_lstm_v2_kernel
+ *                      persistent, two workgroups per CU; 3 = freq_lstm_v2_kernel hardware-dispatched (the fallback that shares a CU)
+ *   "gemm_variant"     0 = per-shape default (gemm_fat_kernel where 256 x 256 tiles fill the chip twice, else the 128 x 128 LDS-tiled
+ *                      kernel; 256 x 256 gemm_big_kernel for the 8192-deep projection at mid sizes); 9 = never the persistent fat
+ *                      kernel (two-workgroups-per-CU fallback); 8 = fat wherever it fits; 5 = 256 x 256 tile wherever it fits;
+ *                      4 = split-bf16 x3 products (NOT exact fp32)
+ *   "pca_lds"          0 = pca_dgrad_res_kernel (basis slab resident in LDS, persistent); 4 = pca_dgrad_kernel (register-direct, two
+ *                      workgroups per CU: the fallback that shares a CU)
+ *   "pca_unfused"      1 = the dgrad PCA expansion as two generic GEMM launches with the scatter epilogue (round-1 form)
+ *   "conv_unfused"     1 = conv1_pool_kernel + conv23_kernel instead of the fused conv123_kernel (what the debug taps use)   */
+int sdfa_debug_set_option(const char *name, int value);
 int sdfa_debug_keep_intermediates(sdfa_model *m, int on);   /* un-aliased workspace: call before sizing it */
 /* Number of distinct columns the LAST sdfa_encoder_forward_shared call evaluated for a chunk of n_frames frames
  * (synchronises the stream).  Tests / reporting only. */

@@ -707,19 +707,18 @@ int64_t sdfa_workspace_bytes(const sdfa_model *m, int64_t max_frames) {
 }
 
 // A/B tuning switches: THREAD-LOCAL, so that a thread that flips one for an experiment cannot change what concurrent
-// callers on other threads launch (the header promises thread-safe concurrent use of the forward calls).
+// callers on other threads launch (the header promises thread-safe concurrent use of the forward calls).  The table is
+// documented next to sdfa_debug_set_option in include/sdfa_hip.h.
 extern thread_local int g_sdfa_gemm_variant;
 thread_local int g_sdfa_freq_lstm_shape = 0;
 thread_local int g_sdfa_pca_unfused = 0;
 thread_local int g_sdfa_conv_unfused = 0;
-thread_local int g_sdfa_time_lstm_shape = 0;
 thread_local int g_sdfa_pca_lds = 0;
 int sdfa_debug_set_option(const char *name, int value) {
     if (name && !strcmp(name, "gemm_variant")) { g_sdfa_gemm_variant = value; return SDFA_OK; }
     if (name && !strcmp(name, "freq_lstm_shape")) { g_sdfa_freq_lstm_shape = value; return SDFA_OK; }
     if (name && !strcmp(name, "pca_unfused")) { g_sdfa_pca_unfused = value; return SDFA_OK; }
     if (name && !strcmp(name, "conv_unfused")) { g_sdfa_conv_unfused = value; return SDFA_OK; }
-    if (name && !strcmp(name, "time_lstm_shape")) { g_sdfa_time_lstm_shape = value; return SDFA_OK; }
     if (name && !strcmp(name, "pca_lds")) { g_sdfa_pca_lds = value; return SDFA_OK; }
     return fail(SDFA_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }
@@ -809,7 +808,7 @@ int sdfa_model_autotune(sdfa_model *m, int64_t n_frames, void *d_workspace, int6
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    static const int forms[] = {9, 8, 5, 3};      // third form persistent / hardware-dispatched; second form persistent / hardware-dispatched (two per CU)
+    static const int forms[] = {9, 8, 5, 3};      // third kernel persistent / hardware-dispatched; second kernel persistent / hardware-dispatched (two per CU)
     float best_ms = 0.f;
     int best = m->freq_shape.load(), rc = SDFA_OK;
     for (int form : forms) {
@@ -964,8 +963,8 @@ static hipError_t expand_rows(const sdfa_model *m, const float *coef, int64_t N,
         for (int x = 1; x < n_outs; ++x) pa.out_extra[x - 1] = h_d_outs[x] + f0 * m->out_dim;
         pa.ld_s = m->pca_ld[0]; pa.ld_r = m->pca_ld[1]; pa.cols_s = m->pca_cols[0]; pa.cols_r = m->pca_cols[1];
         // default: basis slab resident in LDS, persistent work units (pca_dgrad_res_kernel); "pca_lds" option 4 = the register-
-        // direct form of rounds 1-2, 1 = the slab staged through LDS per k-block stage (both bit-identical, slower)
-        if ((g_sdfa_pca_lds == 0 || g_sdfa_pca_lds == 3) && queue) return sdfa_launch_pca_dgrad_res(pa, queue, s);
+        // direct two-workgroups-per-CU form of rounds 1-2 (bit-identical, slower: the fallback that shares a CU)
+        if (g_sdfa_pca_lds != 4 && queue) return sdfa_launch_pca_dgrad_res(pa, queue, s);
         return sdfa_launch_pca_dgrad(pa, s);
     }
     for (int b = 0; b < m->pca_n; ++b) {

@@ -64,7 +64,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs &a, const f32x16 &acc,
 }
 
 
-template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND, bool DMA = false>
+template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
 __global__ __launch_bounds__(256, 2) void gemm_k4_kernel(GemmArgs a) {
     __shared__ float4 sP[2][KQ][TP];
     __shared__ float4 sQ[2][KQ][TQ];
@@ -130,19 +130,6 @@ __global__ __launch_bounds__(256, 2) void gemm_k4_kernel(GemmArgs a) {
     }
 #define GEMM_LSTORE_A(buf) GEMM_LSTORE1(buf, 0, ra0, rb0) GEMM_LSTORE1(buf, 1, ra1, rb1) GEMM_LSTORE1(buf, 2, ra2, rb2) GEMM_LSTORE1(buf, 3, ra3, rb3)
 #define GEMM_LSTORE_B(buf) GEMM_LSTORE1(buf, 0, rc0, rd0) GEMM_LSTORE1(buf, 1, rc1, rd1) GEMM_LSTORE1(buf, 2, rc2, rd2) GEMM_LSTORE1(buf, 3, rc3, rd3)
-    // DMA variant: tiles go HBM/L2 -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction, no VGPR
-    // staging and no ds_write); wave w, piece i fills k-quad row 2i + (w>>1), columns (w&1)*64 .. +63.
-#define GEMM_DMA(st, buf)                                                                                        \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
-        const int kq = 2 * i + (wave >> 1), c0 = (wave & 1) * 64, gkq = (st)*KQ + kq;                            \
-        const int seg = gkq / seg_kq, kin = gkq - seg * seg_kq;                                                  \
-        __builtin_amdgcn_global_load_lds(                                                                        \
-            (const void __attribute__((address_space(1))) *)(P + (int64_t)gkq * a.ldp + p0 + c0 + lane),         \
-            (void __attribute__((address_space(3))) *)(&sP[buf][kq][c0]), 16, 0, 0);                             \
-        __builtin_amdgcn_global_load_lds(                                                                        \
-            (const void __attribute__((address_space(1))) *)(Q + (int64_t)kin * a.ldq + (int64_t)seg * a.seg_col + q0 + c0 + lane), \
-            (void __attribute__((address_space(3))) *)(&sQ[buf][kq][c0]), 16, 0, 0);                             \
-    }
 #define GEMM_COMPUTE(buf)                                                                                              \
     _Pragma("unroll") for (int kb = 0; kb < KQ / 2; ++kb) {                                                            \
         const float4 fa[2] = {sP[buf][2 * kb + h][wp * 64 + l31], sP[buf][2 * kb + h][wp * 64 + 32 + l31]};            \
@@ -158,16 +145,7 @@ __global__ __launch_bounds__(256, 2) void gemm_k4_kernel(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (DMA) {
-        GEMM_DMA(0, 0)
-        __syncthreads();
-        for (int st = 0; st < nstage; ++st) {
-            const int buf = st & 1;
-            if (st + 1 < nstage) { GEMM_DMA(st + 1, buf ^ 1) }
-            GEMM_COMPUTE(buf)
-            __syncthreads();   // also drains the LDS-DMA of the next tile (vmcnt(0) is part of the barrier's fence)
-        }
-    } else {
+    {
 #ifdef SDFA_STAMPS
         // DIAGNOSTIC BUILD ONLY (make STAMPS=1): where do a stage's cycles go?  s_memtime around each phase, summed per wave.
         unsigned long long t0, t1, t2, t3, t4, sum_load = 0, sum_mfma = 0, sum_store = 0, sum_bar = 0;
@@ -217,84 +195,10 @@ __global__ __launch_bounds__(256, 2) void gemm_k4_kernel(GemmArgs a) {
             store_tile<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, acc[i][j], p0 + wp * 64 + i * 32, q0 + wq * 64 + j * 32 + l31, h);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Register-direct variant: no LDS, no barriers.  Every wave owns a (32*MT) x 64 output tile and pulls
-// both operands straight from L1/L2 into VGPRs as K4 quads (one global_load_dwordx4 per operand per
-// k-block of 8, requested one k-block ahead of the MFMAs that consume it).  The four waves of a
-// workgroup take adjacent column tiles of the same row block, so the P (weight) quads of the second to
-// fourth wave are L1 hits.  fp32 MFMA consumes so few operand bytes per cycle (2 dwords per lane per
-// 64 cycles) that the cache path keeps up, and the waves never wait for each other.
-// ------------------------------------------------------------------------------------------------
-template <int MT, int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
-__global__ __launch_bounds__(256, 2) void gemm_direct_kernel(GemmArgs a) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int64_t ntq = (a.Qpad + 255) / 256;
-    const int64_t bid = blockIdx.x;
-    const int64_t p0 = (bid / ntq) * (32 * MT), q0 = (bid % ntq) * 256 + wave * 64;
-    if (q0 >= a.Qpad) return;
-    if (a.q_limit && q0 >= *a.q_limit) return;
-
-    const float4 *__restrict__ P = reinterpret_cast<const float4 *>(a.P) + p0 + l31;
-    const float4 *__restrict__ Q = reinterpret_cast<const float4 *>(a.Q) + q0 + l31;
-    const int nkb = a.K / 8, seg_kb = a.seg_k / 8;
-
-    f32x16 acc[MT][2];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // running operand pointers: one 64-bit add per operand per k-block, everything else is an immediate offset
-    const int64_t pstep = 2 * a.ldp, qstep = 2 * a.ldq;
-    const float4 *pp = P + (int64_t)h * a.ldp;
-    const float4 *qq = Q + (int64_t)h * a.ldq;
-    int kin = 0, seg = 0;
-    float4 an[MT], bn[2];
-#define GD_LOAD()                                                        \
-    {                                                                    \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i) an[i] = pp[i * 32]; \
-        bn[0] = qq[0]; bn[1] = qq[32];                                   \
-        pp += pstep;                                                     \
-        if (++kin == seg_kb) { kin = 0; ++seg; qq = Q + (int64_t)h * a.ldq + (int64_t)seg * a.seg_col; } \
-        else qq += qstep;                                                \
-    }
-    GD_LOAD()
-#pragma unroll 2
-    for (int kb = 0; kb < nkb; ++kb) {
-        float4 ac[MT], bc[2];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) ac[i] = an[i];
-        bc[0] = bn[0]; bc[1] = bn[1];
-        if (kb + 1 < nkb) GD_LOAD()
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            mfma4(acc[i][0], ac[i], bc[0]);
-            mfma4(acc[i][1], ac[i], bc[1]);
-        }
-    }
-#undef GD_LOAD
-
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            store_tile<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, acc[i][j], p0 + i * 32, q0 + j * 32 + l31, h);
-}
-
-template <int MT, int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
-hipError_t launch_direct(const GemmArgs &a, hipStream_t s) {
-    const int64_t nblk = (a.Ppad / (32 * MT)) * ((a.Qpad + 255) / 256);
-    hipLaunchKernelGGL((gemm_direct_kernel<MT, OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>), dim3((unsigned)nblk), dim3(256), 0, s, a);
-    return hipGetLastError();
-}
-
-template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND, bool DMA = false>
+template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
 hipError_t launch(const GemmArgs &a, hipStream_t s) {
     int64_t nblk = (a.Ppad / TP) * (a.Qpad / TQ);
-    hipLaunchKernelGGL((gemm_k4_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, DMA>), dim3((unsigned)nblk), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((gemm_k4_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>), dim3((unsigned)nblk), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -924,88 +828,6 @@ hipError_t launch_fat(const GemmArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------------
-// Producer / consumer variant (gemm_variant 6): 4 MFMA waves + 2 loader waves per workgroup.  The in-kernel stamps
-// showed an MFMA wave losing ~3,900 of 10,600 cycles per stage just ISSUING its eight global loads (the CU's miss
-// path is latency-bound when an operand streams from HBM) -- an in-order wave issues no MFMAs meanwhile.  Here the
-// MFMA waves never execute a vector-memory instruction: waves 4 and 5 move the next tile HBM/L2 -> LDS with LDS-DMA
-// (global_load_lds_dwordx4, 16 x 1 KiB pieces each) and absorb the queueing; one workgroup barrier per stage.
-// ------------------------------------------------------------------------------------------------
-template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
-__global__ __launch_bounds__(384) void gemm_pc_kernel(GemmArgs a) {
-    __shared__ float4 sP[2][KQ][TP];
-    __shared__ float4 sQ[2][KQ][TQ];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t ntp = a.Ppad / TP, bid = blockIdx.x;
-    const int64_t p0 = (bid % ntp) * TP, q0 = (bid / ntp) * TQ;
-    if (a.q_limit && q0 >= *a.q_limit) return;
-    const float4 *__restrict__ P = reinterpret_cast<const float4 *>(a.P);
-    const float4 *__restrict__ Q = reinterpret_cast<const float4 *>(a.Q);
-    const int nkq_total = a.K / 4, seg_kq = a.seg_k / 4, nstage = nkq_total / KQ;
-
-    if (wave >= 4) {
-        // ---------------- loader waves: wave 4 fills k-quad rows 0..3 of a tile, wave 5 rows 4..7
-        const int pw = wave - 4;
-#define PC_DMA(st, buf)                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
-            const int kq = 4 * pw + i, gkq = (st)*KQ + kq;                                                         \
-            const int seg = gkq / seg_kq, kin = gkq - seg * seg_kq;                                                \
-            _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) {                                                     \
-                const int c0 = hf * 64;                                                                            \
-                __builtin_amdgcn_global_load_lds(                                                                  \
-                    (const void __attribute__((address_space(1))) *)(P + (int64_t)gkq * a.ldp + p0 + c0 + lane),   \
-                    (void __attribute__((address_space(3))) *)(&sP[buf][kq][c0]), 16, 0, 0);                       \
-                const float4 *qsrc = a.q_tile_major ? Q + ((q0 >> 7) * (int64_t)a.q_slab_rows + gkq) * 128 + c0 + lane \
-                                                    : Q + (int64_t)kin * a.ldq + (int64_t)seg * a.seg_col + q0 + c0 + lane; \
-                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)qsrc,             \
-                                                 (void __attribute__((address_space(3))) *)(&sQ[buf][kq][c0]), 16, 0, 0); \
-            }                                                                                                      \
-        }
-        PC_DMA(0, 0)
-        __syncthreads();
-        for (int st = 0; st < nstage; ++st) {
-            if (st + 1 < nstage) { PC_DMA(st + 1, (st & 1) ^ 1) }
-            __syncthreads();   // the barrier's fence drains this wave's LDS-DMA (vmcnt(0)): tile st+1 is in LDS for everyone
-        }
-#undef PC_DMA
-        return;
-    }
-    // ---------------- MFMA waves
-    const int wp = wave >> 1, wq = wave & 1, l31 = lane & 31, h = lane >> 5;
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    __syncthreads();
-    for (int st = 0; st < nstage; ++st) {
-        const int buf = st & 1;
-#pragma unroll
-        for (int kb = 0; kb < KQ / 2; ++kb) {
-            const float4 a0 = sP[buf][2 * kb + h][wp * 64 + l31], a1 = sP[buf][2 * kb + h][wp * 64 + 32 + l31];
-            const float4 b0 = sQ[buf][2 * kb + h][wq * 64 + l31], b1 = sQ[buf][2 * kb + h][wq * 64 + 32 + l31];
-            mfma4(acc[0][0], a0, b0); mfma4(acc[0][1], a0, b1);
-            mfma4(acc[1][0], a1, b0); mfma4(acc[1][1], a1, b1);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            store_tile<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, acc[i][j], p0 + wp * 64 + i * 32, q0 + wq * 64 + j * 32 + l31, h);
-}
-
-template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
-hipError_t launch_pc(const GemmArgs &a, hipStream_t s) {
-    const int64_t nblk = (a.Ppad / TP) * (a.Qpad / TQ);
-    hipLaunchKernelGGL((gemm_pc_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>), dim3((unsigned)nblk), dim3(384), 0, s, a);
-    return hipGetLastError();
-}
-
 }  // namespace
 
 #ifdef SDFA_STAMPS
@@ -1016,7 +838,13 @@ extern "C" int sdfa_debug_read_stamps(unsigned long long *out, int reset) {
 }
 #endif
 
-thread_local int g_sdfa_gemm_variant = 0;   // 0 = default choice per shape (gemm_fat_kernel for the large projections, else LDS-tiled 128^2), 9 = the round-1/2 choice (no fat kernel), 8 = fat wherever it fits, 5 = 256^2 tile, 1/2 = register-direct (MT 4 / 2), 3 = LDS-tiled fed by LDS-DMA, 6 = producer/consumer (all fp32, bit-identical); 4 = split-bf16 x3 (opt-in, not exact fp32)
+// "gemm_variant" option (sdfa_debug_set_option, thread-local): 0 = default choice per shape -- gemm_fat_kernel where its 256 x 256
+// tiles fill the chip at least twice, else the LDS-tiled 128 x 128 kernel (256 x 256 gemm_big_kernel for the 8192-deep frequency
+// projection at mid sizes); 9 = the two-workgroups-per-CU fallback (never the fat kernel: DESIGN.md section 7); 8 = fat wherever it
+// fits; 5 = 256 x 256 tile wherever it fits; 4 = split-bf16 x3 (NOT exact fp32).  All fp32 choices are bit-identical.  The
+// variants of rounds 1-2 that were never faster (register-direct 1 / 2, LDS-DMA-fed 128 x 128 tile 3, producer / consumer waves 6)
+// are gone from the library; their A/B records are profiles/r02_ab_gemm.txt and DESIGN.md section 4.2.
+thread_local int g_sdfa_gemm_variant = 0;
 
 template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
 hipError_t launch_any(const GemmArgs &a, hipStream_t s) {
@@ -1026,10 +854,8 @@ hipError_t launch_any(const GemmArgs &a, hipStream_t s) {
         return big ? launch_bf16_big<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 3>(a, s) : launch_bf16<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 3>(a, s);
     }
     if (g_sdfa_gemm_variant == 4 && !a.q_tile_major) return launch_bf16<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 3>(a, s);
-    if (g_sdfa_gemm_variant == 6) return launch_pc<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
     // one 128 x 128 block per wave, persistent (gemm_fat_kernel): by default wherever its 256 x 256 tiles fill the chip at least
-    // twice over -- the frequency projection (-5.6 %) and the BiLSTM input projections (-8 / -9.5 %); gemm_variant 8 forces it,
-    // 9 keeps the round-1/2 choice below
+    // twice over -- the frequency projection (-5.6 %) and the BiLSTM input projections (-8 / -9.5 %)
     {
         const bool fits = a.Ppad % 256 == 0 && a.Qpad % 256 == 0 && a.seg_k == a.K && a.K % 64 == 0 && OUT_MODE == OUT_K4 && !BIAS_Q && !COND &&
                           a.Pstore == a.Ppad && a.ldd * 16 * 2 < (int64_t)1 << 32 &&
@@ -1040,16 +866,12 @@ hipError_t launch_any(const GemmArgs &a, hipStream_t s) {
                 return launch_fat<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
         }
     }
-    // 256 x 256 tile, 8 waves: on request (gemm_variant 5), and in the round-1/2 choice (9) for the 8192-deep frequency projection,
-    // whose operand stream (2 MB of hidden states per frame) is what the 128 x 128 tile waits for (40.3 vs 41.7 ms)
-    // Small batches (a single 2 s / 10 s clip: 64 / 160 such tiles): the 128 x 128 tile instead, four times as many workgroups
+    // 256 x 256 tile, 8 waves: for the 8192-deep frequency projection, whose operand stream (2 MB of hidden states per frame) is
+    // what the 128 x 128 tile waits for (40.3 vs 41.7 ms), as long as such tiles fill the chip.  Small batches (a single 2 s /
+    // 10 s clip: 64 / 160 such tiles): the 128 x 128 tile instead, four times as many workgroups
     const bool big_fills = (a.Ppad / 256) * (a.Qpad / 256) >= 256;
     if ((g_sdfa_gemm_variant == 5 || (a.q_tile_major && ((g_sdfa_gemm_variant == 0 && big_fills) || g_sdfa_gemm_variant == 9))) && a.Ppad % 256 == 0 && a.Qpad % 256 == 0)
         return launch_big<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
-    if (a.q_tile_major) return launch<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);   // only the LDS-tiled kernels read that layout
-    if (g_sdfa_gemm_variant == 1 && a.Ppad % 128 == 0) return launch_direct<4, OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
-    if (g_sdfa_gemm_variant == 2 && a.Ppad % 64 == 0) return launch_direct<2, OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
-    if (g_sdfa_gemm_variant == 3) return launch<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, true>(a, s);
     return launch<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
 }
 

@@ -108,9 +108,9 @@ struct FreqLstmArgs {
     const void *Wb;      // mixed-precision modes: per direction bf16x8 [hi | lo][24 octets][512 rows] (lstm.hip)
     int terms;           // 0 = fp32 MFMA; 1 = bf16 MFMA; 3 = split-bf16 (hi/lo) MFMA
     int *tile_counter;   // one int of workspace: the persistent form's work queue head (zeroed by the launcher)
-    int shape;           // fp32 kernel / launch form (all bit-identical): freq_lstm_v3_kernel 8 = one hardware-dispatched workgroup per tile,
-                         // 9 = persistent (tile queue), one workgroup per CU by design; freq_lstm_v2_kernel 3 = hardware-dispatched, two per CU;
-                         // 5 = persistent, two per CU; 6 / 7 = the same with one per CU; freq_lstm_kernel (round 1) 4, 1, 2
+    int shape;           // fp32 kernel / launch form (all bit-identical): freq_lstm_v3_kernel 9 = persistent (tile queue), one workgroup per CU by
+                         // design (default), 8 = one hardware-dispatched workgroup per tile; freq_lstm_v2_kernel 5 = persistent, two per CU,
+                         // 3 = hardware-dispatched, two per CU (the fallback that shares a CU); anything else = 9
     int reserve_cus;     // persistent forms: launch (CUs - reserve_cus) workgroups (sdfa_model_set_reserved_cus)
 };
 hipError_t sdfa_launch_freq_lstm(const FreqLstmArgs &a, hipStream_t s);

@@ -27,17 +27,6 @@ __device__ unsigned long long g_lxcd[8][4];   // per XCD (block id % 8): max end
 #define LSTAMP(t)
 #endif
 
-#ifdef SDFA_CLOCKPROBE
-// DIAGNOSTIC BUILD ONLY (make EXP=CLOCKPROBE, tools/clock_probe.py): shader-clock cycles (s_memtime) and 100 MHz
-// reference ticks (s_memrealtime) spent inside freq_lstm_kernel workgroups -> the clock the kernel actually ran at.
-__device__ unsigned long long g_clockprobe[3];
-extern "C" int sdfa_debug_read_clockprobe(unsigned long long *out, int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clockprobe), sizeof(unsigned long long) * 3) != hipSuccess) return -3;
-    if (reset) { unsigned long long z[3] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_clockprobe), z, sizeof z) != hipSuccess) return -3; }
-    return 0;
-}
-#endif
-
 namespace {
 
 // fp32 MFMA and the vector ALU do NOT overlap on this chip -- neither across the waves of a SIMD nor inside one wave
@@ -89,200 +78,8 @@ __device__ __forceinline__ void lstm_cell_quad(const f32x16 &ai, const f32x16 &a
     hq = make_float4(hv[0].x, hv[0].y, hv[1].x, hv[1].y);
 }
 
-// ------------------------------------------------------------------------------------ frequency LSTM
-// SHARED = launched over the compacted distinct-column list (column sharing): same code, separate symbol so that
-// profiles keep the two launch shapes apart.
-template <bool SHARED, int NJ, int WGS>
-__global__ __launch_bounds__(256, WGS) void freq_lstm_kernel(FreqLstmArgs a) {
-    constexpr int BT = 32 * NJ;         // sequences (columns) per workgroup
-    __shared__ float4 sH[32][BT];       // h_{s-1}: 128 hidden as 32 k-quads x BT sequences
-    __shared__ float4 sX[2][16][BT];    // x_f tile, double buffered
-    __shared__ float sBias[512];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, h = lane >> 5;
-    // block ids go round-robin over the 8 XCDs: the two directions of one column tile sit 8 ids apart, i.e. on the SAME
-    // XCD (same L2), and are dispatched in the same round
-    const int dir = (blockIdx.x >> 3) & 1;
-    const int64_t m0 = (int64_t)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) * BT;
-    if (SHARED && m0 >= *a.col_limit) return;
-
-    const float4 *__restrict__ X3 = reinterpret_cast<const float4 *>(a.X3);
-    const float4 *__restrict__ W = reinterpret_cast<const float4 *>(a.W) + (size_t)dir * 48 * 512;
-    float4 *__restrict__ HF = reinterpret_cast<float4 *>(a.HF);
-
-    sBias[tid] = a.bias[dir * 512 + tid];
-    sBias[256 + tid] = a.bias[dir * 512 + 256 + tid];
-#ifdef SDFA_CLOCKPROBE
-    const unsigned long long cp_c0 = clock64(), cp_r0 = wall_clock64();
-#endif
-
-    float4 xr0, xr1, xr2, xr3;
-#define XLOAD1(f, i, R) if ((i) < 2 * NJ) { const int idx = (i)*256 + tid; R = X3[(int64_t)((f)*16 + idx / BT) * a.Mc + m0 + idx % BT]; }
-#define XLOAD(f) XLOAD1(f, 0, xr0) XLOAD1(f, 1, xr1) XLOAD1(f, 2, xr2) XLOAD1(f, 3, xr3)
-#define XSTORE1(buf, i, R) if ((i) < 2 * NJ) { const int idx = (i)*256 + tid; sX[buf][idx / BT][idx % BT] = R; }
-#define XSTORE(buf) XSTORE1(buf, 0, xr0) XSTORE1(buf, 1, xr1) XSTORE1(buf, 2, xr2) XSTORE1(buf, 3, xr3)
-    XLOAD(dir ? 31 : 0)
-    XSTORE(0)
-    __syncthreads();
-
-    f32x16 c[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c[j][r] = 0.f;
-
-    const float4 *__restrict__ Ww = W + wave * 128 + l31;   // + quad*512 + gate*32
-
-#ifdef SDFA_STAMPS
-    unsigned long long q0, q1, q2, q3, q4, q5, s_init = 0, s_ld = 0, s_mf = 0, s_b1 = 0, s_ep = 0, s_b2 = 0, s_math = 0, s_lds = 0;
-#endif
-    for (int s = 0; s < 32; ++s) {
-        const int f = dir ? 31 - s : s;
-        const int cur = s & 1;
-        LSTAMP(q0)
-        if (s + 1 < 32) { XLOAD(dir ? 30 - s : s + 1) }   // next x_f tile: in flight during the whole step, staged after the cell update
-
-        f32x16 acc[4][NJ];
-#pragma unroll
-        for (int gt = 0; gt < 4; ++gt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float4 b = *reinterpret_cast<const float4 *>(&sBias[wave * 128 + gt * 32 + 8 * g + 4 * h]);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    acc[gt][j][4 * g + 0] = b.x; acc[gt][j][4 * g + 1] = b.y;
-                    acc[gt][j][4 * g + 2] = b.z; acc[gt][j][4 * g + 3] = b.w;
-                }
-            }
-        // one loop over the concatenated K: k-quads 0..15 = x_f (from sX), 16..47 = h_{s-1} (from sH; h_{-1} = 0 is
-        // skipped on the first step).  Weights for k-block kb+1 are requested before the MFMAs of kb are issued,
-        // so the L2 round trip hides behind the matrix work.
-        const int nkb = s > 0 ? 24 : 8;
-        const float4 *__restrict__ wp = Ww + h * 512;
-        // Two named operand sets (A, B) alternate, so the prefetched quads are consumed where they landed -- a
-        // "current = next" hand-over costs 12 v_mov_b64 per k-block, and vector-ALU cycles come out of the MFMA pipe.
-        float4 wa0, wa1, wa2, wa3, wb0, wb1, wb2, wb3, ba[NJ], bb[NJ];
-#ifdef SDFA_FAKE_WLOAD   /* timing experiment only: every k-block re-reads the SAME weight quads (L1 hits) */
-#define FL_WSTEP(kb) ((kb) & 1)
-#else
-#define FL_WSTEP(kb) (kb)
-#endif
-#define FL_LOAD(kb, W0, W1, W2, W3, B)                                                                       \
-    {                                                                                                        \
-        const float4 *__restrict__ wq = wp + (FL_WSTEP(kb)) * 1024;                                          \
-        W0 = wq[0]; W1 = wq[32]; W2 = wq[64]; W3 = wq[96];                                                   \
-        const float4 *bsrc = (kb) < 8 ? &sX[cur][2 * (kb) + h][0] : &sH[2 * ((kb) - 8) + h][0];              \
-        _Pragma("unroll") for (int j = 0; j < NJ; ++j) B[j] = bsrc[j * 32 + l31];                            \
-    }
-        // (gate-tile-major order: the component-major mfma_block order needs 8 more registers here, which spills)
-#ifdef SDFA_COMPMAJOR   /* experiment: no back-to-back dependent MFMAs (consecutive MFMAs go to different accumulators) */
-#define FL_MFMA(W0, W1, W2, W3, B)                                                \
-    {                                                                             \
-        const float4 wq_[4] = {W0, W1, W2, W3};                                   \
-        mfma_block<4, NJ>(acc, wq_, B);                                           \
-    }
-#else
-#define FL_MFMA(W0, W1, W2, W3, B)                                                \
-    {                                                                             \
-        _Pragma("unroll") for (int j = 0; j < NJ; ++j) mfma4(acc[0][j], W0, B[j]); \
-        _Pragma("unroll") for (int j = 0; j < NJ; ++j) mfma4(acc[1][j], W1, B[j]); \
-        _Pragma("unroll") for (int j = 0; j < NJ; ++j) mfma4(acc[2][j], W2, B[j]); \
-        _Pragma("unroll") for (int j = 0; j < NJ; ++j) mfma4(acc[3][j], W3, B[j]); \
-    }
-#endif
-        FL_LOAD(0, wa0, wa1, wa2, wa3, ba)
-        // the wave in its MFMA phase outranks the partner wave (of the CU's other workgroup) that is in its cell update /
-        // staging phase at the SIMD's issue port: +0.8 % (A/B in profiles/r02_ab.txt; priorities 1, 2, 3 measure the same)
-        __builtin_amdgcn_s_setprio(1);
-        LSTAMP(q1)
-#ifdef SDFA_STAMPS
-        s_init += q1 - q0;
-#endif
-#pragma unroll 1
-        for (int kb = 0; kb < nkb; kb += 2) {      // nkb is even (8 or 24)
-            LSTAMP(q2)
-            FL_LOAD(kb + 1, wb0, wb1, wb2, wb3, bb)
-            __builtin_amdgcn_sched_barrier(0);   // keep all six requests ahead of the MFMAs (the scheduler otherwise sinks
-                                                 // half of them to their first use to save registers, exposing the L2 latency)
-            LSTAMP(q3)
-            FL_MFMA(wa0, wa1, wa2, wa3, ba)
-            LSTAMP(q4)
-#ifdef SDFA_STAMPS
-            s_ld += q3 - q2; s_mf += q4 - q3;
-#endif
-            // unconditional (the last iteration re-requests k-block 0 and drops it): a branch here would let the
-            // optimiser sink the requests above into the block of their first use
-            const int kb2 = kb + 2 < nkb ? kb + 2 : 0;
-            FL_LOAD(kb2, wa0, wa1, wa2, wa3, ba)
-            __builtin_amdgcn_sched_barrier(0);
-            FL_MFMA(wb0, wb1, wb2, wb3, bb)
-        }
-#undef FL_LOAD
-#undef FL_MFMA
-        __builtin_amdgcn_s_setprio(0);
-        LSTAMP(q2)
-        __syncthreads();   // every wave has finished reading sH / sX[cur]
-        LSTAMP(q3)
-        // hidden states go out TILE-MAJOR: float4[column block of 128][8192/4 rows][128]: a workgroup's share of a
-        // step is contiguous runs, and the projection GEMM streams each column block front to back
-#ifdef SDFA_STAMPS
-        {   // diagnostic split: math first, then LDS writes, then global stores
-            float4 hq[NJ][4];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) lstm_cell_quad(acc[0][j], acc[1][j], acc[2][j], acc[3][j], c[j], g, hq[j][g]);
-            unsigned long long e1, e2, e3;
-            LSTAMP(e1)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) sH[8 * wave + 2 * g + h][j * 32 + l31] = hq[j][g];
-            if (s + 1 < 32) { XSTORE(cur ^ 1) }
-            LSTAMP(e2)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) HF[((m0 >> 7) * (int64_t)HF_SLAB_ROWS + (f * 64 + dir * 32 + 8 * wave + 2 * g + h)) * 128 + (m0 & 127) + j * 32 + l31] = hq[j][g];
-            LSTAMP(e3)
-            s_math += e1 - q3; s_lds += e2 - e1;
-        }
-#else
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float4 hq;
-                lstm_cell_quad(acc[0][j], acc[1][j], acc[2][j], acc[3][j], c[j], g, hq);
-                const int hq_idx = 8 * wave + 2 * g + h;
-                sH[hq_idx][j * 32 + l31] = hq;
-                HF[((m0 >> 7) * (int64_t)HF_SLAB_ROWS + (f * 64 + dir * 32 + hq_idx)) * 128 + (m0 & 127) + j * 32 + l31] = hq;
-            }
-        if (s + 1 < 32) { XSTORE(cur ^ 1) }
-#endif
-        LSTAMP(q4)
-        __syncthreads();
-        LSTAMP(q5)
-#ifdef SDFA_STAMPS
-        s_b1 += q3 - q2; s_ep += q4 - q3; s_b2 += q5 - q4;
-#endif
-    }
-#ifdef SDFA_CLOCKPROBE
-    if (tid == 0) {
-        atomicAdd(&g_clockprobe[0], (unsigned long long)(clock64() - cp_c0));
-        atomicAdd(&g_clockprobe[1], (unsigned long long)(wall_clock64() - cp_r0));
-        atomicAdd(&g_clockprobe[2], 1ull);
-    }
-#endif
-#ifdef SDFA_STAMPS
-    if (lane == 0) {
-        atomicAdd(&g_lstamp[0], s_init); atomicAdd(&g_lstamp[1], s_ld); atomicAdd(&g_lstamp[2], s_mf); atomicAdd(&g_lstamp[3], s_b1);
-        atomicAdd(&g_lstamp[4], s_ep); atomicAdd(&g_lstamp[5], s_math); atomicAdd(&g_lstamp[6], 32ull); atomicAdd(&g_lstamp[7], s_lds);
-        atomicAdd(&g_lstamp[3], s_b2);
-    }
-#endif
-}
+// SHARED (all frequency-LSTM kernels) = launched over the compacted distinct-column list (column sharing): same code, separate
+// symbol so that profiles keep the two launch shapes apart.
 
 // ------------------------------------------------------------------------------- frequency LSTM, second form
 // Same arithmetic and the same per-accumulator order of operations as freq_lstm_kernel<.., 2, 2> (bit-identical output);
@@ -1009,103 +806,6 @@ __global__ __launch_bounds__(512, 2) void time_lstm_kernel(TimeLstmArgs a) {
 #undef TL_W1
 }
 
-// The same recurrence as 4-wave workgroups of 32 frames: a wave owns TWO hidden blocks (acc[4 gates][2 blocks], the same
-// 8 accumulator tiles as the 64-frame shape), LDS 64 KiB, so TWO workgroups share a CU and run out of phase -- the cell
-// update and step barrier of one overlap the other's MFMAs (the 8-wave shape leaves the matrix pipe idle there: MfmaUtil
-// 73 %).  Each weight quad now feeds one column tile instead of two, i.e. twice the L2 -> register weight traffic per
-// MFMA.  Same k order and same cell arithmetic: bit-identical to time_lstm_kernel.
-__global__ __launch_bounds__(256, 2) void time_lstm_pair_kernel(TimeLstmArgs a) {
-    extern __shared__ float4 sHt[];   // [2][64 k-quads][32 sequences]
-    constexpr int BT = 32;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // 4 waves: hidden blocks 2w, 2w+1
-    const int l31 = lane & 31, h = lane >> 5;
-    const int dir = blockIdx.x & 1;                                   // the directions share no data (separate gate rows of GX)
-    const int64_t n0 = (int64_t)(blockIdx.x >> 1) * BT;
-
-    const float4 *__restrict__ GX = reinterpret_cast<const float4 *>(a.GX);
-    const float4 *__restrict__ Ww = reinterpret_cast<const float4 *>(a.W) + (size_t)dir * 64 * 1024 + wave * 256 + l31;
-    float4 *__restrict__ H = reinterpret_cast<float4 *>(a.H);
-
-    f32x16 c[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c[b][r] = 0.f;
-
-    f32x16 acc[4][2];     // [gate][hidden block of this wave]
-    // per-lane base + wave-uniform offsets (scalar registers): 32 hoisted 64-bit lane addresses would not fit the register file
-    const float4 *__restrict__ GXl = GX + (int64_t)(dir * 256 + wave * 64 + h) * a.Mc + n0 + l31;
-    float4 *__restrict__ Hl = H + (int64_t)(dir * 64 + wave * 16 + h) * a.Mc + n0 + l31;
-#define TP_GX(t_, gt, g, b) GXl[(int64_t)((b) * 32 + (gt) * 8 + 2 * (g)) * a.Mc + (int64_t)(t_) * a.Nc]
-#pragma unroll
-    for (int gt = 0; gt < 4; ++gt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const float4 v = TP_GX(dir ? 63 : 0, gt, g, b);
-                acc[gt][b][4 * g + 0] = v.x; acc[gt][b][4 * g + 1] = v.y; acc[gt][b][4 * g + 2] = v.z; acc[gt][b][4 * g + 3] = v.w;
-            }
-
-    for (int s = 0; s < 64; ++s) {
-        const int t = dir ? 63 - s : s;
-        const int tn = dir ? t - 1 : t + 1;
-        const int64_t tcol = (int64_t)t * a.Nc;
-        const float4 *sHc = sHt + (size_t)(s & 1) * 64 * BT;
-        float4 *sHn = sHt + (size_t)((s & 1) ^ 1) * 64 * BT;
-
-        if (s > 0) {
-            // one hidden block after the other: the K loop of time_lstm_kernel (4 weight quads per k-block, two alternating
-            // register sets) run twice -- eight quads in flight for both blocks at once do not fit the 256 registers
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const float4 *__restrict__ wp = Ww + h * 1024 + b * 128;
-                float4 wa[4], wb[4];
-#define TP_LOAD(kb, W) { const float4 *__restrict__ wq = wp + (kb) * 2048; W[0] = wq[0]; W[1] = wq[32]; W[2] = wq[64]; W[3] = wq[96]; }
-#define TP_MFMA(kb, W)                                                                    \
-    {                                                                                     \
-        const float4 bq = sHc[(2 * (kb) + h) * BT + l31];                                 \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                     \
-        _Pragma("unroll") for (int gt = 0; gt < 4; ++gt)                                  \
-            acc[gt][b] = MFMA(SDFA_OP(f4c(W[gt], q)), SDFA_OP(f4c(bq, q)), acc[gt][b]);   \
-    }
-                TP_LOAD(0, wa)
-#pragma unroll 1
-                for (int kb = 0; kb < 32; kb += 2) {
-                    TP_LOAD(kb + 1, wb)
-                    __builtin_amdgcn_sched_barrier(0);
-                    TP_MFMA(kb, wa)
-                    const int kn = kb + 2 < 32 ? kb + 2 : 0;
-                    TP_LOAD(kn, wa)
-                    __builtin_amdgcn_sched_barrier(0);
-                    TP_MFMA(kb + 1, wb)
-                }
-#undef TP_LOAD
-#undef TP_MFMA
-            }
-        }
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float4 hq;
-                lstm_cell_quad(acc[0][b], acc[1][b], acc[2][b], acc[3][b], c[b], g, hq);
-                sHn[(8 * (2 * wave + b) + 2 * g + h) * BT + l31] = hq;
-                Hl[(int64_t)(8 * b + 2 * g) * a.Mc + tcol] = hq;
-                if (s + 1 < 64) {
-#pragma unroll
-                    for (int gt = 0; gt < 4; ++gt) {
-                        const float4 v = TP_GX(tn, gt, g, b);
-                        acc[gt][b][4 * g + 0] = v.x; acc[gt][b][4 * g + 1] = v.y; acc[gt][b][4 * g + 2] = v.z; acc[gt][b][4 * g + 3] = v.w;
-                    }
-                }
-            }
-        __syncthreads();
-    }
-#undef TP_GX
-}
-
 // ------------------------------------------------------------------------------ time LSTM on bf16 MFMA
 // Mixed-precision modes: the BiLSTM recurrence h_{t-1} * W_hh^T on v_mfma_f32_32x32x16_bf16 (TERMS 1 or 3, see
 // freq_lstm_bf16_kernel); input projection (from the GEMM), accumulation, cell state and gate math stay fp32.
@@ -1242,56 +942,46 @@ extern "C" int sdfa_debug_read_lstm_span(unsigned long long *out, int reset) {
 }
 #endif
 
+// Launch forms of the fp32 recurrence (FreqLstmArgs::shape; all bit-identical):
+//   9  freq_lstm_v3_kernel, persistent (tile queue), one workgroup per CU   -- default
+//   8  freq_lstm_v3_kernel, one hardware-dispatched workgroup per tile
+//   5  freq_lstm_v2_kernel, persistent, two workgroups per CU
+//   3  freq_lstm_v2_kernel, hardware-dispatched, two workgroups per CU       -- the fallback that shares a CU
+// sdfa_model_autotune times the four on the device.  (The round-1 kernel and the one-per-CU launch forms of the second kernel
+// -- shapes 1, 2, 4, 6, 7 -- were removed in round 3; any other value launches the default.)
 template <bool SHARED>
 static hipError_t launch_freq(const FreqLstmArgs &a, hipStream_t s) {
-    const int shape = a.shape;
+    const int shape = (a.shape == 8 || a.shape == 5 || a.shape == 3) ? a.shape : 9;
+    const unsigned n_tiles = (unsigned)(a.Mc / 64 * 2);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    cus = std::max(1, cus - a.reserve_cus);      // CUs left to kernels of other streams (sdfa_model_set_reserved_cus)
     if (shape == 8 || shape == 9) {      // the third form: one workgroup per CU by construction (96 KiB of LDS)
         const size_t lds = 2 * 48 * 64 * sizeof(float4) + 512 * sizeof(float) + 16;
         const void *fn = shape == 9 ? reinterpret_cast<const void *>(freq_lstm_v3_kernel<SHARED, true>) : reinterpret_cast<const void *>(freq_lstm_v3_kernel<SHARED, false>);
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        const unsigned n_tiles = (unsigned)(a.Mc / 64 * 2);
         if (shape == 9) {
-            int dev = 0, cus = 256;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
             e = hipMemsetAsync(a.tile_counter, 0, sizeof(int), s);
             if (e != hipSuccess) return e;
-            cus = std::max(1, cus - a.reserve_cus);      // CUs left to kernels of other streams (sdfa_model_set_reserved_cus)
             hipLaunchKernelGGL((freq_lstm_v3_kernel<SHARED, true>), dim3(n_tiles < (unsigned)cus ? n_tiles : (unsigned)cus), dim3(256), lds, s, a);
         } else {
             hipLaunchKernelGGL((freq_lstm_v3_kernel<SHARED, false>), dim3(n_tiles), dim3(256), lds, s, a);
         }
         return hipGetLastError();
     }
-    if (shape == 3 || (shape >= 5 && shape <= 7)) {      // the second form
-        const unsigned n_tiles = (unsigned)(a.Mc / 64 * 2);
-        // one workgroup per CU: 32 KB of unused dynamic LDS per workgroup (66 KB static)
-        if (shape == 5 || shape == 7) {      // persistent: workgroups pull tiles from a queue; 5: two per CU, 7: one per CU
-            static const unsigned cus = [] {
-                int dev = 0, n = 256;
-                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
-                return (unsigned)n;
-            }();
-            const bool one = shape == 7;
-            const unsigned slots = one ? cus : 2 * cus;
-            hipError_t e = hipMemsetAsync(a.tile_counter, 0, sizeof(int), s);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((freq_lstm_v2_kernel<SHARED, true>), dim3(n_tiles < slots ? n_tiles : slots), dim3(256), one ? 32 * 1024 : 0, s, a);
-            return hipGetLastError();
-        }
-        bool lone = shape == 6;
-#ifdef SDFA_STAMPS
-        lone = lone || getenv("SDFA_LONE");
-#endif
-        hipLaunchKernelGGL((freq_lstm_v2_kernel<SHARED, false>), dim3(n_tiles), dim3(256), lone ? 32 * 1024 : 0, s, a);
+    if (shape == 5) {                    // persistent: workgroups pull tiles from a queue, two per CU
+        const unsigned slots = 2u * (unsigned)cus;
+        hipError_t e = hipMemsetAsync(a.tile_counter, 0, sizeof(int), s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((freq_lstm_v2_kernel<SHARED, true>), dim3(n_tiles < slots ? n_tiles : slots), dim3(256), 0, s, a);
         return hipGetLastError();
     }
-    if (shape == 1)
-        hipLaunchKernelGGL((freq_lstm_kernel<SHARED, 1, 4>), dim3((unsigned)(a.Mc / 32 * 2)), dim3(256), 0, s, a);
-    else if (shape == 2)
-        hipLaunchKernelGGL((freq_lstm_kernel<SHARED, 1, 3>), dim3((unsigned)(a.Mc / 32 * 2)), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((freq_lstm_kernel<SHARED, 2, 2>), dim3((unsigned)(a.Mc / 64 * 2)), dim3(256), 0, s, a);
+    size_t lone = 0;
+#ifdef SDFA_STAMPS
+    if (getenv("SDFA_LONE")) lone = 32 * 1024;      // diagnostic: 32 KB of unused dynamic LDS = one workgroup per CU
+#endif
+    hipLaunchKernelGGL((freq_lstm_v2_kernel<SHARED, false>), dim3(n_tiles), dim3(256), lone, s, a);
     return hipGetLastError();
 }
 
@@ -1334,20 +1024,9 @@ static hipError_t launch_time_bf16(const TimeLstmArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-extern thread_local int g_sdfa_time_lstm_shape;   // api.cpp ("time_lstm_shape" option): 0 = auto, 1 = 8-wave shapes only, 2 = paired 4-wave workgroups always
-
-static hipError_t launch_time_pair(const TimeLstmArgs &a, hipStream_t s) {
-    const size_t lds = 2 * 64 * 32 * sizeof(float4);   // 64 KiB: two workgroups per CU
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(time_lstm_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(time_lstm_pair_kernel, dim3((unsigned)(a.Nc / 32 * 2)), dim3(256), lds, s, a);
-    return hipGetLastError();
-}
-
 hipError_t sdfa_launch_time_lstm(const TimeLstmArgs &a, hipStream_t s) {
     // 64-frame tiles while they fill the 256 CUs (one 8-wave workgroup per CU); otherwise 32-frame tiles
     const bool big = (a.Nc / 64) * 2 >= 256;
-    if (!a.terms && g_sdfa_time_lstm_shape == 2) return launch_time_pair(a, s);
     if (a.terms) {
         if (!a.Wb) return hipErrorInvalidValue;
         if (a.terms == 1) return big ? launch_time_bf16<2, 1>(a, s) : launch_time_bf16<1, 1>(a, s);

@@ -68,65 +68,16 @@ __device__ __forceinline__ void pca_stage(float *__restrict__ sRow, const f32x16
     }
 }
 
-// The same contraction with the BASIS staged through LDS (round 2).  The register-direct form above has every wave fetch
-// the whole basis slab of its workgroup itself -- the four waves multiply different frames by the SAME columns -- which is
-// 0.3 vector-memory requests per MFMA and keeps the CU's L1 / texture-address path 60 % busy: the kernel is bound there,
-// not by the matrix pipe (MfmaUtil 61 %).  Here the 256 threads load each stage of the slab ONCE (3 requests per thread
-// and stage of 48 MFMAs per wave), park it in registers for one stage, store it to the other LDS buffer and meet at one
-// barrier per stage; the waves read their B operands from LDS and only the coefficient quads (one per k-block) from L2.
-// Same k order per accumulator: bit-identical results.
-template <int NT, int KQS>   // NT column tiles of 32; KQS k-quads per stage (KQS * NT * 32 = 768 float4 = 3 per thread)
-__device__ __forceinline__ void pca_part_lds(const float4 *__restrict__ coef, int64_t ldc, const float4 *__restrict__ basis, int64_t ldb,
-                                             int nkq, float4 *__restrict__ sB, int tid, int h, int l31, f32x16 (&acc)[1][NT]) {
-    constexpr int COLS = NT * 32, ITEMS = KQS * COLS / 256, KB = KQS / 2;
-    static_assert(KQS * COLS == 768 && ITEMS == 3, "a stage is 768 float4");
-    const int nst = nkq / KQS;
-    float4 rg[ITEMS], a_cur[KB], a_nxt[KB];
-#define PL_GLOAD(st)                                                                              \
-    _Pragma("unroll") for (int m = 0; m < ITEMS; ++m) {                                           \
-        const int i = tid + 256 * m;                                                              \
-        rg[m] = basis[(int64_t)((st)*KQS + i / COLS) * ldb + i % COLS];                           \
-    }
-#define PL_LSTORE(buf) _Pragma("unroll") for (int m = 0; m < ITEMS; ++m) sB[(buf)*768 + tid + 256 * m] = rg[m];
-#define PL_ALOAD(st, A) _Pragma("unroll") for (int kb = 0; kb < KB; ++kb) A[kb] = coef[(int64_t)((st)*KQS + 2 * kb + h) * ldc];
-    PL_GLOAD(0)
-    PL_ALOAD(0, a_cur)
-    PL_LSTORE(0)
-    if (nst > 1) { PL_GLOAD(1) }
-    __syncthreads();
-#pragma unroll 1
-    for (int st = 0; st < nst; ++st) {
-        const float4 *__restrict__ sb = sB + (st & 1) * 768;
-        if (st + 1 < nst) { PL_ALOAD(st + 1, a_nxt) }
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            float4 b[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) b[t] = sb[(2 * kb + h) * COLS + 32 * t + l31];
-            const float4 a1[1] = {a_cur[kb]};
-            mfma_block<1, NT>(acc, a1, b);
-        }
-        if (st + 1 < nst) { PL_LSTORE((st & 1) ^ 1) }      // stage st+1 has been in registers for a whole stage
-        __syncthreads();
-        if (st + 2 < nst) { PL_GLOAD(st + 2) }
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) a_cur[kb] = a_nxt[kb];
-    }
-#undef PL_GLOAD
-#undef PL_LSTORE
-#undef PL_ALOAD
-}
-
-template <bool LDS_BASIS>
+// (A form with the basis staged through LDS per k-block stage -- twelve barriers per workgroup -- was 14 % slower and is gone:
+// profiles/r02_ab_final.txt)
 __global__ __launch_bounds__(256, 2) void pca_dgrad_kernel(PcaArgs a) {
-    __shared__ float sOut[4][8 * PCA_ROW];
-    __shared__ float4 sBasis[LDS_BASIS ? 2 * 768 : 1];    // two stages of the basis slab (24 KiB)                // per wave: 8 output rows x 288 floats, staged for 16-byte stores
+    __shared__ float sOut[4][8 * PCA_ROW];                // per wave: 8 output rows x 288 floats, staged for 16-byte stores
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int64_t nfb = a.Nc / 128;                       // frame blocks: fastest-varying, so a basis slab is reused from L2
     const int64_t fb = blockIdx.x % nfb, tb = blockIdx.x / nfb;
     const int64_t frame0 = fb * 128 + wave * 32;
-    if (!LDS_BASIS && frame0 >= a.N) return;      // (with LDS staging every wave helps to load and meets the barriers)
+    if (frame0 >= a.N) return;
 
     const float4 *__restrict__ coef = reinterpret_cast<const float4 *>(a.coef) + frame0 + l31;   // K4 [288/4][Nc]: scale rows 0..95, rotat 96..287
     f32x16 accs[1][6], accr[1][3];
@@ -138,14 +89,8 @@ __global__ __launch_bounds__(256, 2) void pca_dgrad_kernel(PcaArgs a) {
     for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accr[0][t][r] = 0.f;
-    if (LDS_BASIS) {
-        pca_part_lds<6, 4>(coef, a.Nc, reinterpret_cast<const float4 *>(a.basis_s) + tb * 192, a.ld_s, 24, sBasis, tid, h, l31, accs);
-        pca_part_lds<3, 8>(coef + 24 * a.Nc, a.Nc, reinterpret_cast<const float4 *>(a.basis_r) + tb * 96, a.ld_r, 48, sBasis, tid, h, l31, accr);
-        if (frame0 >= a.N) return;
-    } else {
-        pca_part<6>(coef, a.Nc, reinterpret_cast<const float4 *>(a.basis_s) + tb * 192 + l31, a.ld_s, 12, h, accs);
-        pca_part<3>(coef + 24 * a.Nc, a.Nc, reinterpret_cast<const float4 *>(a.basis_r) + tb * 96 + l31, a.ld_r, 24, h, accr);
-    }
+    pca_part<6>(coef, a.Nc, reinterpret_cast<const float4 *>(a.basis_s) + tb * 192 + l31, a.ld_s, 12, h, accs);
+    pca_part<3>(coef + 24 * a.Nc, a.Nc, reinterpret_cast<const float4 *>(a.basis_r) + tb * 96 + l31, a.ld_r, 24, h, accr);
 
     // epilogue: four passes of 8 frames; the wave transposes its (8 x 288) block through LDS and writes whole rows with
     // 16-byte stores (1,152 contiguous bytes per frame) instead of 4-byte stores strided 6-of-9 / 3-of-9
@@ -374,7 +319,6 @@ __global__ __launch_bounds__(256, 1) void pca_dgrad_res_kernel(PcaArgs a, int *q
 
 }  // namespace
 
-extern thread_local int g_sdfa_pca_lds;   // api.cpp ("pca_lds" option): 0 / 3 = pca_dgrad_res_kernel (api.cpp picks it), 4 = register-direct, 1 = basis staged through LDS
 
 hipError_t sdfa_launch_pca_dgrad_res(const PcaArgs &a, int *queue, hipStream_t s) {
     const int64_t ntb = (a.cols_r + 95) / 96;
@@ -400,7 +344,6 @@ hipError_t sdfa_launch_pca_dgrad(const PcaArgs &a, hipStream_t s) {
     // 32 triangles per workgroup: 192 scale columns + 96 rotat columns; the padded leading dimensions must cover whole blocks
     const int64_t ntb = (a.cols_r + 95) / 96;
     if (a.Nc % 128 || a.ld_s < ntb * 192 || a.ld_r < ntb * 96 || a.cols_s != 2 * a.cols_r) return hipErrorInvalidValue;
-    if (g_sdfa_pca_lds == 1) hipLaunchKernelGGL(pca_dgrad_kernel<true>, dim3((unsigned)(ntb * (a.Nc / 128))), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(pca_dgrad_kernel<false>, dim3((unsigned)(ntb * (a.Nc / 128))), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(pca_dgrad_kernel, dim3((unsigned)(ntb * (a.Nc / 128))), dim3(256), 0, s, a);
     return hipGetLastError();
 }
