@@ -195,20 +195,48 @@ def surface_block(sd, head, sr, dev):
     return out
 
 
+def _sha1(name):
+    import hashlib
+    try:
+        return hashlib.sha1(open(os.path.join(ROOT, "sdfa-2019_amd", "csrc", name), "rb").read()).hexdigest()
+    except OSError:
+        return None
+
+
 def traffic_from_profile(frames_per_launch):
-    """HBM bytes per freq_lstm_kernel launch from the newest committed rocprofv3 PMC passes (profiles/r*_pmc/
+    """HBM bytes per frequency-LSTM launch from the newest committed rocprofv3 PMC passes (profiles/r*_pmc/
     freq_lstm_traffic.json, written by profiles/pmc_summary.py: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE
     doubled as MI355X_MICROARCH.md prescribes for gfx950), scaled to this run's frames per launch.  Counters cannot be
-    read inside the benchmark itself.  Returns (traffic bytes, algorithmic bytes, source) or (None, None, None)."""
+    read inside the benchmark itself.  The JSON carries the sha1 of csrc/lstm.hip it was measured at: once the kernel file
+    has changed the figure is stale and `traffic` is null (the source says why).
+    Returns (traffic bytes, algorithmic bytes, source) or (None, None, reason)."""
     import glob
     try:
         path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc", "freq_lstm_traffic.json")))[-1]
         with open(path) as f:
             t = json.load(f)
+        rel = os.path.relpath(path, ROOT)
         k = frames_per_launch / t["frames"]
-        return round(t["traffic_bytes"] * k), round(t["algorithmic_bytes"] * k), os.path.relpath(path, ROOT)
+        alg = round(t["algorithmic_bytes"] * k)
+        if t.get("lstm_hip_sha1") != _sha1("lstm.hip"):
+            return None, alg, f"{rel} was measured at another version of csrc/lstm.hip: stale, re-run tools/collect_profiles.sh"
+        return round(t["traffic_bytes"] * k), alg, rel
     except Exception:
         return None, None, None
+
+
+def frontend_counter_bytes():
+    """Counter-based HBM bytes per frame of the spectrogram stage (profiles/r*_pmc/frontend_traffic.json), or None when absent / stale."""
+    import glob
+    try:
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc", "frontend_traffic.json")))[-1]
+        with open(path) as f:
+            t = json.load(f)
+        if t.get("frontend_hip_sha1") != _sha1("frontend.hip"):
+            return None, None
+        return float(t["bytes_per_frame"]), os.path.relpath(path, ROOT)
+    except Exception:
+        return None, None
 
 
 def main():
@@ -474,6 +502,7 @@ def main():
         flop_per_launch = FLOP_FREQ_LSTM_PER_FRAME * (F / n_chunks)
         achieved = flop_per_launch / (lstm_ms_per_launch * 1e-3) / 1e12
         traffic, traffic_alg, traffic_src = traffic_from_profile(F / n_chunks)
+        fe_cnt, fe_src = frontend_counter_bytes() if (a.frontend == "gather" and sr == 16000 and not a.ragged_seconds and a.seconds == 10.0) else (None, None)
         res = {
             "metric": "animation frames/s/node (10 s@16 kHz clips); max|Δdgrad| vs CPU ref",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -500,7 +529,12 @@ def main():
             "model_frac_of_fp32_mfma_peak": round(value / world * FLOP_MODEL_PER_FRAME / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
             "frontend": {"ms": round(fe_ms, 3), "frames_per_s": round(F / (fe_ms * 1e-3), 1),
                          "hbm_gbps_algorithmic": round(F * FRONTEND_BYTES_PER_FRAME / (fe_ms * 1e-3) / 1e9, 1),
-                         "frac_of_hbm_peak": round(F * FRONTEND_BYTES_PER_FRAME / (fe_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)},
+                         "frac_of_hbm_peak": round(F * FRONTEND_BYTES_PER_FRAME / (fe_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                         # what the HBM counters saw (FETCH_SIZE x 2 + WRITE_SIZE of the stage's two kernels, committed PMC passes) over
+                         # this run's stage time; null when the passes are absent or csrc/frontend.hip has changed since
+                         "hbm_gbps_counters": None if fe_cnt is None else round(F * fe_cnt / (fe_ms * 1e-3) / 1e9, 1),
+                         "frac_of_hbm_peak_counters": None if fe_cnt is None else round(F * fe_cnt / (fe_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                         "counters_source": fe_src},
             "stage_ms_per_step": {k: round(v, 3) for k, v in stages.items()},
         }
         res["peak_device_memory_gb"] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 2)

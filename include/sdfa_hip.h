@@ -64,7 +64,9 @@ const char *sdfa_last_error(void);
  *   ts_delta_ms                   hparams.anime.feature.ts_delta (100)
  *   h_starts[cap], h_tslist[cap]  window start sample (may be negative) and timestamp (ms)
  * Returns the number of frames F (call with cap = 0 and null outputs to size), or
- * SDFA_ESHORTCLIP where the reference's assert would fire.
+ * SDFA_ESHORTCLIP where the reference's assert would fire.  Clips of more than 2^29 - 1 samples return SDFA_EINVAL: the
+ * front-end kernels index a clip's samples in 32-bit arithmetic (a clip handed to sdfa_mel_frontend* directly must respect
+ * the same limit; a clip of length 0 contributes all-zero windows).
  * ---------------------------------------------------------------------------------------- */
 int64_t sdfa_frame_index(int64_t n_samples, int sample_rate, int fps, int win, int hop,
                          int ts_delta_ms, int64_t *h_starts, int32_t *h_tslist, int64_t cap);

@@ -2,6 +2,13 @@
 """Per-kernel, per-launch-shape table from the three separate rocprofv3 --pmc passes (MfmaUtil, FETCH_SIZE, WRITE_SIZE).
 
 Usage: python profiles/pmc_summary.py <dir with MfmaUtil_/FETCH_SIZE_/WRITE_SIZE_counter_collection.csv> [--traffic-json out.json]
+                                      [--chunks 8192,8192,3968] [--frontend-json out.json --frames 20352]
+
+--chunks: the frames of the consecutive launch groups of one step (bench.py --chunk: 20,352 frames = 8192 + 8192 + 3968).  A
+PERSISTENT kernel launches the same grid whatever the problem size, so (symbol, grid) cannot tell its 8192-frame launches from
+its 3968-frame one (the round-2 table averaged them).  With --chunks the dispatches of every constant-grid symbol are
+taken in dispatch order and split into len(chunks) consecutive groups -- the collection runs ONE step with no warm-up, so the
+k-th group IS chunk k -- and printed per chunk in a second table.
 
 Counter handling follows MI355X_MICROARCH.md, section HBM:
   * rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB on gfx950;
@@ -24,12 +31,46 @@ import sys
 FETCH_CORRECTION = 2.0      # MI355X_MICROARCH.md: "double it before comparing with a byte count"
 
 
+def file_sha1(name):
+    """sha1 of a kernel source as it was when the counters were collected (the script runs in the same snapshot): bench.py nulls
+    a figure derived from these counters once the kernel file has changed."""
+    import hashlib
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sdfa-2019_amd", "csrc", name)
+    try:
+        return hashlib.sha1(open(path, "rb").read()).hexdigest()
+    except OSError:
+        return None
+
+
 def load(path):
     out = collections.defaultdict(list)
-    for r in csv.DictReader(open(path)):
+    for r in sorted(csv.DictReader(open(path)), key=lambda r: int(r["Dispatch_Id"])):
         name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
         out[(name, int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
     return out
+
+
+PERSISTENT = ("gemm_fat_kernel", "pca_dgrad_res_kernel", "freq_lstm_v3_kernel<false, true", "freq_lstm_v3_kernel<true, true",
+              "freq_lstm_v2_kernel<false, true", "freq_lstm_v2_kernel<true, true")
+
+
+def per_chunk(M, F, W, chunks):
+    """Second table: dispatches of the constant-grid (persistent) kernels split by launch group."""
+    print()
+    print(f"persistent kernels by launch group (--chunks {','.join(map(str, chunks))}): dispatch order split into {len(chunks)} consecutive groups")
+    print(f"{'kernel':46s} {'frames':>7s} {'calls':>5s} {'MfmaUtil %':>10s} {'read GB (x2)':>13s} {'write GB':>10s}")
+    for k in sorted(M):
+        if not k[0].startswith(PERSISTENT):
+            continue
+        m, f, w = M[k], F.get(k, []), W.get(k, [])
+        if len(m) % len(chunks) or len(f) != len(m) or len(w) != len(m):
+            print(f"{k[0][:46]:46s} -- {len(m)} dispatches do not split into {len(chunks)} groups (or the passes differ): skipped")
+            continue
+        per = len(m) // len(chunks)
+        for ci, frames in enumerate(chunks):
+            sl = slice(ci * per, (ci + 1) * per)
+            mm, ff, ww = m[sl], f[sl], w[sl]
+            print(f"{k[0][:46]:46s} {frames:7d} {per:5d} {sum(mm) / per:10.1f} {sum(ff) / per * 1024 * FETCH_CORRECTION / 1e9:13.3f} {sum(ww) / per * 1024 / 1e9:10.3f}")
 
 
 def main():
@@ -42,6 +83,24 @@ def main():
             continue
         fk, wk = sum(f) / len(f), sum(w) / len(w)
         print(f"{k[0][:46]:46s} {k[1]:10d} {len(m):5d} {sum(m) / len(m):10.1f} {fk:14.0f} {fk * 1024 * FETCH_CORRECTION / 1e9:13.3f} {wk * 1024 / 1e9:10.3f}")
+    if "--chunks" in sys.argv:
+        per_chunk(M, F, W, [int(x) for x in sys.argv[sys.argv.index("--chunks") + 1].split(",")])
+    if "--frontend-json" in sys.argv:
+        # the spectrogram stage (north_star: "rocprof counters reporting achieved HBM GB/s on the spectrogram stage"): counter bytes
+        # of its two kernels per frame; bench.py divides by its live stage time
+        frames = int(sys.argv[sys.argv.index("--frames") + 1])
+        fe = {}
+        for k in M:
+            for stem in ("mel_columns_kernel", "gather_features_kernel"):
+                if k[0].startswith(stem) and F.get(k) and W.get(k):
+                    fe[stem] = {"read_bytes": F[k][-1] * 1024 * FETCH_CORRECTION, "write_bytes": W[k][-1] * 1024, "grid": k[1]}
+        if len(fe) == 2:
+            tot = sum(v["read_bytes"] + v["write_bytes"] for v in fe.values())
+            json.dump({"frames": frames, "kernels": fe, "bytes_per_frame": tot / frames, "fetch_correction": FETCH_CORRECTION,
+                       "frontend_hip_sha1": file_sha1("frontend.hip"),
+                       "source": f"separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes ({os.path.basename(os.path.normpath(d))}), last launch of "
+                                 "mel_columns_kernel + gather_features_kernel (the full batch); FETCH_SIZE doubled per MI355X_MICROARCH.md"},
+                      open(sys.argv[sys.argv.index("--frontend-json") + 1], "w"), indent=1)
     if "--traffic-json" in sys.argv:
         key = max((k for k in M if k[0].startswith(("freq_lstm_v3_kernel<false, false", "freq_lstm_v2_kernel<false, false", "freq_lstm_kernel<false"))),
                   key=lambda k: (k[0].startswith("freq_lstm_v3"), k[0].startswith("freq_lstm_v2"), k[1]))      # hardware-dispatched forms: grid = tiles
@@ -50,7 +109,7 @@ def main():
         read_b, write_b = fk * 1024 * FETCH_CORRECTION, wk * 1024
         alg_once = frames * (512 * 1024 + 2 * 1024 * 1024)
         alg_two = frames * (2 * 512 * 1024 + 2 * 1024 * 1024)
-        json.dump({"kernel": key[0], "frames": frames, "fetch_kib_raw": round(fk), "write_kib": round(wk),
+        json.dump({"kernel": key[0], "frames": frames, "lstm_hip_sha1": file_sha1("lstm.hip"), "fetch_kib_raw": round(fk), "write_kib": round(wk),
                    "fetch_correction": FETCH_CORRECTION, "read_bytes": round(read_b), "write_bytes": round(write_b),
                    "traffic_bytes": round(read_b + write_b),
                    "source": f"separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes ({os.path.basename(os.path.normpath(d))}); FETCH_SIZE doubled per "

@@ -282,6 +282,9 @@ const char *sdfa_last_error(void) { return g_err.c_str(); }
 int64_t sdfa_frame_index(int64_t n_samples, int sample_rate, int fps, int win, int hop, int ts_delta_ms,
                          int64_t *h_starts, int32_t *h_tslist, int64_t cap) {
     if (n_samples <= 0 || sample_rate <= 0 || fps <= 0 || win <= 0 || hop <= 0) return fail(SDFA_EINVAL, "bad frame_index arguments");
+    // the front-end kernels index a clip's samples in 32-bit arithmetic (|index| < 2^29: frontend.hip); refuse longer clips here,
+    // where the length is known on the host (9 h at 16 kHz; the reference's float32 frame arithmetic is exact only up to 2^24)
+    if (n_samples > 0x1fffffff) return fail(SDFA_EINVAL, "frame_index: clips of more than 2^29 - 1 samples are not supported (%lld given)", (long long)n_samples);
     const int64_t sliding = (int64_t)hop * 63 + win;
     int64_t count = 0;
     double idx = -1.0;

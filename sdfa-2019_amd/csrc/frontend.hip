@@ -234,10 +234,14 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(FrontendConsts c, 
     for (int i = tid; i < 1024; i += FE_THREADS) sW8[i >> 7][i & 127] = c.mel_w8[i];
     // window cut, zero pad, pre-emphasis (fp32, one rounding per op as numpy does)
     for (int i = tid; i < SLIDING; i += FE_THREADS) {
-        const int64_t g = s0 + i, last = len - 1;
-        // unconditional requests at clamped addresses, zero padding applied afterwards (see mel_columns_kernel)
-        const float r0 = pcm[off + (g < 0 ? 0 : (g > last ? last : g))];
-        const float rm = pcm[off + (g - 1 < 0 ? 0 : (g - 1 > last ? last : g - 1))];
+        const int64_t g = s0 + i, last = len > 0 ? len - 1 : 0;
+        // unconditional requests at clamped addresses, zero padding applied afterwards (see mel_columns_kernel); a clip of
+        // length 0 owns no sample at all, so nothing is requested for it (block-uniform condition: one frame, one clip)
+        float r0 = 0.f, rm = 0.f;
+        if (len > 0) {
+            r0 = pcm[off + (g < 0 ? 0 : (g > last ? last : g))];
+            rm = pcm[off + (g - 1 < 0 ? 0 : (g - 1 > last ? last : g - 1))];
+        }
         float x = (g >= 0 && g < len) ? r0 : 0.f;
         float xm = (i > 0 && g - 1 >= 0 && g - 1 < len) ? rm : 0.f;
         sY[i] = (i == 0) ? x : __fsub_rn(x, __fmul_rn(0.65f, xm));

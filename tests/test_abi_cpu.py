@@ -51,6 +51,14 @@ def test_frame_count_of_baseline_clip():
     assert len(s) == 156 and list(t[:5]) == [-117, -100, -83, -67, -50]
 
 
+def test_overlong_clip_is_refused_on_the_host():
+    """the front-end kernels index samples in 32-bit arithmetic; a clip beyond 2^29 - 1 samples is refused where its
+    length is known (sdfa_frame_index) instead of being truncated silently on the device."""
+    from sdfa_amd._lib import SdfaError
+    with pytest.raises(SdfaError, match="2\\^29"):
+        engine.frame_index(2 ** 29, 16000)
+
+
 def test_short_clip_raises_like_reference():
     with pytest.raises(AssertionError):
         engine.frame_index(2400, 8000)
