@@ -79,6 +79,9 @@ def load_source(path, sr, return_sound=False):
             return signal, (sound.cpu().numpy() if hasattr(sound, "cpu") else sound)
         return signal
     if ext in (".mp4", ".m4v", ".avi"):
-        raise ValueError(f"{path}: decoding {ext} needs audioread/ffmpeg (the reference's librosa.load route), which this image "
-                         "does not have -- extract the audio track to a .wav of any sample rate first")
+        wav = os.path.splitext(path)[0] + ".wav"
+        raise ValueError(f"{path}: decoding {ext} needs audioread/ffmpeg (the reference's librosa.load route, saber/data/audio/io.py:9-15), "
+                         f"which this image does not have.  Extract the audio track first -- `ffmpeg -i {path} -vn -ac 1 {wav}` (any sample "
+                         f"rate: the ingest resamples to 44.1 kHz and then to the model rate like the reference) -- and pass "
+                         f"`--eval_input {wav}` (evaluate.sh:12 names an .mp4 by default)")
     raise ValueError(f"{ext} is not supported!")

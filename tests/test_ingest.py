@@ -51,6 +51,70 @@ def test_oracle_resampler_properties():
     assert len(up) == int(np.ceil(len(y) * 44100 / 8000))
 
 
+# ---- non-circular anchor.  The resampler cannot be PINNED (resampy is absent, the reference holds no vector), and
+# the HIP kernel is checked against a restatement written for this build.  The one independent implementation of band-limited rate
+# conversion in the image is scipy.signal.resample_poly (polyphase FIR, its own Kaiser design): in the PASSBAND -- tones and a chirp
+# below 0.6 of the lower Nyquist -- any correct resampler must agree with it up to its own filter ripple.  resampy's published
+# algorithm samples its filter table every int(ratio * 512) entries when downsampling, which scales the output by
+# ratio * 512 / int(ratio * 512) (and moves the cutoff by the same factor): divided out below, stated per case.
+_ANCHOR_RATES = [(44100, 8000), (44100, 16000), (16000, 44100), (22050, 44100), (48000, 44100)]
+
+
+def _anchor_signals(a, b):
+    import scipy.signal as ss
+    n = int(0.5 * a)
+    t = np.arange(n) / a
+    nyq = min(a, b) / 2
+    tones = sum(0.15 * np.sin(2 * np.pi * f * nyq * t + i) for i, f in enumerate((0.05, 0.17, 0.31, 0.44, 0.6))).astype(np.float32)
+    chirp = (0.5 * ss.chirp(t, 50, t[-1], 0.6 * nyq)).astype(np.float32)
+    return {"tones": tones, "chirp": chirp}
+
+
+def _anchor_check(y, x, a, b):
+    import scipy.signal as ss
+    from math import gcd
+    g = gcd(a, b)
+    ref = ss.resample_poly(x.astype(np.float64), b // g, a // g, window=("kaiser", R.BETA))
+    m = min(len(y), len(ref))
+    ratio = b / a
+    gain = 1.0 if ratio >= 1 else (ratio * 512) / int(ratio * 512)          # resampy's table-step truncation (see above)
+    edge = int(0.02 * b) + 200                                               # filter transients at both ends
+    d = np.abs(np.asarray(y[:m], np.float64) / gain - ref[:m])[edge:-edge]
+    tol = 1e-4 if ratio >= 1 else 2e-3                                       # upsampling: exact table step; downsampling: the moved cutoff
+    assert d.max() <= tol, (a, b, d.max())
+
+
+@pytest.mark.parametrize("rates", _ANCHOR_RATES)
+def test_oracle_resampler_agrees_with_scipy_polyphase_in_the_passband(rates):
+    a, b = rates
+    for x in _anchor_signals(a, b).values():
+        _anchor_check(R.librosa_resample(x, a, b), x, a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rates", _ANCHOR_RATES)
+def test_hip_resampler_agrees_with_scipy_polyphase_in_the_passband(rates):
+    from sdfa_amd.resample import resample
+    a, b = rates
+    for x in _anchor_signals(a, b).values():
+        _anchor_check(resample(x, a, b).cpu().numpy(), x, a, b)
+
+
+def test_video_containers_fail_with_the_wav_route_spelled_out(tmp_path):
+    """evaluate.sh:12's default input is an .mp4, which the reference decodes through librosa -> audioread -> ffmpeg; this image has
+    no decoder, so the input is refused -- with the command that produces the .wav this build does read."""
+    from speech_anime import audio
+    for ext in (".mp4", ".m4v", ".avi"):
+        p = tmp_path / ("clip" + ext)
+        p.write_bytes(b"\x00" * 16)
+        with pytest.raises(ValueError) as e:
+            audio.load_source(str(p), 8000)
+        msg = str(e.value)
+        assert "ffmpeg -i" in msg and ".wav" in msg and "--eval_input" in msg
+    with pytest.raises(ValueError, match="not supported"):
+        audio.load_source(str(tmp_path / "clip.flac"), 8000)
+
+
 def test_read_tricorres_layout(tmp_path):
     from speech_anime import viewer
     p = tmp_path / "out.tricorrs"
