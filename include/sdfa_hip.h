@@ -244,6 +244,10 @@ int sdfa_ensemble_mean(const float *d_a, const float *d_b, int64_t n, float *d_o
  *                      4 = split-bf16 x3 products (NOT exact fp32)
  *   "pca_lds"          0 = pca_dgrad_res_kernel (basis slab resident in LDS, persistent); 4 = pca_dgrad_kernel (register-direct, two
  *                      workgroups per CU: the fallback that shares a CU)
+ *   "time_lstm_split"  0 = by size: a chunk whose 32-frame time-LSTM tiles leave most CUs idle (a single clip: <= 2048 frames) splits each
+ *                      tile's gate rows over 2 cooperating workgroups that exchange h every step (time_lstm_split_kernel); 1 = never
+ *   "time_lstm_handoff" how those workgroups publish / consume h: 0 = write-through (sc1) stores + sc1 loads (default); bit 0 = plain
+ *                      stores + agent-scope release; bit 1 = agent-scope acquire + plain loads (the always-valid form, slower)
  *   "pca_unfused"      1 = the dgrad PCA expansion as two generic GEMM launches with the scatter epilogue (round-1 form)
  *   "conv_unfused"     1 = conv1_pool_kernel + conv23_kernel instead of the fused conv123_kernel (what the debug taps use)   */
 int sdfa_debug_set_option(const char *name, int value);
@@ -253,6 +257,10 @@ int sdfa_debug_keep_intermediates(sdfa_model *m, int on);   /* un-aliased worksp
 int64_t sdfa_debug_distinct_columns(const sdfa_model *m, int64_t n_frames, const void *d_workspace, void *stream);
 int sdfa_debug_tap(const sdfa_model *m, int what, int64_t n_frames, float *d_dst, const void *d_workspace,
                    void *stream);
+/* 1 if a workgroup of the small-batch time-LSTM kernel (cooperating workgroups exchange h every step, with BOUNDED waits) gave up
+ * waiting for a partner during the LAST sdfa_encoder_forward call on a chunk of n_frames frames -- its output is then invalid; 0
+ * otherwise (always, unless the device was so oversubscribed that a launch's workgroups could not run together).  Synchronises. */
+int sdfa_debug_time_lstm_timeout(const sdfa_model *m, int64_t n_frames, const void *d_workspace, void *stream);
 
 /* Per-stage device timing of the last forward calls made with profiling enabled (HIP events on the
  * caller's stream).  names: "conv1","conv23","freq_lstm","freq_proj","gx0","lstm0","gx1","lstm1",

@@ -637,6 +637,8 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
 // ================================================================================================
 namespace {
 
+constexpr int64_t CT_WORDS = 2048, CT_FLAGS = 16;
+
 struct Ws {
     int64_t P1, X3, HF, Z, GX, H0, H1, KP, QC, QP, ZK, R, SH, ZU, CT, total;   // offsets in floats
 };
@@ -660,7 +662,8 @@ Ws layout(int64_t Nc, bool keep) {
     w.R = take(2560 * Nc);   // regressor scratch: trunk 512 | a 512 | b 256 | coef 288 (+ second branch a/b)
     w.SH = take(2 * Nc + 5 * Mc + Mc / 1024 + 128);   // column-sharing tables (int32 / int64 counters)
     w.ZU = keep ? take(256 * Mc) : w.P1; // freq-proj output over distinct columns (pool1 is dead by then)
-    w.CT = take(64);                     // work-queue heads of persistent kernels (ints)
+    w.CT = take(CT_WORDS);               // ints: [0] / [1] work-queue heads of the persistent kernels; [16 ..] the flag block of
+                                         // time_lstm_split_kernel (timeout word + one flag per workgroup, at most 4 per CU-sized grid)
     w.total = o;
     return w;
 }
@@ -717,7 +720,11 @@ thread_local int g_sdfa_freq_lstm_shape = 0;
 thread_local int g_sdfa_pca_unfused = 0;
 thread_local int g_sdfa_conv_unfused = 0;
 thread_local int g_sdfa_pca_lds = 0;
+thread_local int g_sdfa_time_lstm_split = 0;
+thread_local int g_sdfa_time_lstm_handoff = 0;
 int sdfa_debug_set_option(const char *name, int value) {
+    if (name && !strcmp(name, "time_lstm_handoff")) { g_sdfa_time_lstm_handoff = value; return SDFA_OK; }
+    if (name && !strcmp(name, "time_lstm_split")) { g_sdfa_time_lstm_split = value; return SDFA_OK; }
     if (name && !strcmp(name, "gemm_variant")) { g_sdfa_gemm_variant = value; return SDFA_OK; }
     if (name && !strcmp(name, "freq_lstm_shape")) { g_sdfa_freq_lstm_shape = value; return SDFA_OK; }
     if (name && !strcmp(name, "pca_unfused")) { g_sdfa_pca_unfused = value; return SDFA_OK; }
@@ -917,7 +924,8 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
             gi.terms = stage_terms(m, STAGE_BODY);
             gi.reserve_cus = m->reserved_cus.load();
             pf.begin(gxn[l]); HIP_TRY(sdfa_launch_gemm(gi, s)); pf.end();
-            TimeLstmArgs ta{ws + w.GX, m->tl_w[l], hout[l], Nc, Mc, m->tl_wb[l], stage_terms(m, STAGE_BODY)};
+            TimeLstmArgs ta{ws + w.GX, m->tl_w[l], hout[l], Nc, Mc, m->tl_wb[l], stage_terms(m, STAGE_BODY),
+                            reinterpret_cast<unsigned *>(ws + w.CT) + CT_FLAGS, CT_WORDS - CT_FLAGS};
             pf.begin(lsn[l]); HIP_TRY(sdfa_launch_time_lstm(ta, s)); pf.end();
             xin = hout[l];
         }
@@ -1096,6 +1104,15 @@ int64_t sdfa_debug_distinct_columns(const sdfa_model *m, int64_t n_frames, const
     HIP_TRY(hipMemcpyAsync(counts, (const float *)d_workspace + w.SH, sizeof counts, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return counts[0];
+}
+
+int sdfa_debug_time_lstm_timeout(const sdfa_model *m, int64_t n_frames, const void *d_workspace, void *stream) {
+    if (!m || n_frames <= 0 || !d_workspace) return fail(SDFA_EINVAL, "debug_time_lstm_timeout: bad argument");
+    const Ws w = layout(round_up(n_frames, 128), m->keep);
+    unsigned word = 0;
+    HIP_TRY(hipMemcpyAsync(&word, reinterpret_cast<const unsigned *>((const float *)d_workspace + w.CT) + CT_FLAGS, sizeof word, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return (int)word;
 }
 
 int sdfa_debug_tap(const sdfa_model *m, int what, int64_t n_frames, float *d_dst, const void *d_workspace, void *stream) {

@@ -122,6 +122,8 @@ struct TimeLstmArgs {
     int64_t Nc, Mc;
     const void *Wb;      // mixed-precision modes: per direction bf16x8 [hi | lo][32 octets][1024 rows] (lstm.hip)
     int terms;           // 0 = fp32 MFMA; 1 = bf16; 3 = split-bf16
+    unsigned *flags;     // small-batch form (time_lstm_split_kernel): [0] timeout word, [4 ..] one flag per workgroup; null = never split
+    int64_t flag_words;  // words available at `flags`
 };
 hipError_t sdfa_launch_time_lstm(const TimeLstmArgs &a, hipStream_t s);
 

@@ -806,6 +806,196 @@ __global__ __launch_bounds__(512, 2) void time_lstm_kernel(TimeLstmArgs a) {
 #undef TL_W1
 }
 
+// ---------------------------------------------------------------------------- time LSTM, small batches
+// A single utterance (156 - 640 frames) gives time_lstm_kernel<1> only 10 - 40 workgroups, each alone on its CU for 64 sequential
+// steps of 16.8 MFLOP: two waves per SIMD, 27 us per step, 1.9 ms per layer whatever the clip length -- the largest stage of a
+// single-clip call.  Here the 1024 gate rows of a 32-frame tile are SPLIT over G = 2 workgroups on two CUs (four waves each, ONE per
+// SIMD, a wave owning one block of 32 hidden units x 4 gates exactly as in time_lstm_kernel), so a step's matrix work takes half the
+// time (13.7 us), and the two workgroups exchange their halves of h_t through global memory every step (+ 3 us):
+//   * a workgroup's slice of h_t goes to LDS (its own next-step operand) and, as before, to the H output rows -- here with
+//     WRITE-THROUGH (sc1) stores, which is what makes the H rows themselves the hand-off buffer;
+//   * every storing wave drains its stores (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, ONE lane publishes the step
+//     number in the workgroup's flag word (relaxed agent-scope atomic store);
+//   * wave 0 polls the partner's flag word (relaxed, s_sleep between polls, BOUNDED: a timeout sets a word in the workspace and the
+//     kernel runs on with whatever it has -- it must never hang), the workgroup meets again, and every thread fetches its share
+//     of the partner's slice with sc1 loads (they bypass this CU's L1, which another CU's stores never refresh) into LDS.
+// That is the publish / consume form MI355X_MICROARCH.md (visibility, "Valid forms", first table row) lists as measured for
+// hipMalloc'ed memory with one workgroup per CU (the launch asks for 96 KiB of LDS so that two never share one): no agent-scope
+// fence on either side.  The "time_lstm_handoff" option switches either side to the always-valid form (plain stores + agent release,
+// agent acquire + plain loads: 4 - 15 % slower, same bits).  Results do not depend on placement; the workgroups of a tile are
+// given block ids 8 apart only because such blocks were observed to share an XCD (its L2 then serves the exchange).  All workgroups
+// must be resident together: the launcher uses this kernel only while the grid fits the CUs.  Same k order and cell arithmetic as
+// time_lstm_kernel: bit-identical.  (The template also instantiates for G = 4 -- two waves per workgroup -- which measured no
+// faster: a wave's matrix work per step does not change.  profiles/r03_time_lstm_split.txt)
+template <int G>
+__global__ __launch_bounds__(512 / G) void time_lstm_split_kernel(TimeLstmArgs a, unsigned *flags, unsigned *timeout_word, int mode) {
+    extern __shared__ float4 sHs[];   // [2][64 k-quads][32 sequences]
+    constexpr int BT = 32, NW = 8 / G, NTHR = 64 * NW;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int q8 = blockIdx.x >> 3;
+    const int part = q8 % G, td = (q8 / G) * 8 + (blockIdx.x & 7);      // (tile, direction) index; parts of one tile: block ids 8 apart
+    const int dir = td & 1, hb = part * NW + wave;                      // hb: hidden block of 32 units this wave owns
+    const int64_t n0 = (int64_t)(td >> 1) * BT;
+
+    const float4 *__restrict__ GX = reinterpret_cast<const float4 *>(a.GX);
+    f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+    f32x16 acc[4][1];
+    const float4 *__restrict__ GXl = GX + (int64_t)(dir * 256 + hb * 32 + h) * a.Mc + n0 + l31;
+#define TS_GX(t_, gt, g) GXl[(int64_t)((gt) * 8 + 2 * (g)) * a.Mc + (int64_t)(t_) * a.Nc]
+#define TS_GX_ALL(t_)                                                                                               \
+    _Pragma("unroll") for (int gt = 0; gt < 4; ++gt) _Pragma("unroll") for (int g = 0; g < 4; ++g) {                  \
+        const float4 v = TS_GX(t_, gt, g);                                                                          \
+        acc[gt][0][4 * g + 0] = v.x; acc[gt][0][4 * g + 1] = v.y; acc[gt][0][4 * g + 2] = v.z; acc[gt][0][4 * g + 3] = v.w; \
+    }
+    TS_GX_ALL(dir ? 63 : 0)
+
+    // H rows of this direction as a buffer: write-through stores of the own slice, sc1 loads of the partners' slices
+    const unsigned long long hptr = (unsigned long long)(reinterpret_cast<float4 *>(a.H) + (int64_t)dir * 64 * a.Mc);
+    const unsigned long long huni = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(hptr >> 32)) << 32) |
+                                    (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)hptr);
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void *)huni, 0, 0x7fffffff, 0x00020000);
+    const unsigned ldm = (unsigned)a.Mc * 16u;                           // bytes per k-quad row (launcher: 64 rows stay below 2 GB)
+
+    const unsigned long long wptr = (unsigned long long)(reinterpret_cast<const float4 *>(a.W) + (size_t)dir * 64 * 1024 + hb * 128);
+    const unsigned long long wuni = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(wptr >> 32)) << 32) |
+                                    (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wptr);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)wuni, 0, 64 * 1024 * 16, 0x00020000);
+    const unsigned woff = (unsigned)((l31 + h * 1024) * 16);
+#define TS_W1(so, g_) __builtin_bit_cast(float4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(wrs, woff + 512 * (g_), so, 0))
+    float4 wn0, wn1, wn2, wn3;
+    { wn0 = TS_W1(0u, 0); wn1 = TS_W1(0u, 1); wn2 = TS_W1(0u, 2); wn3 = TS_W1(0u, 3); }
+    unsigned *my_flag = flags + (size_t)td * G + part;
+    bool dead = false;                 // a poll timed out: stop waiting for partners (the result is wrong and the timeout word says so)
+    for (int s = 0; s < 64; ++s) {
+        const int t = dir ? 63 - s : s;
+        const int tn = dir ? t - 1 : t + 1;
+        const unsigned tcol = (unsigned)(((int64_t)t * a.Nc + n0) * 16);
+        const float4 *sHc = sHs + (size_t)(s & 1) * 64 * BT;
+        float4 *sHn = sHs + (size_t)((s & 1) ^ 1) * 64 * BT;
+
+        if (s > 0) {
+            float4 wa0 = wn0, wa1 = wn1, wa2 = wn2, wa3 = wn3, wb0, wb1, wb2, wb3, ba, bb;
+#define TS_SB() __builtin_amdgcn_sched_barrier(0);
+#define TS_Q(W0, W1, W2, W3, B, q)                                              \
+    acc[0][0] = MFMA(SDFA_OP(f4c(W0, q)), SDFA_OP(f4c(B, q)), acc[0][0]);       \
+    acc[1][0] = MFMA(SDFA_OP(f4c(W1, q)), SDFA_OP(f4c(B, q)), acc[1][0]);       \
+    acc[2][0] = MFMA(SDFA_OP(f4c(W2, q)), SDFA_OP(f4c(B, q)), acc[2][0]);       \
+    acc[3][0] = MFMA(SDFA_OP(f4c(W3, q)), SDFA_OP(f4c(B, q)), acc[3][0]);
+#define TS_KB(CW0, CW1, CW2, CW3, CB, NW0, NW1, NW2, NW3, NB, so, bp)           \
+    {                                                                           \
+        TS_SB() NW0 = TS_W1(so, 0); NW1 = TS_W1(so, 1); TS_SB()                 \
+        TS_Q(CW0, CW1, CW2, CW3, CB, 0)                                         \
+        TS_SB() NW2 = TS_W1(so, 2); NW3 = TS_W1(so, 3); TS_SB()                 \
+        TS_Q(CW0, CW1, CW2, CW3, CB, 1)                                         \
+        TS_SB() NB = (bp)[0]; TS_SB()                                           \
+        TS_Q(CW0, CW1, CW2, CW3, CB, 2)                                         \
+        TS_Q(CW0, CW1, CW2, CW3, CB, 3)                                         \
+    }
+            const float4 *brow = sHc + h * BT + l31;          // row pair of k-block kb: brow + kb * 2 * BT
+            ba = brow[0];
+#pragma unroll 1
+            for (int tt = 0; tt < 4; ++tt) {
+                const float4 *bt = brow + tt * 16 * BT;
+                const float4 *bn = tt + 1 < 4 ? bt + 16 * BT : brow;
+                const unsigned so = (unsigned)tt * (8 * 2048 * 16);
+                const unsigned son = tt + 1 < 4 ? so + 8 * 2048 * 16 : 0u;
+                TS_KB(wa0, wa1, wa2, wa3, ba, wb0, wb1, wb2, wb3, bb, so + 1 * 2048 * 16, bt + 1 * 2 * BT)
+                TS_KB(wb0, wb1, wb2, wb3, bb, wa0, wa1, wa2, wa3, ba, so + 2 * 2048 * 16, bt + 2 * 2 * BT)
+                TS_KB(wa0, wa1, wa2, wa3, ba, wb0, wb1, wb2, wb3, bb, so + 3 * 2048 * 16, bt + 3 * 2 * BT)
+                TS_KB(wb0, wb1, wb2, wb3, bb, wa0, wa1, wa2, wa3, ba, so + 4 * 2048 * 16, bt + 4 * 2 * BT)
+                TS_KB(wa0, wa1, wa2, wa3, ba, wb0, wb1, wb2, wb3, bb, so + 5 * 2048 * 16, bt + 5 * 2 * BT)
+                TS_KB(wb0, wb1, wb2, wb3, bb, wa0, wa1, wa2, wa3, ba, so + 6 * 2048 * 16, bt + 6 * 2 * BT)
+                TS_KB(wa0, wa1, wa2, wa3, ba, wb0, wb1, wb2, wb3, bb, so + 7 * 2048 * 16, bt + 7 * 2 * BT)
+                TS_KB(wb0, wb1, wb2, wb3, bb, wa0, wa1, wa2, wa3, ba, son, bn)
+            }
+            TS_SB()
+#undef TS_KB
+#undef TS_Q
+#undef TS_SB
+            wn0 = wa0; wn1 = wa1; wn2 = wa2; wn3 = wa3;
+        }
+        // cell update: own slice of h_t -> LDS (next step's operand) and -> the H output rows, write-through
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 hq;
+            lstm_cell_quad(acc[0][0], acc[1][0], acc[2][0], acc[3][0], c, g, hq);
+            const int hq_idx = 8 * hb + 2 * g + h;
+            sHn[hq_idx * BT + l31] = hq;
+            // STORE-DATA HAZARD (found the hard way, round 3): a 16-byte buffer store whose `soffset` is a scalar REGISTER may be
+            // followed at once by a vector instruction that overwrites its data registers -- LLVM's hazard recogniser assumes the
+            // hardware interlocks that form (GCNHazardRecognizer::createsVALUHazard), gfx950 does not: lanes 12-15 / 28-31 of the
+            // stored quad then carried the NEXT quad's intermediate values.  So the whole offset goes in the vector operand
+            // (soffset = 0: the form the compiler does pad) and a wait state follows the store explicitly.
+            const unsigned off = (unsigned)hq_idx * ldm + (unsigned)l31 * 16u + tcol;
+            if (mode & 1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hq), hrs, off, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hq), hrs, off, 0, 16);   // aux 16 = sc1 (write-through)
+            asm volatile("s_nop 1" ::: "memory");
+        }
+        if (s + 1 < 64) {
+            // publish: every storing wave drains, the workgroup meets, one lane stores the step number (never 0)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                if (mode & 1) {      // plain stores: agent-scope release (write-back) in front of the flag, and its own drain (Guideline 16, Pitfall 12)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __hip_atomic_store(my_flag, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // the next step's input projection seeds the accumulators (requested now: its HBM latency runs under the hand-off)
+            TS_GX_ALL(tn)
+            // consume: wave 0 polls the partners' flags (lanes 0..G-2), bounded
+            if (wave == 0 && !dead) {
+                const int pl = lane < G - 1 ? lane : 0;
+                const int partner = pl >= part ? pl + 1 : pl;
+                const unsigned *pf = flags + (size_t)td * G + partner;
+                unsigned spins = 0;
+                for (;;) {
+                    const unsigned v = __hip_atomic_load(pf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__all((int)(v >= (unsigned)(s + 1)))) break;
+                    if (++spins > (1u << 20)) {                      // ~1 s: a partner is not running -- give up for good, say so, never hang
+                        if (lane == 0) __hip_atomic_store(timeout_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        dead = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            if (mode & 2) {      // plain loads below: ONE agent-scope acquire by the polling wave, drained before the barrier lets the others load
+                if (wave == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: keeps the loads below behind the poll
+            }
+            __syncthreads();
+            // the partners' slices of h_t: 64 - 64/G k-quad rows x 32 sequences, sc1 loads (never this CU's L1), into LDS
+            constexpr int NQ = 64 - 64 / G, PER = NQ * BT / NTHR;
+            float4 pv[PER];
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int idx = i * NTHR + tid, r = idx >> 5, col = idx & 31;
+                const int kq = r < part * (64 / G) ? r : r + 64 / G;      // skip the own slice
+                if (mode & 2) pv[i] = __builtin_bit_cast(float4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(hrs, (unsigned)kq * ldm + (unsigned)col * 16u, tcol, 0));
+                else pv[i] = __builtin_bit_cast(float4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(hrs, (unsigned)kq * ldm + (unsigned)col * 16u, tcol, 16));
+            }
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int idx = i * NTHR + tid, r = idx >> 5, col = idx & 31;
+                const int kq = r < part * (64 / G) ? r : r + 64 / G;
+                sHn[kq * BT + col] = pv[i];
+            }
+        }
+        __syncthreads();   // h_t complete in sHn (own and partners' slices) before anyone reads it
+    }
+#undef TS_GX
+#undef TS_GX_ALL
+#undef TS_W1
+}
+
 // ------------------------------------------------------------------------------ time LSTM on bf16 MFMA
 // Mixed-precision modes: the BiLSTM recurrence h_{t-1} * W_hh^T on v_mfma_f32_32x32x16_bf16 (TERMS 1 or 3, see
 // freq_lstm_bf16_kernel); input projection (from the GEMM), accumulation, cell state and gate math stay fp32.
@@ -1024,9 +1214,38 @@ static hipError_t launch_time_bf16(const TimeLstmArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
+extern thread_local int g_sdfa_time_lstm_handoff;   // api.cpp ("time_lstm_handoff"): bit 0 = plain stores + agent release, bit 1 = agent acquire + plain loads
+
+template <int G>
+static hipError_t launch_time_split(const TimeLstmArgs &a, hipStream_t s) {
+    const size_t lds = 96 * 1024;      // 64 KiB used; 96 KiB requested so that two workgroups never share a CU (see the kernel)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(time_lstm_split_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const unsigned grid = (unsigned)(a.Nc / 32 * 2 * G);
+    // flag words (one per workgroup) + the timeout word, zeroed every launch: a block of its own, a multiple of 16 bytes
+    e = hipMemsetAsync(a.flags, 0, ((size_t)grid + 4) * sizeof(unsigned), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(time_lstm_split_kernel<G>, dim3(grid), dim3(512 / G), lds, s, a, a.flags + 4, a.flags, g_sdfa_time_lstm_handoff);
+    return hipGetLastError();
+}
+
+extern thread_local int g_sdfa_time_lstm_split;   // api.cpp ("time_lstm_split" option): 0 = by size, 1 = never
+
 hipError_t sdfa_launch_time_lstm(const TimeLstmArgs &a, hipStream_t s) {
     // 64-frame tiles while they fill the 256 CUs (one 8-wave workgroup per CU); otherwise 32-frame tiles
     const bool big = (a.Nc / 64) * 2 >= 256;
+    if (!a.terms && a.flags && g_sdfa_time_lstm_split != 1) {
+        // small batches: the gate rows of a tile split over G cooperating workgroups (time_lstm_split_kernel).  They exchange h
+        // every step, so ALL of them must be resident at once: only while the grid fits the CUs (one workgroup per CU)
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        const int64_t wg1 = a.Nc / 32 * 2;                       // workgroups of time_lstm_kernel<1>
+        const bool range_ok = (int64_t)64 * a.Mc * 16 + (int64_t)a.Mc * 16 < 0x7fffffff && a.Nc % 128 == 0 && a.flag_words >= wg1 * 2 + 4;   // buffer offsets; 8-block groups
+        // G = 2: four waves per workgroup, one per SIMD.  (G = 4 -- two waves per workgroup -- was measured too: no faster, a wave's
+        // matrix work per step is the same; profiles/r03_time_lstm_split.txt.)
+        const int G = (range_ok && wg1 * 2 <= cus) ? 2 : 0;
+        if (G == 2) return launch_time_split<2>(a, s);
+    }
     if (a.terms) {
         if (!a.Wb) return hipErrorInvalidValue;
         if (a.terms == 1) return big ? launch_time_bf16<2, 1>(a, s) : launch_time_bf16<1, 1>(a, s);

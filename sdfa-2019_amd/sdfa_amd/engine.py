@@ -364,6 +364,10 @@ class Engine(FrontendOnly):
         """Distinct columns evaluated by the last shared encoder call on a chunk of n_frames (reporting only)."""
         return int(check(lib.sdfa_debug_distinct_columns(self._m, int(n_frames), _ptr(self._ws), _stream())))
 
+    def time_lstm_timeout(self, n_frames):
+        """1 if the small-batch time-LSTM kernel gave up waiting for a partner workgroup in the last encoder call (tests)."""
+        return int(check(lib.sdfa_debug_time_lstm_timeout(self._m, int(n_frames), _ptr(self._ws), _stream())))
+
     def tap(self, what, n_frames):
         shapes = {0: (32, 64, 64), 1: (64, 32, 64), 2: (256, 64), 3: (64, 512)}
         dst = torch.empty((n_frames,) + shapes[what], dtype=torch.float32, device=self.device)
