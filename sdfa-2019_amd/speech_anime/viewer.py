@@ -93,6 +93,13 @@ def has_template():
     return _solver is not None
 
 
+def clear_template():
+    """Forget the template mesh (evaluate() then writes the dgrad track only)."""
+    global _template_verts, _template_faces, _template_c_indices, _template_corres, _solver
+    _template_verts = _template_faces = _template_corres = _solver = None
+    _template_c_indices = []
+
+
 def template_faces():
     return _template_faces
 

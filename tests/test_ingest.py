@@ -153,6 +153,8 @@ def test_config0_wav_16k_through_8k_model_end_to_end(tmp_path, synth_sd):
     ck = tmp_path / "epoch0050.ckpt"
     torch.save({"epoch": 50, "global_step": 1, "state": {k: torch.from_numpy(np.array(v)) for k, v in synth_sd["dgrad"].items()}}, str(ck))
     DatasetSlidingWindow.hparams = None
+    from speech_anime import viewer
+    viewer.clear_template()                       # module state: a template set by another test has another topology
     res = evaluate_model(dict(mode="evaluate", load_from=str(ck), custom_hparams="dgrad", output_dir=str(tmp_path / "out"),
                               eval_input=str(wav), eval_spk_cond="m1", overwrite_video=True, export_mesh_frames=True))
     _, ts, animes = res[0]

@@ -102,6 +102,8 @@ def test_evaluate_cli_path_writes_dgrad_track(tmp_path, synth_sd):
     hpj = tmp_path / "hparams.json"
     hpj.write_text('{"audio": {"sample_rate": 16000}}')
     DatasetSlidingWindow.hparams = None
+    from speech_anime import viewer
+    viewer.clear_template()
     res = evaluate_model(dict(mode="evaluate", load_from=str(ck), custom_hparams=str(hpj), output_dir=str(tmp_path / "out"),
                               eval_input=str(wav), eval_spk_cond="m1", overwrite_video=True, export_mesh_frames=True))
     path, ts, animes = res[0]
