@@ -416,7 +416,9 @@ class HostPipeline:
 
     def __init__(self, engine):
         self.eng = engine
-        self.copy_stream = torch.cuda.Stream(device=engine.device)
+        # high priority: HIP then gives the stream a hardware queue of its own -- two streams that share a queue run one after the
+        # other (measured: profiles/r03_overlap_env.txt), and the copies must run UNDER the kernels
+        self.copy_stream = torch.cuda.Stream(device=engine.device, priority=-1)
         self.bufs = [None, None]
         self.tmp = None                 # second pass of test-time ensembling
         self.done = [None, None]        # copy-done event of the last copy out of each buffer
