@@ -276,6 +276,13 @@ def main():
     eng = Engine(sd, device=dev, max_frames=a.chunk, precision=a.precision, autotune=not any(kv.startswith("freq_lstm_shape=") for kv in a.opt))
     if a.reserve_cus:
         eng.set_reserved_cus(a.reserve_cus)
+    comm_probe = None
+    if dist_on and a.backend == "nccl":
+        # run the kernels on a stream the process group's collectives really overlap with (probed: sdfa_amd/streams.py)
+        from sdfa_amd import streams as sstreams
+        cs, ok, log = sstreams.pick_compute_stream_for_collectives(dev, sstreams.engine_busy(eng))
+        torch.cuda.set_stream(cs)
+        comm_probe = {"overlaps": ok, "probes": log}
 
     # ---- this rank's clips: global clip ids [rank*C, (rank+1)*C), PCM resident in HBM before timing
     C = a.clips_per_gpu
@@ -457,9 +464,34 @@ def main():
         outs_host = [torch.empty((F, eng.out_dim), dtype=torch.float32, pin_memory=True) for _ in range(2)]
         table = (frame_clip, frame_start, hop)
 
+        # The PCM of step k+1 goes up on an upload stream while step k computes (two device PCM buffers).  Measured (tools/trace_hostio.sh):
+        # an upload issued on the compute stream at the START of a step can queue behind the previous step's last device -> host
+        # copy (1.4 GB, 26 ms) inside the runtime's copy path and hold the step's first kernel for exactly that long -- in 4 of 10
+        # processes.  Issued a whole step ahead, nothing waits for it.
+        up_stream = torch.cuda.Stream(device=dev)
+        pcm_dev = [pcm, torch.empty_like(pcm)]
+        up_done = [None, None]
+        consumed = [None, None]
+
+        def upload(k):
+            b = k & 1
+            with torch.cuda.stream(up_stream):
+                if consumed[b] is not None:
+                    up_stream.wait_event(consumed[b])                    # the front end that last read this buffer
+                pcm_dev[b].copy_(pcm_host, non_blocking=True)            # H2D of step k's PCM (1 KB per frame)
+                up_done[b] = torch.cuda.Event()
+                up_done[b].record(up_stream)
+
         def step_host(k, share):
-            pcm.copy_(pcm_host, non_blocking=True)                       # H2D of this step's PCM (1 KB per frame)
-            eng.mel_frontend_device(pcm, clip_off, clip_len, frame_clip, frame_start, sr, out=feat, gather=(a.frontend == "gather"))
+            b = k & 1
+            if up_done[b] is None:
+                upload(k)
+            torch.cuda.current_stream().wait_event(up_done[b])
+            up_done[b] = None
+            eng.mel_frontend_device(pcm_dev[b], clip_off, clip_len, frame_clip, frame_start, sr, out=feat, gather=(a.frontend == "gather"))
+            consumed[b] = torch.cuda.Event()
+            consumed[b].record()
+            upload(k + 1)                                                # the next step's input, a whole step ahead
             eng.forward_host(feat, spk, out=outs_host[k & 1], table=table if share else None, piece=a.chunk, wait=False)
 
         host_io = {}
@@ -518,6 +550,8 @@ def main():
                        "gather": (Mode.kind if Mode.gatherer is not None or Mode.direct is not None else "none") if dist_on else "none (1 GPU)",
                        "force_gather_world1": bool(a.force_gather and world == 1), "backend": a.backend if dist_on else None,
                        "reserved_cus": a.reserve_cus,
+                       # does an asynchronous RCCL all-gather run UNDER the kernels of the stream the steps ran on?  (probe before the run)
+                       "collective_overlap_probe": comm_probe,
                        "gather_auto_ms_per_step": None if auto is None else {k: round(v, 2) for k, v in auto.items()},
                        "gather_checksum_ok": gather_check, "weights": "synthetic seed 1234",
                        "mesh_stage": None if mesh is None else f"seek to 60 fps + mesh solve, {mesh[1].n_queries} video frames x {mesh[0].n_verts} vertices per GPU per step"},
@@ -540,6 +574,7 @@ def main():
         res["peak_device_memory_gb"] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 2)
         if host_io is not None:
             tw = host_io["fp32"]
+            host_io["copy_stream_overlaps"] = None if eng._host is None else {"overlaps": bool(eng._host.copy_overlaps), "probes": eng._host.copy_probe}
             res["with_h2d_d2h"] = {
                 "note": "PCIe-inclusive twin of `value` (SURVEY 8(d) 'report both'): the same steps with the PCM copied host -> device and ALL "
                         "output rows (359 KB per frame) copied device -> pinned host inside the timed region, the copies of one piece "
@@ -548,6 +583,7 @@ def main():
                 "d2h_gb_per_step": round(F * eng.out_dim * 4 / 1e9, 3),
                 "d2h_alone_gbps": round(host_io["d2h_alone_gbps"], 1),
                 "rows_identical_to_device_path": host_io["rows_identical_to_device_path"],
+                "copy_stream_overlaps_kernels": host_io["copy_stream_overlaps"],      # probed when the pipeline was created (sdfa_amd/streams.py)
                 "with_column_sharing": None if "fp32_column_sharing" not in host_io else round(F * a.steps / host_io["fp32_column_sharing"], 1)}
         if surface is not None:
             res["surface"] = surface

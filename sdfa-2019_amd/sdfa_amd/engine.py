@@ -416,9 +416,10 @@ class HostPipeline:
 
     def __init__(self, engine):
         self.eng = engine
-        # high priority: HIP then gives the stream a hardware queue of its own -- two streams that share a queue run one after the
-        # other (measured: profiles/r03_overlap_env.txt), and the copies must run UNDER the kernels
-        self.copy_stream = torch.cuda.Stream(device=engine.device, priority=-1)
+        # a stream whose copies REALLY run under this stream's kernels: which new stream shares the compute stream's hardware queue
+        # is a matter of creation order, priorities and GPU_MAX_HW_QUEUES, so candidates are probed (sdfa_amd/streams.py)
+        from .streams import pick_copy_stream, engine_busy
+        self.copy_stream, self.copy_overlaps, self.copy_probe = pick_copy_stream(engine.device, engine_busy(engine))
         self.bufs = [None, None]
         self.tmp = None                 # second pass of test-time ensembling
         self.done = [None, None]        # copy-done event of the last copy out of each buffer
