@@ -244,8 +244,10 @@ int sdfa_ensemble_mean(const float *d_a, const float *d_b, int64_t n, float *d_o
  *                      4 = split-bf16 x3 products (NOT exact fp32)
  *   "pca_lds"          0 = pca_dgrad_res_kernel (basis slab resident in LDS, persistent); 4 = pca_dgrad_kernel (register-direct, two
  *                      workgroups per CU: the fallback that shares a CU)
- *   "time_lstm_split"  0 = by size: a chunk whose 32-frame time-LSTM tiles leave most CUs idle (a single clip: <= 2048 frames) splits each
- *                      tile's gate rows over 2 cooperating workgroups that exchange h every step (time_lstm_split_kernel); 1 = never
+ *   "time_lstm_split"  0 = by size: a chunk whose 32-frame time-LSTM tiles leave most CUs idle (a single clip) splits each tile's gate rows
+ *                      over 2 cooperating workgroups that exchange h every step -- 16-frame tiles on v_mfma_f32_16x16x4_f32 up to 1,024
+ *                      frames (time_lstm_split16_kernel), 32-frame tiles up to 2,048 (time_lstm_split_kernel); 1 = never; 32 = 32-frame
+ *                      tiles only; 16 = 16-frame tiles or an error
  *   "time_lstm_handoff" how those workgroups publish / consume h: 0 = write-through (sc1) stores + sc1 loads (default); bit 0 = plain
  *                      stores + agent-scope release; bit 1 = agent-scope acquire + plain loads (the always-valid form, slower)
  *   "pca_unfused"      1 = the dgrad PCA expansion as two generic GEMM launches with the scatter epilogue (round-1 form)

@@ -141,6 +141,7 @@ struct sdfa_model {
     int precision = SDFA_PREC_FP32;
     const float *gx_w[2], *tl_w[2];
     const void *tl_wb[2] = {nullptr, nullptr};   // BiLSTM recurrent weights as bf16 hi/lo planes (mixed-precision modes)
+    const float *tl_w16[2] = {nullptr, nullptr}; // BiLSTM recurrent weights in the operand order of time_lstm_split16_kernel
     const float *kp_w, *qc_w, *qp_w, *at_v, *at_b;
     struct Fc { const float *w, *b, *cw; int K, P, Ppad, Pstore; int act; };
     Fc trunk, br[2][3], off[3];
@@ -250,6 +251,20 @@ void pack_rec_bf16(uint16_t *dst, const float *whh, const int *perm) {
                 dst[((size_t)o * 1024 + p) * 8 + e] = hi;
                 dst[((size_t)(32 + o) * 1024 + p) * 8 + e] = lo;
             }
+}
+
+// Recurrent weights of one BiLSTM direction for time_lstm_split16_kernel (v_mfma_f32_16x16x4_f32): float4 [16 K16][4 g][1024 gate rows],
+// element j of (K16, g, p) = W_hh[perm[p]][k], k = 8 kb + {0, 4, 1, 5}[g] (m = 0) / {2, 6, 3, 7}[g] (m = 1) with kb = 2 K16 + (j >> 1),
+// m = j & 1 -- the order in which the 32x32x2 kernels add a gate row's products (lstm.hip), so both forms give the same bits.
+void pack_rec_16x16x4(float *dst, const float *whh, const int *perm) {
+    static const int kk[2][4] = {{0, 4, 1, 5}, {2, 6, 3, 7}};
+    for (int K16 = 0; K16 < 16; ++K16)
+        for (int g = 0; g < 4; ++g)
+            for (int p = 0; p < 1024; ++p)
+                for (int j = 0; j < 4; ++j) {
+                    const int kb = 2 * K16 + (j >> 1), m = j & 1, k = 8 * kb + kk[m][g];
+                    dst[(((size_t)K16 * 4 + g) * 1024 + p) * 4 + j] = whh[(size_t)perm[p] * 256 + k];
+                }
 }
 
 int pack_fc(sdfa_model *m, Packer &pk, const std::string &key, int P, int Kin, bool cond, int act, size_t off[3],
@@ -514,10 +529,11 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
         memcpy(&pk.buf[o_fpb], b->data(), 256 * 4);
     }
     // ---- time BiLSTM (bias=False): input projections as one 2048-row GEMM per layer, recurrent weights K4
-    size_t o_gx[2], o_tl[2], o_tlb[2];
+    size_t o_gx[2], o_tl[2], o_tlb[2], o_tl16[2];
     {
         const auto perm = gate_perm(256);
         for (int l = 0; l < 2; ++l) o_tlb[l] = pk.add((size_t)2 * 2 * 32 * 1024 * 8 / 2);   // bf16 planes, two per float slot
+        for (int l = 0; l < 2; ++l) o_tl16[l] = pk.add((size_t)2 * 16 * 4 * 1024 * 4);      // two directions, 16x16x4 operand order
         const char *suf[2] = {"", "_reverse"};
         for (int l = 0; l < 2; ++l) {
             const int Kin = l == 0 ? 256 : 512;
@@ -530,6 +546,7 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
                 for (int p = 0; p < 1024; ++p) memcpy(&both[((size_t)d * 1024 + p) * Kin], &(*wih)[(size_t)perm[p] * Kin], Kin * 4);
                 size_t o = pack_k4(pk, whh->data(), 1024, 256, 256, 0, 256, 1024, perm.data());
                 pack_rec_bf16(reinterpret_cast<uint16_t *>(&pk.buf[o_tlb[l]]) + (size_t)d * 2 * 32 * 1024 * 8, whh->data(), perm.data());
+                pack_rec_16x16x4(&pk.buf[o_tl16[l]] + (size_t)d * 16 * 4 * 1024 * 4, whh->data(), perm.data());
                 if (d == 0) first = o;
                 else if (o != first + (size_t)64 * 1024 * 4) return fail(SDFA_ESTATE, "internal: time-lstm weights not contiguous");
             }
@@ -612,7 +629,7 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
     m->w3 = d + o_conv[2][0]; m->b3 = d + o_conv[2][1]; m->s3 = d + o_conv[2][2]; m->t3 = d + o_conv[2][3];
     m->fl_wb = d + o_flwb;
     m->fl_w = d + o_flw; m->fl_b = d + o_flb; m->fp_w = d + o_fpw; m->fp_b = d + o_fpb;
-    for (int l = 0; l < 2; ++l) { m->gx_w[l] = d + o_gx[l]; m->tl_w[l] = d + o_tl[l]; m->tl_wb[l] = d + o_tlb[l]; }
+    for (int l = 0; l < 2; ++l) { m->gx_w[l] = d + o_gx[l]; m->tl_w[l] = d + o_tl[l]; m->tl_wb[l] = d + o_tlb[l]; m->tl_w16[l] = d + o_tl16[l]; }
     m->kp_w = d + o_kp; m->qc_w = d + o_qc; m->qp_w = d + o_qp; m->at_v = d + o_v; m->at_b = d + o_b;
     auto bind = [&](sdfa_model::Fc &fc, size_t o[3]) {
         fc.w = d + o[0]; fc.b = d + o[1]; fc.cw = o[2] == (size_t)-1 ? nullptr : d + o[2];
@@ -925,7 +942,7 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
             gi.reserve_cus = m->reserved_cus.load();
             pf.begin(gxn[l]); HIP_TRY(sdfa_launch_gemm(gi, s)); pf.end();
             TimeLstmArgs ta{ws + w.GX, m->tl_w[l], hout[l], Nc, Mc, m->tl_wb[l], stage_terms(m, STAGE_BODY),
-                            reinterpret_cast<unsigned *>(ws + w.CT) + CT_FLAGS, CT_WORDS - CT_FLAGS};
+                            reinterpret_cast<unsigned *>(ws + w.CT) + CT_FLAGS, CT_WORDS - CT_FLAGS, m->tl_w16[l]};
             pf.begin(lsn[l]); HIP_TRY(sdfa_launch_time_lstm(ta, s)); pf.end();
             xin = hout[l];
         }

@@ -124,6 +124,7 @@ struct TimeLstmArgs {
     int terms;           // 0 = fp32 MFMA; 1 = bf16; 3 = split-bf16
     unsigned *flags;     // small-batch form (time_lstm_split_kernel): [0] timeout word, [4 ..] one flag per workgroup; null = never split
     int64_t flag_words;  // words available at `flags`
+    const float *W16;    // time_lstm_split16_kernel: per direction float4 [16 K16][4 g][1024 rows] (api.cpp pack_rec_16x16x4); null = not packed
 };
 hipError_t sdfa_launch_time_lstm(const TimeLstmArgs &a, hipStream_t s);
 

@@ -996,6 +996,178 @@ __global__ __launch_bounds__(512 / G) void time_lstm_split_kernel(TimeLstmArgs a
 #undef TS_W1
 }
 
+// ------------------------------------------------------------------- time LSTM, small batches, 16-frame tiles
+// The next factor of two for a single clip: 16 frames per tile on v_mfma_f32_16x16x4_f32 (same FLOP per cycle as the 32x32x2 form,
+// half the columns), so a wave's matrix work per step halves again (512 MFMAs x 32 cycles = 6.8 us) and twice as many CUs take part.
+// Two workgroups per tile and direction as in time_lstm_split_kernel (same publish / consume protocol; four waves, one per SIMD, a
+// wave owns one block of 32 hidden units x 4 gates = 8 accumulator tiles of 16 x 16).
+//
+// BIT-IDENTITY with the 32x32x2 kernels.  An fp32 MFMA accumulates its products as an fma chain in k order, so the result depends
+// only on the ORDER in which a gate row's 256 products are added.  The 32x32x2 kernels add, per k-block kb, the pairs (8kb+q, 8kb+4+q),
+// q = 0..3 (K4 operands: lane half 0 holds k-quad 2kb, half 1 k-quad 2kb+1).  Here one MFMA adds FOUR products, lane group g = l >> 4
+// supplying the g-th: MFMA (kb, m), m = 0, 1, takes k = 8kb + {0, 4, 1, 5} (m = 0) / {2, 6, 3, 7} (m = 1) -- the same sequence.  Both
+// operands are stored in that order: the weights by the host ([K16 = kb / 2][g][gate row][j = 2 (kb & 1) + m], api.cpp), h by the lanes
+// that produce it (LDS [K16][g][frame][j]), so one 16-byte read per lane feeds four consecutive MFMAs.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ void lstm_cell_4(const f32x4v &ai, const f32x4v &af, const f32x4v &ag, const f32x4v &ao, f32x4v &c, float4 &hq) {
+    f32x2 hv[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = 2 * p;
+        f32x2 cp = {c[r], c[r + 1]};
+        const f32x2 ig = sigmoid2(f32x2{ai[r], ai[r + 1]});
+        const f32x2 fg = sigmoid2(f32x2{af[r], af[r + 1]});
+        const f32x2 gg = tanh2(f32x2{ag[r], ag[r + 1]});
+        const f32x2 og = sigmoid2(f32x2{ao[r], ao[r + 1]});
+        const f32x2 fc = fg * cp;
+        const f32x2 cn = __builtin_elementwise_fma(ig, gg, fc);
+        c[r] = cn.x; c[r + 1] = cn.y;
+        hv[p] = og * tanh2(cn);
+    }
+    hq = make_float4(hv[0].x, hv[0].y, hv[1].x, hv[1].y);
+}
+
+__global__ __launch_bounds__(256) void time_lstm_split16_kernel(TimeLstmArgs a, unsigned *flags, unsigned *timeout_word, int mode) {
+    extern __shared__ float4 sH16[];   // [2 buffers][16 K16][4 g][16 frames] float4 (j = 0..3): 2 x 16 KiB
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f = lane & 15, lg = lane >> 4;
+    const int q8 = blockIdx.x >> 3;
+    const int part = q8 & 1, td = (q8 >> 1) * 8 + (blockIdx.x & 7);     // parts of one tile: block ids 8 apart
+    const int dir = td & 1, hb = part * 4 + wave;                       // hb: hidden block of 32 units this wave owns
+    const int64_t n0 = (int64_t)(td >> 1) * 16;
+
+    // accumulators: tile (gate qg, half hh) holds gate rows hb*128 + qg*32 + 16 hh + 4 lg + r (r = register) of frame n0 + f
+    f32x4v acc[4][2], c[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) c[hh] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const float4 *__restrict__ GXl = reinterpret_cast<const float4 *>(a.GX) + (int64_t)(dir * 256 + hb * 32 + lg) * a.Mc + n0 + f;
+#define T16_GX_ALL(t_)                                                                                              \
+    _Pragma("unroll") for (int qg = 0; qg < 4; ++qg) _Pragma("unroll") for (int hh = 0; hh < 2; ++hh) {               \
+        const float4 v = GXl[(int64_t)(qg * 8 + 4 * hh) * a.Mc + (int64_t)(t_) * a.Nc];                            \
+        acc[qg][hh] = f32x4v{v.x, v.y, v.z, v.w};                                                                   \
+    }
+    T16_GX_ALL(dir ? 63 : 0)
+
+    const unsigned long long hptr = (unsigned long long)(reinterpret_cast<float4 *>(a.H) + (int64_t)dir * 64 * a.Mc);
+    const unsigned long long huni = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(hptr >> 32)) << 32) |
+                                    (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)hptr);
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void *)huni, 0, 0x7fffffff, 0x00020000);
+    const unsigned ldm = (unsigned)a.Mc * 16u;
+
+    // weights of this direction: float4 [16 K16][4 g][1024 rows]; lane (row-in-tile f, group lg) reads [K16][lg][hb*128 + tile*16 + f]
+    const unsigned long long wptr = (unsigned long long)(reinterpret_cast<const float4 *>(a.W16) + (size_t)dir * 16 * 4 * 1024 + hb * 128);
+    const unsigned long long wuni = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(wptr >> 32)) << 32) |
+                                    (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wptr);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)wuni, 0, 16 * 4 * 1024 * 16, 0x00020000);
+    const unsigned woff = (unsigned)((lg * 1024 + f) * 16);
+#define T16_W(K16, tile) __builtin_bit_cast(float4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(wrs, woff + (unsigned)(tile) * 256u, (unsigned)(K16) * (4 * 1024 * 16), 0))
+
+    unsigned *my_flag = flags + (size_t)td * 2 + part;
+    const unsigned *partner_flag = flags + (size_t)td * 2 + (part ^ 1);
+    bool dead = false;
+    for (int s = 0; s < 64; ++s) {
+        const int t = dir ? 63 - s : s;
+        const int tn = dir ? t - 1 : t + 1;
+        const unsigned tcol = (unsigned)(((int64_t)t * a.Nc + n0) * 16);
+        const float4 *sHc = sH16 + (size_t)(s & 1) * 1024;
+        float *sHn = reinterpret_cast<float *>(sH16 + (size_t)((s & 1) ^ 1) * 1024);
+
+        if (s > 0) {
+            const float4 *brow = sHc + lg * 16 + f;                 // [K16][lg][f]: + K16 * 64
+            float4 wa[8], wb[8], ba, bb;
+#pragma unroll
+            for (int tl = 0; tl < 8; ++tl) wa[tl] = T16_W(0, tl);
+            ba = brow[0];
+#define T16_STEP(WC, BC, WN, BN, Kn)                                                                                \
+            {                                                                                                       \
+                _Pragma("unroll") for (int tl = 0; tl < 8; ++tl) WN[tl] = T16_W(Kn, tl);                             \
+                BN = brow[(Kn) * 64];                                                                               \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
+                    _Pragma("unroll") for (int tl = 0; tl < 8; ++tl)                                                 \
+                        acc[tl >> 1][tl & 1] = MFMA16(SDFA_OP(f4c(WC[tl], j)), SDFA_OP(f4c(BC, j)), acc[tl >> 1][tl & 1]); \
+            }
+#pragma unroll 1
+            for (int K16 = 0; K16 < 16; K16 += 2) {
+                T16_STEP(wa, ba, wb, bb, K16 + 1)
+                T16_STEP(wb, bb, wa, ba, (K16 + 2) & 15)          // behind the last pair: K16 0 again (dropped)
+            }
+#undef T16_STEP
+        }
+        // cell update: hidden units 32 hb + 16 hh + 4 lg + r of frame f
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            float4 hq;
+            lstm_cell_4(acc[0][hh], acc[1][hh], acc[2][hh], acc[3][hh], c[hh], hq);
+            // LDS [K16 = 2 hb + hh][g = 2 (r & 1) + (lg & 1)][f][j = 2 (lg >> 1) + (r >> 1)]
+            const int K16 = 2 * hb + hh, jb = 2 * (lg >> 1), ga = lg & 1;
+            sHn[(((K16 * 4 + ga) * 16 + f) << 2) + jb] = hq.x;             // r = 0: g = a,     j = jb
+            sHn[(((K16 * 4 + 2 + ga) * 16 + f) << 2) + jb] = hq.y;         // r = 1: g = 2 + a, j = jb
+            sHn[(((K16 * 4 + ga) * 16 + f) << 2) + jb + 1] = hq.z;         // r = 2: g = a,     j = jb + 1
+            sHn[(((K16 * 4 + 2 + ga) * 16 + f) << 2) + jb + 1] = hq.w;     // r = 3: g = 2 + a, j = jb + 1
+            // H output rows, K4: quad row 8 hb + 4 hh + lg.  (soffset = 0 and a wait state: see time_lstm_split_kernel)
+            const unsigned off = (unsigned)(8 * hb + 4 * hh + lg) * ldm + (unsigned)f * 16u + tcol;
+            if (mode & 1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hq), hrs, off, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hq), hrs, off, 0, 16);
+            asm volatile("s_nop 1" ::: "memory");
+        }
+        if (s + 1 < 64) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                if (mode & 1) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __hip_atomic_store(my_flag, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            T16_GX_ALL(tn)
+            if (wave == 0 && !dead) {
+                unsigned spins = 0;
+                for (;;) {
+                    const unsigned v = __hip_atomic_load(partner_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__all((int)(v >= (unsigned)(s + 1)))) break;
+                    if (++spins > (1u << 20)) {
+                        if (lane == 0) __hip_atomic_store(timeout_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        dead = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            if (mode & 2) {
+                if (wave == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            __syncthreads();
+            // the partner's slice: quad rows (part ^ 1) * 32 .. + 31 of the 16 frames = 512 float4, two per thread
+            float4 pv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = i * 256 + tid, q = (part ^ 1) * 32 + (idx >> 4), col = idx & 15;
+                if (mode & 2) pv[i] = __builtin_bit_cast(float4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(hrs, (unsigned)q * ldm + (unsigned)col * 16u + tcol, 0, 0));
+                else pv[i] = __builtin_bit_cast(float4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(hrs, (unsigned)q * ldm + (unsigned)col * 16u + tcol, 0, 16));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = i * 256 + tid, q = (part ^ 1) * 32 + (idx >> 4), col = idx & 15;
+                // k = 4 q + r: k-block q >> 1, K16 = q >> 2, a = q & 1, j = 2 ((q >> 1) & 1) + (r >> 1), g = 2 (r & 1) + a
+                const int K16 = q >> 2, ga = q & 1, jb = 2 * ((q >> 1) & 1);
+                sHn[(((K16 * 4 + ga) * 16 + col) << 2) + jb] = pv[i].x;
+                sHn[(((K16 * 4 + 2 + ga) * 16 + col) << 2) + jb] = pv[i].y;
+                sHn[(((K16 * 4 + ga) * 16 + col) << 2) + jb + 1] = pv[i].z;
+                sHn[(((K16 * 4 + 2 + ga) * 16 + col) << 2) + jb + 1] = pv[i].w;
+            }
+        }
+        __syncthreads();
+    }
+#undef T16_GX_ALL
+#undef T16_W
+}
+
 // ------------------------------------------------------------------------------ time LSTM on bf16 MFMA
 // Mixed-precision modes: the BiLSTM recurrence h_{t-1} * W_hh^T on v_mfma_f32_32x32x16_bf16 (TERMS 1 or 3, see
 // freq_lstm_bf16_kernel); input projection (from the GEMM), accumulation, cell state and gate math stay fp32.
@@ -1229,6 +1401,17 @@ static hipError_t launch_time_split(const TimeLstmArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
+static hipError_t launch_time_split16(const TimeLstmArgs &a, hipStream_t s) {
+    const size_t lds = 96 * 1024;      // 32 KiB used; 96 KiB requested: one workgroup per CU (hand-off form, see time_lstm_split_kernel)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(time_lstm_split16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const unsigned grid = (unsigned)(a.Nc / 16 * 2 * 2);
+    e = hipMemsetAsync(a.flags, 0, ((size_t)grid + 4) * sizeof(unsigned), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(time_lstm_split16_kernel, dim3(grid), dim3(256), lds, s, a, a.flags + 4, a.flags, g_sdfa_time_lstm_handoff);
+    return hipGetLastError();
+}
+
 extern thread_local int g_sdfa_time_lstm_split;   // api.cpp ("time_lstm_split" option): 0 = by size, 1 = never
 
 hipError_t sdfa_launch_time_lstm(const TimeLstmArgs &a, hipStream_t s) {
@@ -1244,6 +1427,9 @@ hipError_t sdfa_launch_time_lstm(const TimeLstmArgs &a, hipStream_t s) {
         // G = 2: four waves per workgroup, one per SIMD.  (G = 4 -- two waves per workgroup -- was measured too: no faster, a wave's
         // matrix work per step is the same; profiles/r03_time_lstm_split.txt.)
         const int G = (range_ok && wg1 * 2 <= cus) ? 2 : 0;
+        // 16-frame tiles (time_lstm_split16_kernel) while even their grid -- twice the workgroups -- fits the CUs; option 16 / 32 force one
+        if (range_ok && a.W16 && g_sdfa_time_lstm_split != 32 && wg1 * 4 <= cus && a.flag_words >= wg1 * 4 + 4) return launch_time_split16(a, s);
+        if (g_sdfa_time_lstm_split == 16) return hipErrorInvalidValue;      // asked for, not possible at this size
         if (G == 2) return launch_time_split<2>(a, s);
     }
     if (a.terms) {

@@ -153,24 +153,25 @@ def test_reserved_cus_do_not_change_results(synth_sd):
 
 
 def test_split_time_lstm_is_bitwise_the_single_workgroup_form(synth_sd):
-    """Small batches: the gate rows of every 32-frame time-LSTM tile are split over 2 cooperating workgroups that exchange h
-    through global memory every step (time_lstm_split_kernel).  Same k order and cell arithmetic: not a bit may differ from
-    time_lstm_kernel<1>, at every size that takes the split, repeatedly, with both hand-off forms (a stale hand-off or a lost
-    store would show as a difference)."""
+    """Small batches: the gate rows of every time-LSTM tile are split over 2 cooperating workgroups that exchange h through global
+    memory every step -- 16-frame tiles on v_mfma_f32_16x16x4_f32 up to 1,024 frames (time_lstm_split16_kernel, operands stored in
+    the accumulation order of the 32x32x2 kernels), 32-frame tiles up to 2,048 (time_lstm_split_kernel).  Same order of products and
+    the same cell arithmetic: not a bit may differ from time_lstm_kernel<1>, at every size, repeatedly, with both hand-off forms (a
+    stale hand-off, a lost store or a wrong operand order would show as a difference)."""
     from sdfa_amd import _lib
     e = Engine(synth_sd["dgrad"], max_frames=4096)
     rs = np.random.RandomState(5)
-    for n, handoff in ((156, 0), (636, 0), (1500, 0), (156, 3), (1000, 1), (2000, 2)):
+    for n, split, handoff in ((156, 0, 0), (636, 0, 0), (1000, 0, 3), (156, 32, 0), (636, 32, 3), (1500, 0, 0), (1000, 32, 1), (2000, 0, 2), (17, 0, 0)):
         x = torch.from_numpy(rs.uniform(0, 1, (n, 64, 128, 3)).astype(np.float32)).cuda()
         try:
             _lib.set_option("time_lstm_split", 1)                         # never split
             z0, a0 = e.encoder(x)
-            _lib.set_option("time_lstm_split", 0)
+            _lib.set_option("time_lstm_split", split)                     # 0 = by size (16-frame tiles <= 1024 frames), 32 = 32-frame tiles only
             _lib.set_option("time_lstm_handoff", handoff)
             for rep in range(3):
                 z1, a1 = e.encoder(x)
                 assert e.time_lstm_timeout(n) == 0
-                assert torch.equal(z0, z1) and torch.equal(a0, a1), (n, handoff, rep)
+                assert torch.equal(z0, z1) and torch.equal(a0, a1), (n, split, handoff, rep)
         finally:
             _lib.set_option("time_lstm_split", 0)
             _lib.set_option("time_lstm_handoff", 0)

@@ -1,4 +1,4 @@
-"""Time-LSTM stage time per encoder call for small batches: time_lstm_kernel<1> (split off) against time_lstm_split_kernel<2 / 4>,
+"""Time-LSTM stage time per encoder call for small batches: time_lstm_kernel<1> (split 1) against time_lstm_split_kernel (32) and time_lstm_split16_kernel (0 = by size: 16-frame tiles up to 1,024 frames),
 with the sc1 hand-off (mode 0) and the release / acquire hand-off (mode 3).  Usage (GPU box): python tools/time_split_lstm.py"""
 import os
 import sys
@@ -13,7 +13,7 @@ rs = np.random.RandomState(0)
 print(f"{'frames':>7s} {'split':>6s} {'handoff':>8s} {'lstm0+lstm1 ms':>15s} {'whole encoder ms':>17s}")
 for n in (156, 636, 1000, 1900):
     x = torch.from_numpy(rs.uniform(0, 1, (n, 64, 128, 3)).astype(np.float32)).cuda()
-    for split, mode in ((1, 0), (2, 0), (2, 3), (4, 0), (4, 3), (0, 0)):
+    for split, mode in ((1, 0), (32, 0), (32, 3), (0, 0), (0, 3)):
         _lib.set_option("time_lstm_split", split)
         _lib.set_option("time_lstm_handoff", mode)
         for _ in range(3):
