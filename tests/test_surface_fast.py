@@ -175,3 +175,28 @@ def test_split_time_lstm_is_bitwise_the_single_workgroup_form(synth_sd):
         finally:
             _lib.set_option("time_lstm_split", 0)
             _lib.set_option("time_lstm_handoff", 0)
+
+
+def test_copy_stream_probe_and_ensembled_pipeline(eng):
+    """sdfa_amd/streams.py picks the copy stream by probing (a 128 MiB copy against the encoder on zeros) and logs what it saw; the
+    ensembling form of the pipeline (both passes in one launch group, mean on the device) is bitwise two separate passes averaged
+    with numpy's float32 roundings, in pieces too."""
+    sr = 16000
+    pcm = synth.make_pcm(11, int(2.5 * sr))
+    pad = 20 * sr // 1000
+    clips = [pcm, np.pad(pcm[:-pad], [[pad, 0]], "constant")]
+    feat, _, counts = eng.mel_frontend(clips, sr)
+    n = counts[0]
+    assert counts[1] == n and feat.shape[0] == 2 * n
+    spk = torch.full((n,), 4, dtype=torch.int64)
+    a = eng.forward_host(feat[:n].contiguous(), spk).numpy().copy()
+    b = eng.forward_host(feat[n:].contiguous(), spk).numpy().copy()
+    want = a
+    want += b
+    want = want / float(2)
+    got = eng.forward_host(feat, spk, table=eng.last_frame_table, ensemble=True, piece=128)      # 64-frame pieces of both passes
+    assert np.array_equal(got.numpy(), want)
+    host = eng._host
+    assert isinstance(host.copy_overlaps, bool) and len(host.copy_probe) >= 1
+    assert all({"priority", "kernels_ms", "copy_end_ms", "overlaps"} <= set(p) for p in host.copy_probe)
+    assert host.copy_probe[-1]["overlaps"] == host.copy_overlaps
