@@ -547,7 +547,7 @@ def main():
                                     f"stream of {C} sentences, {a.ragged_seconds} s@{sr} Hz synthetic PCM per GPU -> {a.head} (BASELINE configs[4] rehearsal)"),
                        "clips_per_gpu": C, "frames_per_gpu": F, "head": a.head, "chunk_frames": a.chunk,
                        "freq_lstm_form": eng.freq_lstm_form,      # picked by sdfa_model_autotune in the first warm-up step (bit-identical forms)
-                       "gather": (Mode.kind if Mode.gatherer is not None or Mode.direct is not None else "none") if dist_on else "none (1 GPU)",
+                       "gather": (Mode.kind if (Mode.gatherer is not None or Mode.direct is not None or (mesh is not None and mesh[3] is not None)) else "none") if dist_on else "none (1 GPU)",
                        "force_gather_world1": bool(a.force_gather and world == 1), "backend": a.backend if dist_on else None,
                        "reserved_cus": a.reserve_cus,
                        # does an asynchronous RCCL all-gather run UNDER the kernels of the stream the steps ran on?  (probe before the run)
