@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SDFA_ABI_VERSION 3   /* 3: + sdfa_ensemble_mean, sdfa_model_set_reserved_cus (round 3); 2: + seek, resample, mesh correspondences,
+#define SDFA_ABI_VERSION 3   /* 3: + sdfa_ensemble_mean, sdfa_model_set_reserved_cus, sdfa_debug_time_lstm_timeout (round 3); 2: + seek, resample, mesh correspondences,
                                 multi-destination regress, expand_coef, autotune (round 2); all earlier entry points unchanged */
 
 #define SDFA_OK            0
