@@ -31,6 +31,29 @@ def test_generate_animation_matches_reference_fixture(golden, synth_sd, sr):
     assert others["inputs"].shape == (len(ts), 3, 128, 64)
 
 
+def test_generate_animation_10s_matches_reference_fixture(golden, synth_sd):
+    """BASELINE clip length against the reference itself (oracle/gen_golden_10s.py: the reference's generate_animation on clips 0 and 1 of
+    the headline workload, 10 s @ 16 kHz): timestamps bit-exact, dgrad within the north star's 1e-4 on every frame -- through the single
+    call (16-frame split time-LSTM, small-batch GEMMs) and through generate_animation_batch (one launch group)."""
+    sr = 16000
+    g = golden["e2e_dgrad_10s"]
+    hp, model = _model(synth_sd["dgrad"], sr)
+    clips = [synth.make_pcm(c, 10 * sr) for c in (0, 1)]
+    worst = 0.0
+    for c, pcm in enumerate(clips):
+        ts, animes, _ = model.generate_animation(pcm, "m1", 0, 0, want_inputs=False)
+        assert list(ts) == list(g[f"clip{c}_tslist"]) and animes.shape == (636, 9976, 9)
+        flat = animes.reshape(636, -1)
+        worst = max(worst, float(np.abs(flat[:, ::193] - g[f"clip{c}_stride193"]).max()), float(np.abs(flat[g[f"clip{c}_frames"]] - g[f"clip{c}_full"]).max()))
+        assert np.abs(flat.astype(np.float64).sum(1) - g[f"clip{c}_sum"]).max() <= 89784 * 2e-6
+    assert worst <= 1e-4, worst
+    res = model.generate_animation_batch(clips, "m1")
+    for c in (0, 1):
+        flat = res[c][1].reshape(636, -1)
+        assert list(res[c][0]) == list(g[f"clip{c}_tslist"])
+        assert np.abs(flat[:, ::193] - g[f"clip{c}_stride193"]).max() <= 1e-4
+
+
 def test_fetch_audio_features_contract(golden, synth_sd):
     sr = 8000
     hp, model = _model(synth_sd["dgrad"], sr)

@@ -59,3 +59,16 @@ def test_end_to_end_generate_animation(golden, synth_sd):
     animes = animes.reshape(len(ts), 9976, 9)
     assert np.abs(animes[:, ::97] - g[f"sr{sr}_stride97"]).max() <= 2e-5
     assert np.abs(animes[10] - g[f"sr{sr}_frame10"]).max() <= 2e-5
+
+
+def test_end_to_end_10s_clip_at_the_baseline_length(golden, synth_sd):
+    """The oracle bench.py times and checks against (torch_oracle) pinned to the reference ITSELF at the BASELINE clip length: 10 s @
+    16 kHz, 636 frames, clip 0 of the headline workload (oracle/gen_golden_10s.py ran the reference's generate_animation)."""
+    sr = 16000
+    g = golden["e2e_dgrad_10s"]
+    ts, animes = TO.generate_animation(TO.TorchOracle(synth_sd["dgrad"], "dgrad"), synth.make_pcm(0, 10 * sr), sr, 2, batch=100)
+    assert np.array_equal(np.asarray(ts), g["clip0_tslist"]) and len(ts) == 636
+    animes = animes.reshape(len(ts), -1)
+    assert np.abs(animes[:, ::193] - g["clip0_stride193"]).max() <= 2e-5
+    assert np.abs(animes[g["clip0_frames"]] - g["clip0_full"]).max() <= 2e-5
+    assert np.abs(animes.astype(np.float64).sum(1) - g["clip0_sum"]).max() <= 89784 * 2e-6
