@@ -456,8 +456,7 @@ def main():
     # the step (H2D) and every output row delivered to pinned host memory inside the step (D2H, 359 KB per frame): pieces of
     # `chunk` frames, piece i's copy on a copy stream under piece i+1's kernels (Engine.forward_host), two alternating host
     # output buffers so that a step's last copy overlaps the next step's first piece.  Never `value`.
-    host_io = None
-    if world == 1 and not dist_on and not a.no_host_io and mesh is None:
+    def host_io_twin():
         Mode.out = None
         torch.cuda.empty_cache()
         pcm_host = pcm.cpu().pin_memory()
@@ -514,11 +513,25 @@ def main():
         e0.record(); outs_host[0].copy_(Mode.out, non_blocking=True); e1.record(); torch.cuda.synchronize()
         host_io["d2h_alone_gbps"] = F * eng.out_dim * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del outs_host, pcm_host
+        return host_io
+
+    host_io, host_io_error = None, None
+    if world == 1 and not dist_on and not a.no_host_io and mesh is None:
+        try:
+            host_io = host_io_twin()
+        except Exception as e:      # the headline above stands on its own: say what went wrong with the twin (e.g. no pinned memory)
+            host_io, host_io_error = None, repr(e)
+            torch.cuda.synchronize()
+            if Mode.out is None:
+                Mode.out = torch.empty((F, eng.out_dim), dtype=torch.float32, device=dev)
 
     # ---- the speech_anime surface: what a caller of generate_animation sees, wall clock, host work + copies included
     surface = None
     if world == 1 and not dist_on and not a.no_surface and a.precision == "fp32":
-        surface = surface_block(sd, a.head, sr, dev)
+        try:
+            surface = surface_block(sd, a.head, sr, dev)
+        except Exception as e:          # never at the price of the headline line
+            surface = {"error": repr(e)}
 
     # front end: timed separately (same stream, HIP events), outside the headline region
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -585,6 +598,8 @@ def main():
                 "rows_identical_to_device_path": host_io["rows_identical_to_device_path"],
                 "copy_stream_overlaps_kernels": host_io["copy_stream_overlaps"],      # probed when the pipeline was created (sdfa_amd/streams.py)
                 "with_column_sharing": None if "fp32_column_sharing" not in host_io else round(F * a.steps / host_io["fp32_column_sharing"], 1)}
+        if host_io_error is not None:
+            res["with_h2d_d2h"] = {"value": None, "error": host_io_error}
         if surface is not None:
             res["surface"] = surface
         if shared is not None:
