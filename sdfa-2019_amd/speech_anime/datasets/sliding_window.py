@@ -1,5 +1,7 @@
 """DatasetSlidingWindow -- the inference half of speech_anime/datasets/sliding_window.py (fetch_audio_features and
 the unit converters of speech_anime/datasets/speech_anime.py:128-164).  The training data loader is out of scope."""
+import weakref
+
 import numpy as np
 import torch
 
@@ -8,7 +10,9 @@ from sdfa_amd import engine as _engine
 
 class DatasetSlidingWindow:
     hparams = None
-    _engine = None          # set by SaberSpeechDrivenAnimation; a bare front-end engine is created on demand
+    _engine = None          # a bare front-end engine, created on demand
+    _engine_ref = None      # weak reference to the model's engine (set by SaberSpeechDrivenAnimation.load_state_dict): the class must
+                            # not keep a dropped model's weights and workspace alive
 
     # ---- units: same float32 roundings as the reference (speech_anime.py:128-164)
     @classmethod
@@ -59,7 +63,14 @@ class DatasetSlidingWindow:
                     audio_feat=feat.cpu().numpy() if as_numpy else feat)
 
     @classmethod
+    def use_engine(cls, engine):
+        cls._engine_ref = weakref.ref(engine)
+
+    @classmethod
     def _frontend_engine(cls):
+        eng = cls._engine_ref() if cls._engine_ref is not None else None
+        if eng is not None:
+            return eng
         if cls._engine is None:
             cls._engine = _engine.FrontendOnly()
         return cls._engine

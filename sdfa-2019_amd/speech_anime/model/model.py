@@ -81,7 +81,7 @@ class SaberSpeechDrivenAnimation:
     # ---- weights ------------------------------------------------------------------------------
     def load_state_dict(self, state_dict, strict=True):
         self._model.load_state_dict(state_dict, strict)
-        DatasetSlidingWindow._engine = self._model._engine
+        DatasetSlidingWindow.use_engine(self._model._engine)
         return self
 
     def eval(self):
