@@ -34,17 +34,16 @@ namespace {
 // instructions completely, and a vector instruction issued behind an MFMA of the same wave costs the matrix pipe its full
 // 4-5 cycles) -- so every vector instruction of the cell update is matrix-pipe time lost, and the update is written for
 // the fewest of them: two elements per instruction (v_pk_mul/add/fma_f32), exponent arguments negated / made absolute by
-// the source modifiers of v_exp_f32 instead of by separate multiplies.  Same operations on the same values as the scalar
-// form sigmoidf_acc / tanhf_acc of common.h (x * -log2e == -(x * log2e); (|x| * -2) * log2e == -|x * (2 log2e)|: a scaling by
-// two commutes with rounding), so the results are bit-identical to rounds 1-2.
+// the source modifiers of v_exp_f32 instead of by separate multiplies.  sigmoid2 / tanh2 are the same operations on the same
+// values as the scalar forms sigmoidf_acc / tanhf_acc of common.h (x * -log2e == -(x * log2e); (|x| * -2) * log2e ==
+// -|x * (2 log2e)|: a scaling by two commutes with rounding).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x2 rcp2(f32x2 d) { return f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)}; }
+__device__ __forceinline__ f32x2 exp2n(f32x2 y) { return f32x2{__builtin_amdgcn_exp2f(-y.x), __builtin_amdgcn_exp2f(-y.y)}; }   // 2^-y
 
 __device__ __forceinline__ f32x2 sigmoid2(f32x2 x) {      // 1 / (1 + exp(-x))
-    const f32x2 y = x * 1.4426950408889634f;
-    const f32x2 e = {__builtin_amdgcn_exp2f(-y.x), __builtin_amdgcn_exp2f(-y.y)};
-    return rcp2(e + 1.0f);
+    return rcp2(exp2n(x * 1.4426950408889634f) + 1.0f);
 }
 
 __device__ __forceinline__ f32x2 tanh2(f32x2 x) {         // (1 - e) / (1 + e), e = exp(-2|x|), sign restored
@@ -54,6 +53,20 @@ __device__ __forceinline__ f32x2 tanh2(f32x2 x) {         // (1 - e) / (1 + e), 
     return f32x2{__builtin_copysignf(t.x, x.x), __builtin_copysignf(t.y, x.y)};
 }
 
+// One quad (4 hidden units x this lane's column) of an LSTM step.
+//   FREQ = false (the BiLSTM recurrences): sigmoid2 / tanh2 as above, 41 vector instructions per element pair.
+//   FREQ = true  (the frequency LSTM, where the cell update is 8 % of the dominant kernel's time: 320 of its 560 vector instructions
+//   per wave and step are v_exp / v_rcp at ~11 cycles each, the rest ~5; round 3, same-call A/B 116.4 -> 115.3 ms per step):
+//     * tanh(g) = 2 sigmoid(2g) - 1: 7 instructions instead of 10 (no |x| / copysign pair, one add less).  Saturates correctly
+//       (e = inf -> rcp 0 -> -1; e = 0 -> 1); its absolute error near 0 is one rounding of a value near 1 (~1.2e-7) where the
+//       (1 - e) / (1 + e) form has ~3e-8 -- the size of sigmoid's own error, and g only enters through i * g.
+//     * sigmoid(o) * tanh(c') = (1 - e_c) / ((1 + e_o) (1 + e_c)), e_c = exp(-2c'), e_o = exp(-o): ONE reciprocal for both and no
+//       sign handling.  Needs a finite e_c: |c'| < step count = 32 here (|c_t| <= |f c_{t-1}| + |i g| < |c_{t-1}| + 1), so
+//       e_c <= 2^92.4; e_o may overflow -- the product is then inf, its reciprocal 0 and h = (1 - e_c) * 0 = 0 = sigmoid(-inf).
+//       (Not usable in the BiLSTM: 64 steps allow e_c = 2^185.)  Near c' = 0 it keeps the (1 - e) form's accuracy.
+//   The end-to-end error against the CPU port is unchanged (max |d dgrad| 7.5e-7 on the 10 s clip); all frequency-LSTM launch
+//   forms share this function and stay bit-identical to each other.
+template <bool FREQ = false>
 __device__ __forceinline__ void lstm_cell_quad(const f32x16 &ai, const f32x16 &af, const f32x16 &ag, const f32x16 &ao,
                                                f32x16 &c, int g, float4 &hq) {
     f32x2 hv[2];
@@ -64,16 +77,22 @@ __device__ __forceinline__ void lstm_cell_quad(const f32x16 &ai, const f32x16 &a
 #ifdef SDFA_FAKE_CELL   /* timing experiment only: what does the cell math cost? */
         { const f32x2 cn = f32x2{af[r], af[r + 1]} * cp + f32x2{ai[r], ai[r + 1]} * f32x2{ag[r], ag[r + 1]}; c[r] = cn.x; c[r + 1] = cn.y; hv[p] = f32x2{ao[r], ao[r + 1]} * cn; continue; }
 #endif
-        // (a fused form with one reciprocal per product -- 8 transcendental instructions per element instead of 10 --
-        // measured the same in round 2 and changes the last bits: not taken)
         const f32x2 ig = sigmoid2(f32x2{ai[r], ai[r + 1]});
         const f32x2 fg = sigmoid2(f32x2{af[r], af[r + 1]});
-        const f32x2 gg = tanh2(f32x2{ag[r], ag[r + 1]});
-        const f32x2 og = sigmoid2(f32x2{ao[r], ao[r + 1]});
-        const f32x2 fc = fg * cp;                                   // rounded product first, then one fused multiply-add:
-        const f32x2 cn = __builtin_elementwise_fma(ig, gg, fc);     // what the scalar form compiled to in rounds 1-2
-        c[r] = cn.x; c[r + 1] = cn.y;
-        hv[p] = og * tanh2(cn);
+        const f32x2 fc = fg * cp;                                   // rounded product first, then one fused multiply-add
+        if (FREQ) {
+            const f32x2 gg = __builtin_elementwise_fma(rcp2(exp2n(f32x2{ag[r], ag[r + 1]} * 2.8853900817779268f) + 1.0f), f32x2{2.0f, 2.0f}, f32x2{-1.0f, -1.0f});
+            const f32x2 cn = __builtin_elementwise_fma(ig, gg, fc);
+            c[r] = cn.x; c[r + 1] = cn.y;
+            const f32x2 eo = exp2n(f32x2{ao[r], ao[r + 1]} * 1.4426950408889634f), ec = exp2n(cn * 2.8853900817779268f);
+            hv[p] = (1.0f - ec) * rcp2((1.0f + eo) * (1.0f + ec));
+        } else {
+            const f32x2 gg = tanh2(f32x2{ag[r], ag[r + 1]});
+            const f32x2 og = sigmoid2(f32x2{ao[r], ao[r + 1]});
+            const f32x2 cn = __builtin_elementwise_fma(ig, gg, fc);
+            c[r] = cn.x; c[r + 1] = cn.y;
+            hv[p] = og * tanh2(cn);
+        }
     }
     hq = make_float4(hv[0].x, hv[0].y, hv[1].x, hv[1].y);
 }
@@ -258,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_v2_kernel(FreqLstmArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float4 hq;
-                lstm_cell_quad(acc[0][j], acc[1][j], acc[2][j], acc[3][j], c[j], g, hq);
+                lstm_cell_quad<true>(acc[0][j], acc[1][j], acc[2][j], acc[3][j], c[j], g, hq);
                 const int hq_idx = 8 * wave + 2 * g + h;
                 sH[hq_idx][j * 32 + l31] = hq;
                 HF[((m0 >> 7) * (int64_t)HF_SLAB_ROWS + (f * 64 + dir * 32 + hq_idx)) * 128 + (m0 & 127) + j * 32 + l31] = hq;
@@ -484,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_v3_kernel(FreqLstmArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float4 hq;
-                lstm_cell_quad(acc[0][j], acc[1][j], acc[2][j], acc[3][j], c[j], g, hq);
+                lstm_cell_quad<true>(acc[0][j], acc[1][j], acc[2][j], acc[3][j], c[j], g, hq);
                 const int hq_idx = 8 * wave + 2 * g + h;
                 sXH[cur ^ 1][16 + hq_idx][j * 32 + l31] = hq;
                 HF[((m0 >> 7) * (int64_t)HF_SLAB_ROWS + (f * 64 + dir * 32 + hq_idx)) * 128 + (m0 & 127) + j * 32 + l31] = hq;
@@ -656,7 +675,7 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_bf16_kernel(FreqLstmArgs a) 
             float4 hq[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                lstm_cell_quad(acc[0][j], acc[1][j], acc[2][j], acc[3][j], c[j], g, hq[g]);
+                lstm_cell_quad<true>(acc[0][j], acc[1][j], acc[2][j], acc[3][j], c[j], g, hq[g]);
                 HF[((m0 >> 7) * (int64_t)HF_SLAB_ROWS + (f * 64 + dir * 32 + 8 * wave + 2 * g + h)) * 128 + (m0 & 127) + j * 32 + l31] = hq[g];
             }
 #pragma unroll
