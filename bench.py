@@ -40,6 +40,7 @@ sys.path.insert(0, os.path.join(ROOT, "sdfa-2019_amd"))
 
 FLOP_FREQ_LSTM_PER_FRAME = 64 * 32 * 2 * 512 * (64 + 128) * 2      # 268.4 + 536.9 MFLOP
 FLOP_MODEL_PER_FRAME = 1.514e9
+FLOP_ATTENTION_PER_FRAME = 10.2e6                                    # SURVEY 8(a) a10 / DESIGN section 4: key projection 8.39 + query Conv1d 1.57 + query projection + tail
 FRONTEND_BYTES_PER_FRAME = 4 * 16000 / 60 + 64 * 128 * 3 * 4         # new PCM + feature write = 99.4 KB (at 16 kHz; 8 kHz: 98.8 KB)
 PEAK_FP32_MFMA_TFLOPS = 157.3                                        # MI355X_MICROARCH.md chip table
 PEAK_HBM_GBPS = 8000.0
@@ -235,6 +236,21 @@ def frontend_counter_bytes():
         if t.get("frontend_hip_sha1") != _sha1("frontend.hip"):
             return None, None
         return float(t["bytes_per_frame"]), os.path.relpath(path, ROOT)
+    except Exception:
+        return None, None
+
+
+def attention_counter_util():
+    """Time-weighted rocprofv3 MfmaUtil of the attention stage (profiles/r*_pmc/attention_mfma.json, written by profiles/pmc_summary.py
+    from the committed --pmc pass), or None when absent or csrc/attn.hip / csrc/gemm.hip have changed since."""
+    import glob
+    try:
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc", "attention_mfma.json")))[-1]
+        with open(path) as f:
+            t = json.load(f)
+        if t.get("attn_hip_sha1") != _sha1("attn.hip") or t.get("gemm_hip_sha1") != _sha1("gemm.hip"):
+            return None, None
+        return float(t["mfma_util_pct_time_weighted"]), os.path.relpath(path, ROOT)
     except Exception:
         return None, None
 
@@ -584,6 +600,13 @@ def main():
                          "counters_source": fe_src},
             "stage_ms_per_step": {k: round(v, 3) for k, v in stages.items()},
         }
+        # north_star: "MFMA utilisation on the attention stage against gfx950 peak" (target >= 40 %): key / query projections (MFMA GEMMs)
+        # + the softmax / context tail (vector + HBM), live stage time and the counter figure of the committed pass
+        att_util, att_src = attention_counter_util() if a.precision == "fp32" else (None, None)
+        att_ms = stages.get("attn_proj", 0.0) + stages.get("attn", 0.0)
+        res["attention"] = {"ms": round(att_ms, 3), "flop_per_frame": FLOP_ATTENTION_PER_FRAME,
+                            "frac_of_fp32_mfma_peak_by_flop": round(F * FLOP_ATTENTION_PER_FRAME / (att_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if att_ms > 0 else None,
+                            "mfma_util_pct_counters": att_util, "counters_source": att_src}
         res["peak_device_memory_gb"] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 2)
         if host_io is not None:
             tw = host_io["fp32"]

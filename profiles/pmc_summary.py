@@ -2,7 +2,11 @@
 """Per-kernel, per-launch-shape table from the three separate rocprofv3 --pmc passes (MfmaUtil, FETCH_SIZE, WRITE_SIZE).
 
 Usage: python profiles/pmc_summary.py <dir with MfmaUtil_/FETCH_SIZE_/WRITE_SIZE_counter_collection.csv> [--traffic-json out.json]
-                                      [--chunks 8192,8192,3968] [--frontend-json out.json --frames 20352]
+                                      [--chunks 8192,8192,3968] [--frontend-json out.json --frames 20352] [--attention-json out.json]
+
+--attention-json: the attention stage (north_star: "MFMA utilisation on the attention stage against gfx950 peak") = every dispatch
+between a launch group's second BiLSTM recurrence and its attn_kernel, inclusive: key projection, query Conv1d, query projection
+(gemm_k4_kernel) and the softmax / context tail.  MfmaUtil is weighted by each dispatch's duration in the same pass.
 
 --chunks: the frames of the consecutive launch groups of one step (bench.py --chunk: 20,352 frames = 8192 + 8192 + 3968).  A
 PERSISTENT kernel launches the same grid whatever the problem size, so (symbol, grid) cannot tell its 8192-frame launches from
@@ -73,6 +77,30 @@ def per_chunk(M, F, W, chunks):
             print(f"{k[0][:46]:46s} {frames:7d} {per:5d} {sum(mm) / per:10.1f} {sum(ff) / per * 1024 * FETCH_CORRECTION / 1e9:13.3f} {sum(ww) / per * 1024 / 1e9:10.3f}")
 
 
+def attention_stage(path):
+    """Dispatches of the attention stage in the MfmaUtil pass, by position: after the second time_lstm* launch of a launch group, up
+    to and including attn_kernel.  Returns (time-weighted MfmaUtil %, total ns, per-symbol rows)."""
+    rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Dispatch_Id"]))
+    n_lstm, inside, picked = 0, False, []
+    for r in rows:
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        if name.startswith("time_lstm"):
+            n_lstm += 1
+            inside = n_lstm % 2 == 0
+            continue
+        if inside and "at::" not in name and not name.startswith("__amd"):
+            picked.append((name, float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+            if name.startswith("attn_kernel"):
+                inside = False
+    tot = sum(t for _, _, t in picked)
+    by = collections.OrderedDict()
+    for name, u, t in picked:
+        e = by.setdefault(name, [0, 0.0, 0])
+        e[0] += 1; e[1] += u * t; e[2] += t
+    per = [{"kernel": k, "calls": v[0], "mfma_util_pct": round(v[1] / v[2], 2), "ns": v[2]} for k, v in by.items()]
+    return (sum(u * t for _, u, t in picked) / tot if tot else None), tot, per
+
+
 def main():
     d = sys.argv[1]
     M, F, W = (load(os.path.join(d, f"{c}_counter_collection.csv")) for c in ("MfmaUtil", "FETCH_SIZE", "WRITE_SIZE"))
@@ -101,6 +129,18 @@ def main():
                        "source": f"separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes ({os.path.basename(os.path.normpath(d))}), last launch of "
                                  "mel_columns_kernel + gather_features_kernel (the full batch); FETCH_SIZE doubled per MI355X_MICROARCH.md"},
                       open(sys.argv[sys.argv.index("--frontend-json") + 1], "w"), indent=1)
+    if "--attention-json" in sys.argv:
+        util, ns, per = attention_stage(os.path.join(d, "MfmaUtil_counter_collection.csv"))
+        if util is not None:
+            print()
+            print(f"attention stage (after the second BiLSTM recurrence .. attn_kernel), one step: {ns / 1e6:.3f} ms under the counter pass, time-weighted MfmaUtil {util:.1f} %")
+            for e in per:
+                print(f"  {e['kernel'][:60]:60s} calls {e['calls']:3d}  MfmaUtil {e['mfma_util_pct']:5.1f} %  {e['ns'] / 1e6:7.3f} ms")
+            json.dump({"mfma_util_pct_time_weighted": round(util, 2), "stage_ns_under_counters": ns, "kernels": per,
+                       "attn_hip_sha1": file_sha1("attn.hip"), "gemm_hip_sha1": file_sha1("gemm.hip"),
+                       "source": f"rocprofv3 --pmc MfmaUtil pass ({os.path.basename(os.path.normpath(d))}), one step of the headline workload; every dispatch between a launch "
+                                 "group's second time_lstm launch and its attn_kernel, weighted by its duration in that pass"},
+                      open(sys.argv[sys.argv.index("--attention-json") + 1], "w"), indent=1)
     if "--traffic-json" in sys.argv:
         key = max((k for k in M if k[0].startswith(("freq_lstm_v3_kernel<false, false", "freq_lstm_v2_kernel<false, false", "freq_lstm_kernel<false"))),
                   key=lambda k: (k[0].startswith("freq_lstm_v3"), k[0].startswith("freq_lstm_v2"), k[1]))      # hardware-dispatched forms: grid = tiles

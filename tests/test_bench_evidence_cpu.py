@@ -1,0 +1,67 @@
+"""bench.py's counter-derived figures (roofline.traffic, frontend.hbm_gbps_counters, attention.mfma_util_pct_counters) come from
+committed rocprofv3 passes, each stamped with the sha1 of the kernel source it was measured at: a figure must go null -- never stale
+-- once that source has changed.  And profiles/pmc_summary.py must pick the attention stage's dispatches by position."""
+import importlib.util
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_counter_figures_are_nulled_when_the_kernel_source_changed(tmp_path, monkeypatch):
+    bench = _load("bench_for_test", "bench.py")
+    prof = tmp_path / "profiles" / "r99_pmc"
+    prof.mkdir(parents=True)
+    (prof / "freq_lstm_traffic.json").write_text(json.dumps({"frames": 8192, "traffic_bytes": 1000, "algorithmic_bytes": 800, "lstm_hip_sha1": "L"}))
+    (prof / "frontend_traffic.json").write_text(json.dumps({"bytes_per_frame": 164000.0, "frontend_hip_sha1": "F"}))
+    (prof / "attention_mfma.json").write_text(json.dumps({"mfma_util_pct_time_weighted": 50.6, "attn_hip_sha1": "A", "gemm_hip_sha1": "G"}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    sha = {"lstm.hip": "L", "frontend.hip": "F", "attn.hip": "A", "gemm.hip": "G"}
+    monkeypatch.setattr(bench, "_sha1", lambda name: sha[name])
+    assert bench.traffic_from_profile(4096)[:2] == (500, 400)                  # scaled to the frames of a launch
+    assert bench.frontend_counter_bytes()[0] == 164000.0
+    assert bench.attention_counter_util()[0] == 50.6
+    for changed in ("lstm.hip", "frontend.hip", "attn.hip", "gemm.hip"):
+        sha2 = dict(sha, **{changed: "other"})
+        monkeypatch.setattr(bench, "_sha1", lambda name, s=sha2: s[name])
+        t, alg, why = bench.traffic_from_profile(4096)
+        assert (t is None and alg == 400 and "stale" in why) if changed == "lstm.hip" else t == 500
+        assert (bench.frontend_counter_bytes()[0] is None) == (changed == "frontend.hip")
+        assert (bench.attention_counter_util()[0] is None) == (changed in ("attn.hip", "gemm.hip"))
+
+
+def test_committed_counter_files_match_the_committed_kernels():
+    """The tree as committed must not carry stale evidence: the newest profiles/r*_pmc JSONs were measured at the csrc/ files next to
+    them (re-run tools/collect_profiles.sh + tools/install_profiles.sh after touching lstm.hip / frontend.hip / attn.hip / gemm.hip)."""
+    bench = _load("bench_for_test2", "bench.py")
+    t, alg, src = bench.traffic_from_profile(8192)
+    assert t is not None and t > alg > 0, src
+    assert bench.frontend_counter_bytes()[0] is not None
+    assert bench.attention_counter_util()[0] is not None
+
+
+def test_attention_stage_is_picked_by_dispatch_position(tmp_path):
+    pmc = _load("pmc_summary_for_test", "profiles/pmc_summary.py")
+    hdr = '"Correlation_Id","Dispatch_Id","Grid_Size","Kernel_Name","Counter_Name","Counter_Value","Start_Timestamp","End_Timestamp"\n'
+    seq = [("conv123_kernel", 75, 100), ("time_lstm_kernel<2>", 84, 100), ("gemm_fat_kernel<0>", 90, 100), ("time_lstm_kernel<2>", 84, 100),
+           ("gemm_k4_kernel<0>", 80, 300), ("gemm_k4_kernel<0>", 60, 100), ("attn_kernel", 0, 100), ("gemm_k4_kernel<1>", 50, 1000), ("pca_dgrad_res_kernel", 70, 100),
+           # second launch group
+           ("time_lstm_kernel<1>", 82, 100), ("time_lstm_kernel<1>", 82, 100), ("gemm_k4_kernel<0>", 70, 100), ("attn_kernel", 0, 100), ("gemm_k4_kernel<1>", 50, 1000)]
+    rows, t = [], 0
+    for i, (name, util, dur) in enumerate(seq):
+        rows.append(f'{i},{i},256,"void (anonymous namespace)::{name}(Args)","MfmaUtil",{util},{t},{t + dur}\n')
+        t += dur + 10
+    path = tmp_path / "MfmaUtil_counter_collection.csv"
+    path.write_text(hdr + "".join(rows))
+    util, ns, per = pmc.attention_stage(str(path))
+    assert ns == 300 + 100 + 100 + 100 + 100                                   # the MLP GEMMs behind attn_kernel are not the attention stage
+    assert abs(util - (80 * 300 + 60 * 100 + 70 * 100) / 700) < 1e-9
+    assert {e["kernel"]: e["calls"] for e in per} == {"gemm_k4_kernel<0>": 3, "attn_kernel": 2}

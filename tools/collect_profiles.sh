@@ -20,7 +20,7 @@ for C in MfmaUtil FETCH_SIZE WRITE_SIZE; do
 done
 mkdir -p $OUT/pmc
 for C in MfmaUtil FETCH_SIZE WRITE_SIZE; do cp $(find $OUT/pmc_$C -name "*counter_collection.csv" | head -1) $OUT/pmc/${C}_counter_collection.csv; done
-python3 $R/profiles/pmc_summary.py $OUT/pmc --traffic-json $OUT/pmc/freq_lstm_traffic.json --chunks 8192,8192,3968 --frontend-json $OUT/pmc/frontend_traffic.json --frames 20352 > $OUT/pmc/summary.txt
+python3 $R/profiles/pmc_summary.py $OUT/pmc --traffic-json $OUT/pmc/freq_lstm_traffic.json --chunks 8192,8192,3968 --frontend-json $OUT/pmc/frontend_traffic.json --frames 20352 --attention-json $OUT/pmc/attention_mfma.json > $OUT/pmc/summary.txt
 python3 $R/profiles/summarize.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) > $OUT/per_launch.txt
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 rm -rf $OUT/pmc_MfmaUtil $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
