@@ -374,6 +374,29 @@ def test_freq_lstm_kernel_forms_are_bitwise_identical(synth_sd, golden):
     assert torch.equal(z, res[9][2][0]) and torch.equal(al, res[9][2][1])
 
 
+def test_freq_lstm_cell_update_saturates_like_the_reference(synth_sd):
+    """The frequency LSTM's cell update uses one reciprocal for sigmoid(o) * tanh(c') and tanh(g) = 2 sigmoid(2g) - 1 (lstm.hip:
+    lstm_cell_quad<true>): exponentials that overflow must give the limits, never inf * 0.  Gate biases of +-150 (e^150 overflows
+    fp32) in every combination over blocks of hidden units, both directions, against torch's LSTM (oracle/torch_oracle.py)."""
+    import torch_oracle as TO
+    sd = {k: np.array(v, copy=True) for k, v in synth_sd["dgrad"].items()}
+    key = [k for k in sd if k.endswith("6._lstm.bias_ih_l0")][0][:-len("bias_ih_l0")]
+    levels = (-150.0, 0.0, 150.0)
+    for suf in ("", "_reverse"):
+        b = sd[key + "bias_ih_l0" + suf]
+        for u in range(81):                                   # unit u: gate q gets levels[(u // 3**q) % 3]; units 81..127 stay as they are
+            for q in range(4):
+                b[q * 128 + u] += levels[(u // 3 ** q) % 3]
+    eng = Engine(sd, debug_keep=True)
+    feat = torch.rand((96, 64, 128, 3), generator=torch.Generator().manual_seed(3)).cuda()
+    z, align = eng.encoder(feat)
+    freq = eng.tap(2, 96).cpu().numpy()
+    assert np.isfinite(freq).all() and torch.isfinite(z).all()
+    zr, ar = TO.TorchOracle(sd).encoder(feat.cpu().numpy())
+    assert np.abs(z.cpu().numpy() - zr.numpy()).max() <= TOL_ACT
+    assert np.abs(align.cpu().numpy() - ar.numpy()).max() <= 1e-5
+
+
 @pytest.mark.parametrize("variant", [4, 5, 8, 9])
 def test_gemm_variants_agree(eng, golden, variant):
     """The GEMM choices that ship (split-bf16 x3, 256-tile, one 128 x 128 block per wave wherever it fits, never the fat kernel) give
