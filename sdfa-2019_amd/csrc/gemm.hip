@@ -20,6 +20,8 @@
 __device__ unsigned long long g_stamp[8];
 #endif
 
+extern thread_local int g_sdfa_gemm_variant;   // "gemm_variant" option, defined below
+
 namespace {
 
 constexpr int TP = 128, TQ = 128, KQ = 8;   // tile p, tile q, k-quads per stage
@@ -64,10 +66,17 @@ __device__ __forceinline__ void store_tile(const GemmArgs &a, const f32x16 &acc,
 }
 
 
-template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
-__global__ __launch_bounds__(256, 2) void gemm_k4_kernel(GemmArgs a) {
-    __shared__ float4 sP[2][KQ][TP];
-    __shared__ float4 sQ[2][KQ][TQ];
+// WT = MFMA tiles per wave and dimension: 2 -> the 128 x 128 workgroup tile described above; 1 -> a 64 x 64 tile (each wave one
+// 32 x 32 block, 32 KiB of LDS, four workgroups per CU) for the launches that would otherwise put at most one or two workgroups on
+// a CU: the MLP layers, the attention query path, everything at single-clip sizes.  Such a launch is a latency chain, not a
+// throughput problem -- profiles/r03_per_launch.txt: a 256-deep MLP GEMM took 43-45 us whether it had 8 or 256 workgroups, 5 us
+// per 32-deep stage for 1.7 us of MFMAs -- and four times as many workgroups of a quarter of the work overlap each other's
+// round trips.  Same k order per accumulator: bit-identical to the 128 x 128 tile.
+template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND, int WT>
+__global__ __launch_bounds__(256, WT == 2 ? 2 : 4) void gemm_k4_kernel(GemmArgs a) {
+    constexpr int TPW = 64 * WT, SH = WT == 2 ? 7 : 6, RPP = 256 >> SH;   // tile edge, log2 of it, k-quad rows per staging pass
+    __shared__ float4 sP[2][KQ][TPW];
+    __shared__ float4 sQ[2][KQ][TPW];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -76,10 +85,10 @@ __global__ __launch_bounds__(256, 2) void gemm_k4_kernel(GemmArgs a) {
 
     // tile order: all p-tiles of one q-tile are dispatched together, so the streamed activation tile (Q) comes
     // from HBM once and from L2 for the other row blocks; the weight slab (P) is small and L2-resident anyway
-    const int64_t ntp = a.Ppad / TP;
+    const int64_t ntp = a.Ppad / TPW;
     const int64_t bid = blockIdx.x;
     const int64_t tp = bid % ntp, tq = bid / ntp;
-    const int64_t p0 = tp * TP, q0 = tq * TQ;
+    const int64_t p0 = tp * TPW, q0 = tq * TPW;
     if (a.q_limit && q0 >= *a.q_limit) return;
 
     const float4 *__restrict__ P = reinterpret_cast<const float4 *>(a.P);
@@ -87,19 +96,19 @@ __global__ __launch_bounds__(256, 2) void gemm_k4_kernel(GemmArgs a) {
     const int nkq_total = a.K / 4;
     const int seg_kq = a.seg_k / 4;
     const int nstage = nkq_total / KQ;
-    // tile-major Q (frequency-LSTM hidden states): a column block of 128 is one contiguous [K/4][128] slab
+    // tile-major Q (frequency-LSTM hidden states; WT = 2 only): a column block of 128 is one contiguous [K/4][128] slab
     const int64_t qrow = a.q_tile_major ? 128 : a.ldq;               // float4 elements between consecutive k-quads
     const float4 *Pn = P + p0;
     const float4 *Qn = a.q_tile_major ? Q + (q0 >> 7) * (int64_t)a.q_slab_rows * 128 : Q + q0;
     int kin_n = 0;
-    const unsigned boffP = (unsigned)(((tid >> 7) * a.ldp + (tid & 127)) * 16);
-    const unsigned boffQ = (unsigned)(((tid >> 7) * qrow + (tid & 127)) * 16);
+    const unsigned boffP = (unsigned)(((tid >> SH) * a.ldp + (tid & (TPW - 1))) * 16);
+    const unsigned boffQ = (unsigned)(((tid >> SH) * qrow + (tid & (TPW - 1))) * 16);
 
     // Register staging runs TWO tiles ahead of the MFMAs: while tile st is multiplied out of LDS, tile st+1 sits
     // in one register set (written to the other LDS buffer at the end of the stage) and the loads of tile st+2 are
     // in flight into the second set.  One stage is ~4,100 MFMA cycles per wave; an HBM-streamed operand (the 8192-deep
     // frequency projection) takes longer than that to arrive, which held the kernel at 76 % with a single tile ahead.
-    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;   // set A: P quads ra*, Q quads rb*
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;   // set A: P quads ra*, Q quads rb*   (WT = 1: two quads per operand)
     float4 rc0, rc1, rc2, rc3, rd0, rd1, rd2, rd3;   // set B
     // Addressing of the staging loads: a UNIFORM running base per operand (scalar registers, advanced by scalar adds)
     // plus one loop-invariant 32-bit byte offset per thread -- the global_load "saddr + voffset" form, so a load costs
@@ -109,8 +118,8 @@ __global__ __launch_bounds__(256, 2) void gemm_k4_kernel(GemmArgs a) {
     // 64 MFMAs, i.e. 15 % of the pipe.)
 #define GEMM_GLOAD1(i, RP, RQ)                                                                          \
     {                                                                                                   \
-        RP = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Pn + (i) * 2 * a.ldp) + boffP); \
-        RQ = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Qn + (i) * 2 * qrow) + boffQ);  \
+        RP = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Pn + (i) * RPP * a.ldp) + boffP); \
+        RQ = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Qn + (i) * RPP * qrow) + boffQ);  \
     }
 #define GEMM_ADVANCE()                                                                                  \
     {                                                                                                   \
@@ -120,28 +129,31 @@ __global__ __launch_bounds__(256, 2) void gemm_k4_kernel(GemmArgs a) {
         else Qn += KQ * qrow;                                                                           \
     }
     // stages are requested strictly in order (0, 1, 2, ...), so the bases just run forward
-#define GEMM_GLOAD_A(st) GEMM_GLOAD1(0, ra0, rb0) GEMM_GLOAD1(1, ra1, rb1) GEMM_GLOAD1(2, ra2, rb2) GEMM_GLOAD1(3, ra3, rb3) GEMM_ADVANCE()
-#define GEMM_GLOAD_B(st) GEMM_GLOAD1(0, rc0, rd0) GEMM_GLOAD1(1, rc1, rd1) GEMM_GLOAD1(2, rc2, rd2) GEMM_GLOAD1(3, rc3, rd3) GEMM_ADVANCE()
-#define GEMM_LSTORE1(buf, i, RP, RQ)                                   \
-    {                                                                  \
-        const int idx = (i)*256 + tid, kq = idx >> 7, c = idx & 127;   \
-        sP[buf][kq][c] = RP;                                           \
-        sQ[buf][kq][c] = RQ;                                           \
+#define GEMM_GLOAD_A(st) { GEMM_GLOAD1(0, ra0, rb0) GEMM_GLOAD1(1, ra1, rb1) if constexpr (WT == 2) { GEMM_GLOAD1(2, ra2, rb2) GEMM_GLOAD1(3, ra3, rb3) } GEMM_ADVANCE() }
+#define GEMM_GLOAD_B(st) { GEMM_GLOAD1(0, rc0, rd0) GEMM_GLOAD1(1, rc1, rd1) if constexpr (WT == 2) { GEMM_GLOAD1(2, rc2, rd2) GEMM_GLOAD1(3, rc3, rd3) } GEMM_ADVANCE() }
+#define GEMM_LSTORE1(buf, i, RP, RQ)                                          \
+    {                                                                         \
+        const int idx = (i)*256 + tid, kq = idx >> SH, c = idx & (TPW - 1);   \
+        sP[buf][kq][c] = RP;                                                  \
+        sQ[buf][kq][c] = RQ;                                                  \
     }
-#define GEMM_LSTORE_A(buf) GEMM_LSTORE1(buf, 0, ra0, rb0) GEMM_LSTORE1(buf, 1, ra1, rb1) GEMM_LSTORE1(buf, 2, ra2, rb2) GEMM_LSTORE1(buf, 3, ra3, rb3)
-#define GEMM_LSTORE_B(buf) GEMM_LSTORE1(buf, 0, rc0, rd0) GEMM_LSTORE1(buf, 1, rc1, rd1) GEMM_LSTORE1(buf, 2, rc2, rd2) GEMM_LSTORE1(buf, 3, rc3, rd3)
+#define GEMM_LSTORE_A(buf) { GEMM_LSTORE1(buf, 0, ra0, rb0) GEMM_LSTORE1(buf, 1, ra1, rb1) if constexpr (WT == 2) { GEMM_LSTORE1(buf, 2, ra2, rb2) GEMM_LSTORE1(buf, 3, ra3, rb3) } }
+#define GEMM_LSTORE_B(buf) { GEMM_LSTORE1(buf, 0, rc0, rd0) GEMM_LSTORE1(buf, 1, rc1, rd1) if constexpr (WT == 2) { GEMM_LSTORE1(buf, 2, rc2, rd2) GEMM_LSTORE1(buf, 3, rc3, rd3) } }
 #define GEMM_COMPUTE(buf)                                                                                              \
     _Pragma("unroll") for (int kb = 0; kb < KQ / 2; ++kb) {                                                            \
-        const float4 fa[2] = {sP[buf][2 * kb + h][wp * 64 + l31], sP[buf][2 * kb + h][wp * 64 + 32 + l31]};            \
-        const float4 fb[2] = {sQ[buf][2 * kb + h][wq * 64 + l31], sQ[buf][2 * kb + h][wq * 64 + 32 + l31]};            \
-        mfma_block<2, 2>(acc, fa, fb);                                                                                 \
+        float4 fa[WT], fb[WT];                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < WT; ++i) {                                                               \
+            fa[i] = sP[buf][2 * kb + h][wp * 32 * WT + 32 * i + l31];                                                  \
+            fb[i] = sQ[buf][2 * kb + h][wq * 32 * WT + 32 * i + l31];                                                  \
+        }                                                                                                              \
+        mfma_block<WT, WT>(acc, fa, fb);                                                                               \
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[WT][WT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -189,16 +201,38 @@ __global__ __launch_bounds__(256, 2) void gemm_k4_kernel(GemmArgs a) {
 
     // ---------------------------------------------------------------- epilogue
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-            store_tile<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, acc[i][j], p0 + wp * 64 + i * 32, q0 + wq * 64 + j * 32 + l31, h);
+        for (int j = 0; j < WT; ++j)
+            store_tile<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, acc[i][j], p0 + wp * 32 * WT + i * 32, q0 + wq * 32 * WT + j * 32 + l31, h);
+}
+
+// Which launches take the 64 x 64 tile (gemm_k4_kernel<.., 1>): by the number of 128 x 128 tiles the problem has.  Fewer than half a
+// tile per CU: always (single-clip sizes; a quarter of the work per workgroup and four times the workgroups).  Up to two per CU: when
+// the contraction is short (K <= 512: at most 16 stages, the launch is one workgroup's latency chain); a long contraction at that
+// count already runs the matrix pipe at 87 % (the attention query Conv1d, K = 1536: 94 us for 82 us of MFMAs).
+// "gemm_variant" 6 forces it wherever it applies, 2 forbids it.
+inline bool small_tile_pays(const GemmArgs &a) {
+    if (a.q_tile_major || g_sdfa_gemm_variant == 2) return false;
+    if (g_sdfa_gemm_variant == 6) return true;
+    static const int64_t cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        return (int64_t)n;
+    }();
+    const int64_t n128 = (a.Ppad / TP) * (a.Qpad / TQ);
+    return n128 * 2 < cus || (n128 <= 2 * cus && a.K <= 512);
 }
 
 template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
 hipError_t launch(const GemmArgs &a, hipStream_t s) {
+    if (small_tile_pays(a)) {
+        const int64_t nblk = (a.Ppad / 64) * (a.Qpad / 64);
+        hipLaunchKernelGGL((gemm_k4_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 1>), dim3((unsigned)nblk), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     int64_t nblk = (a.Ppad / TP) * (a.Qpad / TQ);
-    hipLaunchKernelGGL((gemm_k4_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>), dim3((unsigned)nblk), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((gemm_k4_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 2>), dim3((unsigned)nblk), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -841,19 +875,21 @@ extern "C" int sdfa_debug_read_stamps(unsigned long long *out, int reset) {
 // "gemm_variant" option (sdfa_debug_set_option, thread-local): 0 = default choice per shape -- gemm_fat_kernel where its 256 x 256
 // tiles fill the chip at least twice, else the LDS-tiled 128 x 128 kernel (256 x 256 gemm_big_kernel for the 8192-deep frequency
 // projection at mid sizes); 9 = the two-workgroups-per-CU fallback (never the fat kernel: DESIGN.md section 7); 8 = fat wherever it
-// fits; 5 = 256 x 256 tile wherever it fits; 4 = split-bf16 x3 (NOT exact fp32).  All fp32 choices are bit-identical.  The
+// fits; 5 = 256 x 256 tile wherever it fits; 6 / 2 = the 64 x 64 form of the LDS-tiled kernel wherever it applies / never (default: small
+// launches, small_tile_pays); 4 = split-bf16 x3 (NOT exact fp32).  All fp32 choices are bit-identical.  The
 // variants of rounds 1-2 that were never faster (register-direct 1 / 2, LDS-DMA-fed 128 x 128 tile 3, producer / consumer waves 6)
 // are gone from the library; their A/B records are profiles/r02_ab_gemm.txt and DESIGN.md section 4.2.
 thread_local int g_sdfa_gemm_variant = 0;
 
 template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
 hipError_t launch_any(const GemmArgs &a, hipStream_t s) {
+    const int variant = (g_sdfa_gemm_variant == 2 || g_sdfa_gemm_variant == 6) ? 0 : g_sdfa_gemm_variant;   // 2 / 6 only steer the small-tile choice (launch)
     if (a.terms) {   // mixed-precision modes
-        const bool big = a.Ppad % 256 == 0 && a.Qpad % 256 == 0 && g_sdfa_gemm_variant != 7;
+        const bool big = a.Ppad % 256 == 0 && a.Qpad % 256 == 0 && variant != 7;
         if (a.terms == 1) return big ? launch_bf16_big<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 1>(a, s) : launch_bf16<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 1>(a, s);
         return big ? launch_bf16_big<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 3>(a, s) : launch_bf16<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 3>(a, s);
     }
-    if (g_sdfa_gemm_variant == 4 && !a.q_tile_major) return launch_bf16<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 3>(a, s);
+    if (variant == 4 && !a.q_tile_major) return launch_bf16<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 3>(a, s);
     // one 128 x 128 block per wave, persistent (gemm_fat_kernel): by default wherever its 256 x 256 tiles fill the chip at least
     // twice over -- the frequency projection (-5.6 %) and the BiLSTM input projections (-8 / -9.5 %)
     {
@@ -862,7 +898,7 @@ hipError_t launch_any(const GemmArgs &a, hipStream_t s) {
                           (int64_t)(a.K / 4) * a.ldp * 16 < 0x7fffffff && (int64_t)(a.K / 4) * (a.q_tile_major ? 128 : a.ldq) * 16 < 0x7fffffff;   // buffer offsets
         const int64_t ntiles = (a.Ppad / 256) * (a.Qpad / 256);
         if constexpr (OUT_MODE == OUT_K4 && !BIAS_Q && !COND) {
-            if (fits && (g_sdfa_gemm_variant == 8 || (g_sdfa_gemm_variant == 0 && ntiles >= 512)))
+            if (fits && (variant == 8 || (variant == 0 && ntiles >= 512)))
                 return launch_fat<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
         }
     }
@@ -870,7 +906,7 @@ hipError_t launch_any(const GemmArgs &a, hipStream_t s) {
     // what the 128 x 128 tile waits for (40.3 vs 41.7 ms), as long as such tiles fill the chip.  Small batches (a single 2 s /
     // 10 s clip: 64 / 160 such tiles): the 128 x 128 tile instead, four times as many workgroups
     const bool big_fills = (a.Ppad / 256) * (a.Qpad / 256) >= 256;
-    if ((g_sdfa_gemm_variant == 5 || (a.q_tile_major && ((g_sdfa_gemm_variant == 0 && big_fills) || g_sdfa_gemm_variant == 9))) && a.Ppad % 256 == 0 && a.Qpad % 256 == 0)
+    if ((variant == 5 || (a.q_tile_major && ((variant == 0 && big_fills) || variant == 9))) && a.Ppad % 256 == 0 && a.Qpad % 256 == 0)
         return launch_big<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
     return launch<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
 }
