@@ -5,6 +5,7 @@ set -e
 T=gpurun_out/$1; R=$2
 # profiles/<round>_pmc is REPLACED: nothing else may live there (the co-execution counter passes of tools/pmc_coexec.sh have their own
 # directory, profiles/<round>_coexec -- an earlier install wiped them when they shared this one)
+[ -d $T/pmc ] || { echo "$T/pmc missing: nothing installed"; exit 1; }
 rm -rf profiles/${R}_pmc && mkdir -p profiles/${R}_pmc && cp $T/pmc/* profiles/${R}_pmc/
 sed -i "s#(pmc);#(profiles/${R}_pmc);#" profiles/${R}_pmc/freq_lstm_traffic.json
 cp $T/bench.json profiles/${R}_bench.json
