@@ -393,16 +393,30 @@ __global__ __launch_bounds__(256) void gather_features_kernel(const float4 *__re
     __shared__ float sMel[64][128];
     const int tid = threadIdx.x;
     const int64_t frame = blockIdx.x;
-    for (int i4 = tid; i4 < 64 * 32; i4 += 256) {
-        const int t = i4 >> 5, f4 = i4 & 31;
-        const int64_t u = col_to_u[(int64_t)t * Nc + frame];
-        *reinterpret_cast<float4 *>(&sMel[t][4 * f4]) = mel_table[u * 32 + f4];
+    {   // the frame's 64 table rows: all eight index requests, then all eight row requests, then the LDS writes (as a rolled loop
+        // this was eight dependent round-trip pairs in front of every workgroup's barrier)
+        const int f4 = tid & 31;
+        int32_t u[8];
+        float4 row[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) u[i] = col_to_u[(int64_t)((tid >> 5) + 8 * i) * Nc + frame];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) row[i] = mel_table[(int64_t)u[i] * 32 + f4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<float4 *>(&sMel[(tid >> 5) + 8 * i][4 * f4]) = row[i];
     }
     __syncthreads();
-    // Savitzky-Golay deltas (edges replicate the first / last interior value) + (T,F,C) store: as in frontend_kernel
+    // Savitzky-Golay deltas (edges replicate the first / last interior value) + (T,F,C) store: as in frontend_kernel.  The frame's
+    // 96 KiB go out as 16-byte stores through a buffer descriptor on the frame (left to itself the compiler stored a thread's 48
+    // bytes as 12 + 12 + 16 + 8: four partially covered passes over every line)
     const float c2[9] = {28.f / 462.f, 7.f / 462.f, -8.f / 462.f, -17.f / 462.f, -20.f / 462.f,
                          -17.f / 462.f, -8.f / 462.f, 7.f / 462.f, 28.f / 462.f};
-    float4 *dst = reinterpret_cast<float4 *>(out + frame * (64 * 128 * 3));
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned long long ob = (unsigned long long)(out + frame * (64 * 128 * 3));
+    const unsigned long long ouni = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ob >> 32)) << 32) |
+                                    (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ob);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)ouni, 0, 64 * 128 * 3 * 4, 0x00020000);
+#define GF_ST(off, a_, b_, c_, d_) __builtin_amdgcn_raw_buffer_store_b128(u32x4{__builtin_bit_cast(unsigned, a_), __builtin_bit_cast(unsigned, b_), __builtin_bit_cast(unsigned, c_), __builtin_bit_cast(unsigned, d_)}, ors, (unsigned)(off), 0, 0)
     for (int i4 = tid; i4 < 64 * 128 / 4; i4 += 256) {
         const int t = i4 >> 5, f0 = (i4 & 31) * 4;
         const int tc = t < 4 ? 4 : (t > 59 ? 59 : t);
@@ -418,10 +432,11 @@ __global__ __launch_bounds__(256) void gather_features_kernel(const float4 *__re
             }
             m[q] = sMel[t][f0 + q]; d1[q] = s1; d2[q] = s2;
         }
-        dst[i4 * 3 + 0] = make_float4(m[0], d1[0], d2[0], m[1]);
-        dst[i4 * 3 + 1] = make_float4(d1[1], d2[1], m[2], d1[2]);
-        dst[i4 * 3 + 2] = make_float4(d2[2], m[3], d1[3], d2[3]);
+        GF_ST(i4 * 48, m[0], d1[0], d2[0], m[1]);
+        GF_ST(i4 * 48 + 16, d1[1], d2[1], m[2], d1[2]);
+        GF_ST(i4 * 48 + 32, d2[2], m[3], d1[3], d2[3]);
     }
+#undef GF_ST
 }
 
 }  // namespace
