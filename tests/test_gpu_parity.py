@@ -374,6 +374,23 @@ def test_freq_lstm_kernel_forms_are_bitwise_identical(synth_sd, golden):
     assert torch.equal(z, res[9][2][0]) and torch.equal(al, res[9][2][1])
 
 
+def test_forward_is_bitwise_reproducible_run_to_run(synth_sd):
+    """The persistent kernels take tiles from atomic queues and the single-clip time LSTM hands h between workgroups: which
+    workgroup does what differs from run to run, the bits must not (no floating-point atomics, fixed order per accumulator).
+    2,500 frames (persistent queues, several tiles per workgroup) and 300 frames (cooperating workgroups), three runs each and
+    once more through a second engine."""
+    eng = Engine(synth_sd["dgrad"], max_frames=4096)
+    for n in (2500, 300):
+        feat = torch.rand((n, 64, 128, 3), generator=torch.Generator().manual_seed(n)).cuda()
+        spk = torch.arange(n, dtype=torch.int64) % 8
+        ref = [t.clone() for t in eng.forward(feat, spk, want_coef=True)]
+        for _ in range(2):
+            for a_, b_ in zip(ref, eng.forward(feat, spk, want_coef=True)):
+                assert torch.equal(a_, b_)
+        for a_, b_ in zip(ref, Engine(synth_sd["dgrad"], max_frames=4096).forward(feat, spk, want_coef=True)):
+            assert torch.equal(a_, b_)
+
+
 def test_freq_lstm_cell_update_saturates_like_the_reference(synth_sd):
     """The frequency LSTM's cell update uses one reciprocal for sigmoid(o) * tanh(c') and tanh(g) = 2 sigmoid(2g) - 1 (lstm.hip:
     lstm_cell_quad<true>): exponentials that overflow must give the limits, never inf * 0.  Gate biases of +-150 (e^150 overflows
