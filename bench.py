@@ -192,8 +192,82 @@ def surface_block(sd, head, sr, dev):
     clips = [synth.make_pcm(c, int(10.0 * sr)) for c in range(32)]
     frames = sum(len(r[0]) for r in model.generate_animation_batch(clips, "m1"))
     out["32x10s_batch"] = run(lambda: model.generate_animation_batch(clips, "m1"), frames, 3, warm=1)
+    # speaker sweep over ONE clip: the second and later speakers reuse the cached, speaker-independent encoder output (the reference
+    # keeps the last signal's features for the same purpose, model.py:364-367,409-416) -- only the regressor + the copy run
+    pcm = synth.make_pcm(0, int(10.0 * sr))
+    names = ["m0", "m1", "m2", "m3", "f0", "f1", "f2", "f3"]
+    frames = len(model.generate_animation(pcm, "m1", 0, 0, want_inputs=False)[0])
+    state = {"i": 0}
+
+    def sweep():
+        state["i"] += 1
+        model.generate_animation(pcm, names[state["i"] % 8], 0, 0, want_inputs=False)
+    out["1x10s_speaker_sweep"] = run(sweep, frames, 16)
+    out["time_lstm_repairs"] = eng.time_lstm_repairs()        # waits of the cooperating-workgroup time LSTM that expired (0 unless the device is oversubscribed)
     del model
+    # BASELINE configs[4] through the surface: a VOCASET-like stream -- 80 ragged 3 - 6 s sentences @ 8 kHz, 8 speakers, offsets head --
+    # through generate_animation_batch, rows delivered to pinned host memory (what evaluate() does per launch group)
+    try:
+        sr4 = 8000
+        hp4 = configure(dict(mode="evaluate", custom_hparams="offsets"))
+        hp4.audio.set_key("sample_rate", sr4)
+        hp4.set_key("device", str(dev))
+        DatasetSlidingWindow.hparams = None
+        m4 = build_model(hp4, synth.make_state_dict("offsets", 1234))
+        rs = np.random.RandomState(4242)
+        clips4 = [synth.make_pcm(1000 + c, int(rs.uniform(3.0, 6.0) * sr4)) for c in range(80)]
+        spk4 = [names[c % 8] for c in range(80)]
+        frames4 = sum(len(r[0]) for r in m4.generate_animation_batch(clips4, spk4))
+        r4 = run(lambda: m4.generate_animation_batch(clips4, spk4), frames4, 3, warm=1)
+        r4["workload"] = "80 sentences, 3 - 6 s @ 8 kHz, 8 speakers, offsets head (15,069 floats per frame) -> pinned host rows (BASELINE configs[4] shape, 1 GPU)"
+        out["stream_offsets"] = r4
+        del m4
+    except Exception as e:
+        out["stream_offsets"] = {"error": repr(e)}
+    DatasetSlidingWindow.hparams = None
     return out
+
+
+def memory_plan(world, clips_per_gpu=32, seconds=10.0, sr=16000, head="dgrad", chunk=8192, gather="auto"):
+    """Per-rank device memory (GB) of `bench.py --gpus world`, from the size functions the run itself uses (no GPU needed): what
+    DESIGN.md section 5 quotes for N = 8 and tests/test_memory_plan_cpu.py holds to 288 GB.  `gather` auto builds the dgrad and the
+    expand buffers IN TURN (set_mode empties the cache in between), so its peak is the larger of the two."""
+    from sdfa_amd import _lib
+    from sdfa_amd.engine import frame_index
+    F = len(frame_index(int(seconds * sr), sr)[0]) * clips_per_gpu
+    m = _lib.lib.sdfa_model_create(_lib.HEAD_DGRAD if head == "dgrad" else _lib.HEAD_OFFSETS)
+    try:
+        out_dim, coef_dim = int(_lib.lib.sdfa_model_out_dim(m)), int(_lib.lib.sdfa_model_coef_dim(m))
+        ws = int(_lib.check(_lib.lib.sdfa_workspace_bytes(m, min(chunk, F))))
+    finally:
+        _lib.lib.sdfa_model_destroy(m)
+    fe_ws = int(_lib.check(_lib.lib.sdfa_frontend_workspace_bytes(F)))
+    n_chunks = (F + chunk - 1) // chunk
+    rows = F * out_dim * 4
+    parts = {
+        "weights_packed": 0.5e9,                                   # 70 MB of fp32 weights + PCA basis, plus the packed fp32 / bf16 operand forms (upper bound)
+        "pcm": clips_per_gpu * int(seconds * sr) * 4,
+        "audio_feat": F * 64 * 128 * 3 * 4,
+        "frontend_workspace": fe_ws,
+        "encoder_workspace": ws,
+        "z_and_ids": n_chunks and min(chunk, F) * (512 + 64 + 2) * 4 * 2,
+    }
+    modes = {
+        "none": rows,                                              # N = 1: the step's output rows
+        "dgrad": rows + world * rows,                              # own rows + FrameGatherer.buf (all ranks' rows)
+        "expand": world * rows + 2 * world * F * coef_dim * 4,     # ExpandGatherer.buf (own rows written in place) + the coefficient gather
+        "direct": 2 * world * rows,                                # DirectGatherer: two alternating gathered buffers
+    }
+    if world == 1:
+        kinds = ["none"]
+    else:
+        kinds = ["dgrad", "expand"] if gather == "auto" else [gather]
+    fixed = sum(parts.values())
+    plan = {k: round(v / 1e9, 3) for k, v in parts.items()}
+    plan["output_and_gathered"] = {k: round(modes[k] / 1e9, 3) for k in kinds}
+    plan["total_gb"] = round((fixed + max(modes[k] for k in kinds)) / 1e9, 2)
+    plan["frames_per_gpu"] = F
+    return plan
 
 
 def _sha1(name):
@@ -579,6 +653,8 @@ def main():
                        "gather": (Mode.kind if (Mode.gatherer is not None or Mode.direct is not None or (mesh is not None and mesh[3] is not None)) else "none") if dist_on else "none (1 GPU)",
                        "force_gather_world1": bool(a.force_gather and world == 1), "backend": a.backend if dist_on else None,
                        "reserved_cus": a.reserve_cus,
+                       "memory_plan_gb": memory_plan(world, C, a.seconds, sr, a.head, a.chunk, a.gather) if not a.ragged_seconds else None,   # planned; peak_device_memory_gb is measured
+                       "env": __import__("sdfa_amd").runtime_env(),      # set at import by bench.py / sdfa_amd unless the caller had set them
                        # does an asynchronous RCCL all-gather run UNDER the kernels of the stream the steps ran on?  (probe before the run)
                        "collective_overlap_probe": comm_probe,
                        "gather_auto_ms_per_step": None if auto is None else {k: round(v, 2) for k, v in auto.items()},

@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define SDFA_ABI_VERSION 3   /* 3: + sdfa_ensemble_mean, sdfa_model_set_reserved_cus, sdfa_debug_time_lstm_timeout (round 3); 2: + seek, resample, mesh correspondences,
+#define SDFA_ABI_VERSION 4   /* 4: workspace status block (sdfa_workspace_init / _status*, replaces sdfa_debug_time_lstm_timeout), unaligned sdfa_ensemble_mean (round 4);
+                                3: + sdfa_ensemble_mean, sdfa_model_set_reserved_cus, sdfa_debug_time_lstm_timeout (round 3); 2: + seek, resample, mesh correspondences,
                                 multi-destination regress, expand_coef, autotune (round 2); all earlier entry points unchanged */
 
 #define SDFA_OK            0
@@ -157,6 +158,24 @@ int         sdfa_model_set_reserved_cus(sdfa_model *m, int k);
 /* Bytes of scratch device memory the forward calls need for up to `max_frames` frames per call. */
 int64_t sdfa_workspace_bytes(const sdfa_model *m, int64_t max_frames);
 
+/* Status block = the first SDFA_WS_STATUS_BYTES bytes of a workspace: counters the kernels only ever INCREMENT.
+ *   word SDFA_WS_TIME_LSTM_REPAIRS  waits of the small-batch time-LSTM kernels that expired.  For a single clip the BiLSTM recurrence
+ *       runs on pairs of cooperating workgroups that hand h to each other every step and wait for each other with a wall-clock
+ *       bound (0.2 s; "time_lstm_timeout_us").  A wait can only expire when other work keeps a partner off the device for that
+ *       long; the launch then marks itself and a repair pass that needs no co-residency recomputes the layer ON THE DEVICE, in
+ *       stream order, before anything reads it -- a forward call never returns rows of a timed-out launch (the reference never
+ *       returns partial results either: speech_anime/model/model.py:428-489).  The counter only says that it happened (a
+ *       performance event: about the bound + 2 ms per occurrence).
+ * sdfa_workspace_init zeroes the block (once, after allocating; the forward calls never do).  sdfa_workspace_status_async enqueues a
+ * copy of the SDFA_WS_STATUS_WORDS words to h_status (pinned host memory: valid once the stream has passed it; never
+ * synchronises); sdfa_workspace_status reads one word and synchronises the stream.  (New: no counterpart in the reference.) */
+#define SDFA_WS_STATUS_BYTES 256
+#define SDFA_WS_STATUS_WORDS 4
+#define SDFA_WS_TIME_LSTM_REPAIRS 0
+int     sdfa_workspace_init(void *d_workspace, int64_t workspace_bytes, void *stream);
+int     sdfa_workspace_status_async(const void *d_workspace, uint32_t *h_status, void *stream);
+int64_t sdfa_workspace_status(const void *d_workspace, int word, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * (a6-a10) Audio encoder: permute, conv2d x3 (+LeakyReLU 0.2 then eval BatchNorm) with two
  * max-pools along frequency, frequency BiLSTM + 8192->256 projection, 2-layer time BiLSTM,
@@ -225,7 +244,8 @@ int sdfa_expand_coef(const sdfa_model *m, const float *d_coef, int64_t n_frames,
 
 /* Test-time ensembling (speech_anime/model/model.py:369-403, `--ensembling_ms`): the mean of the two passes' output rows,
  * d_out[i] = (d_a[i] + d_b[i]) / 2 with numpy's float32 roundings (`anime_sum += second; anime_sum / 2.0`), so that the
- * averaged track never has to be formed on the host.  n = elements; all pointers 16-byte aligned; d_out may equal d_a. */
+ * averaged track never has to be formed on the host.  n = elements; pointers 4-byte aligned (16-byte aligned operands take the
+ * vector path: the offsets head's 60,276-byte rows are 16-byte aligned only every fourth row); d_out may equal d_a. */
 int sdfa_ensemble_mean(const float *d_a, const float *d_b, int64_t n, float *d_out, void *stream);
 
 /* Debug / parity taps: copy an intermediate activation of the LAST sdfa_encoder_forward call out of
@@ -251,7 +271,9 @@ int sdfa_ensemble_mean(const float *d_a, const float *d_b, int64_t n, float *d_o
  *                      frames (time_lstm_split16_kernel), 32-frame tiles up to 2,048 (time_lstm_split_kernel); 1 = never; 32 = 32-frame
  *                      tiles only; 16 = 16-frame tiles or an error
  *   "time_lstm_handoff" how those workgroups publish / consume h: 0 = write-through (sc1) stores + sc1 loads (default); bit 0 = plain
- *                      stores + agent-scope release; bit 1 = agent-scope acquire + plain loads (the always-valid form, slower)
+ *                      stores + agent-scope release; bit 1 = agent-scope acquire + plain loads (the always-valid form, slower);
+ *                      bit 2 (tests only) = the second workgroup of every pair never publishes, so every wait of the first expires
+ *   "time_lstm_timeout_us" bound of one such wait in microseconds (0 = the default, 200,000)
  *   "pca_unfused"      1 = the dgrad PCA expansion as two generic GEMM launches with the scatter epilogue (round-1 form)
  *   "conv_unfused"     1 = conv1_pool_kernel + conv23_kernel instead of the fused conv123_kernel (what the debug taps use)   */
 int sdfa_debug_set_option(const char *name, int value);
@@ -261,11 +283,6 @@ int sdfa_debug_keep_intermediates(sdfa_model *m, int on);   /* un-aliased worksp
 int64_t sdfa_debug_distinct_columns(const sdfa_model *m, int64_t n_frames, const void *d_workspace, void *stream);
 int sdfa_debug_tap(const sdfa_model *m, int what, int64_t n_frames, float *d_dst, const void *d_workspace,
                    void *stream);
-/* 1 if a workgroup of the small-batch time-LSTM kernel (cooperating workgroups exchange h every step, with BOUNDED waits) gave up
- * waiting for a partner during the LAST sdfa_encoder_forward call on a chunk of n_frames frames -- its output is then invalid; 0
- * otherwise (always, unless the device was so oversubscribed that a launch's workgroups could not run together).  Synchronises. */
-int sdfa_debug_time_lstm_timeout(const sdfa_model *m, int64_t n_frames, const void *d_workspace, void *stream);
-
 /* Per-stage device timing of the last forward calls made with profiling enabled (HIP events on the
  * caller's stream).  names: "conv1","conv23","freq_lstm","freq_proj","gx0","lstm0","gx1","lstm1",
  * "attn_proj","attn","mlp","pca".  Returns milliseconds or a negative code. */

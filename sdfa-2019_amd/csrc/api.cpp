@@ -654,7 +654,7 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
 // ================================================================================================
 namespace {
 
-constexpr int64_t CT_WORDS = 2048, CT_FLAGS = 16;
+constexpr int64_t CT_WORDS = 2048, CT_FLAGS = 16, ST_WORDS = SDFA_WS_STATUS_BYTES / 4;
 
 struct Ws {
     int64_t P1, X3, HF, Z, GX, H0, H1, KP, QC, QP, ZK, R, SH, ZU, CT, total;   // offsets in floats
@@ -665,6 +665,7 @@ Ws layout(int64_t Nc, bool keep) {
     Ws w{};
     int64_t o = 0;
     auto take = [&](int64_t n) { int64_t r = o; o += round_up(n, 64); return r; };
+    take(ST_WORDS);       // the status block (sdfa_workspace_init / sdfa_workspace_status*): always the first 256 bytes, whatever Nc
     if (keep) {   // debug: nothing aliased, taps stay valid after the forward
         w.P1 = take(2048 * Mc); w.X3 = take(2048 * Mc); w.HF = take((int64_t)HF_SLAB_ROWS * 4 * Mc); w.Z = take(256 * Mc);
         w.GX = take(2048 * Mc); w.H0 = take(512 * Mc); w.H1 = take(512 * Mc); w.KP = take(128 * Mc);
@@ -739,7 +740,9 @@ thread_local int g_sdfa_conv_unfused = 0;
 thread_local int g_sdfa_pca_lds = 0;
 thread_local int g_sdfa_time_lstm_split = 0;
 thread_local int g_sdfa_time_lstm_handoff = 0;
+thread_local int g_sdfa_time_lstm_timeout_us = 0;
 int sdfa_debug_set_option(const char *name, int value) {
+    if (name && !strcmp(name, "time_lstm_timeout_us")) { g_sdfa_time_lstm_timeout_us = value; return SDFA_OK; }
     if (name && !strcmp(name, "time_lstm_handoff")) { g_sdfa_time_lstm_handoff = value; return SDFA_OK; }
     if (name && !strcmp(name, "time_lstm_split")) { g_sdfa_time_lstm_split = value; return SDFA_OK; }
     if (name && !strcmp(name, "gemm_variant")) { g_sdfa_gemm_variant = value; return SDFA_OK; }
@@ -942,7 +945,8 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
             gi.reserve_cus = m->reserved_cus.load();
             pf.begin(gxn[l]); HIP_TRY(sdfa_launch_gemm(gi, s)); pf.end();
             TimeLstmArgs ta{ws + w.GX, m->tl_w[l], hout[l], Nc, Mc, m->tl_wb[l], stage_terms(m, STAGE_BODY),
-                            reinterpret_cast<unsigned *>(ws + w.CT) + CT_FLAGS, CT_WORDS - CT_FLAGS, m->tl_w16[l]};
+                            reinterpret_cast<unsigned *>(ws + w.CT) + CT_FLAGS, CT_WORDS - CT_FLAGS, m->tl_w16[l],
+                            reinterpret_cast<unsigned *>(ws), m->reserved_cus.load()};
             pf.begin(lsn[l]); HIP_TRY(sdfa_launch_time_lstm(ta, s)); pf.end();
             xin = hout[l];
         }
@@ -1123,13 +1127,25 @@ int64_t sdfa_debug_distinct_columns(const sdfa_model *m, int64_t n_frames, const
     return counts[0];
 }
 
-int sdfa_debug_time_lstm_timeout(const sdfa_model *m, int64_t n_frames, const void *d_workspace, void *stream) {
-    if (!m || n_frames <= 0 || !d_workspace) return fail(SDFA_EINVAL, "debug_time_lstm_timeout: bad argument");
-    const Ws w = layout(round_up(n_frames, 128), m->keep);
-    unsigned word = 0;
-    HIP_TRY(hipMemcpyAsync(&word, reinterpret_cast<const unsigned *>((const float *)d_workspace + w.CT) + CT_FLAGS, sizeof word, hipMemcpyDeviceToHost, (hipStream_t)stream));
+// ---- workspace status block -----------------------------------------------------------------------------------------------
+int sdfa_workspace_init(void *d_workspace, int64_t workspace_bytes, void *stream) {
+    if (!d_workspace || workspace_bytes < SDFA_WS_STATUS_BYTES || ((uintptr_t)d_workspace & 15)) return fail(SDFA_EINVAL, "workspace_init: bad argument");
+    HIP_TRY(hipMemsetAsync(d_workspace, 0, SDFA_WS_STATUS_BYTES, (hipStream_t)stream));
+    return SDFA_OK;
+}
+
+int sdfa_workspace_status_async(const void *d_workspace, uint32_t *h_status, void *stream) {
+    if (!d_workspace || !h_status) return fail(SDFA_EINVAL, "workspace_status_async: bad argument");
+    HIP_TRY(hipMemcpyAsync(h_status, d_workspace, SDFA_WS_STATUS_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return SDFA_OK;
+}
+
+int64_t sdfa_workspace_status(const void *d_workspace, int word, void *stream) {
+    if (!d_workspace || word < 0 || word >= SDFA_WS_STATUS_WORDS) return fail(SDFA_EINVAL, "workspace_status: bad argument");
+    uint32_t v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, reinterpret_cast<const uint32_t *>(d_workspace) + word, sizeof v, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    return (int)word;
+    return (int64_t)v;
 }
 
 int sdfa_debug_tap(const sdfa_model *m, int what, int64_t n_frames, float *d_dst, const void *d_workspace, void *stream) {
@@ -1385,7 +1401,7 @@ int sdfa_seek_plan(const int32_t *d_tslist, const int64_t *d_clip_frame_off, con
 int sdfa_ensemble_mean(const float *d_a, const float *d_b, int64_t n, float *d_out, void *stream) {
     if (n == 0) return SDFA_OK;
     if (!d_a || !d_b || !d_out || n < 0) return fail(SDFA_EINVAL, "ensemble_mean: bad argument");
-    if (((uintptr_t)d_a | (uintptr_t)d_b | (uintptr_t)d_out) & 15) return fail(SDFA_EINVAL, "ensemble_mean: pointers must be 16-byte aligned");
+    if (((uintptr_t)d_a | (uintptr_t)d_b | (uintptr_t)d_out) & 3) return fail(SDFA_EINVAL, "ensemble_mean: pointers must be 4-byte aligned");
     HIP_TRY(sdfa_launch_ensemble_mean(d_a, d_b, n, d_out, (hipStream_t)stream));
     return SDFA_OK;
 }

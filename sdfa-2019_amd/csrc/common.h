@@ -110,3 +110,22 @@ __device__ __forceinline__ float tanhf_acc(float x) {
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, const float4 &v) { *reinterpret_cast<float4 *>(p) = v; }
+
+// CUs of the CURRENT device, looked up per launch (a process may drive differently sized or CU-masked devices; a function-local
+// static would freeze the first device's count -- ADVICE r3).  The attribute query is a table lookup in the runtime; the small
+// per-device cache only saves the call.
+#include <atomic>
+inline int sdfa_cu_count() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev >= 0 && dev < 64) {
+        const int c = cache[dev].load(std::memory_order_relaxed);
+        if (c > 0) return c;
+    }
+    int n = 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    if (dev >= 0 && dev < 64) cache[dev].store(n, std::memory_order_relaxed);
+    return n;
+}
+

@@ -215,11 +215,7 @@ __global__ __launch_bounds__(256, WT == 2 ? 2 : 4) void gemm_k4_kernel(GemmArgs 
 inline bool small_tile_pays(const GemmArgs &a) {
     if (a.q_tile_major || g_sdfa_gemm_variant == 2) return false;
     if (g_sdfa_gemm_variant == 6) return true;
-    static const int64_t cus = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
-        return (int64_t)n;
-    }();
+    const int64_t cus = sdfa_cu_count();
     const int64_t n128 = (a.Ppad / TP) * (a.Qpad / TQ);
     return n128 * 2 < cus || (n128 <= 2 * cus && a.K <= 512);
 }
@@ -851,11 +847,7 @@ hipError_t launch_fat(const GemmArgs &a, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_fat_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    static const int64_t cus = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
-        return (int64_t)n;
-    }();
+    const int64_t cus = sdfa_cu_count();
     const int64_t ntiles = (a.Ppad / 256) * (a.Qpad / 256);
     const int64_t wgs = std::max<int64_t>(1, cus - a.reserve_cus);      // CUs left to kernels of other streams (sdfa_model_set_reserved_cus)
     hipLaunchKernelGGL((gemm_fat_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>), dim3((unsigned)std::min(ntiles, wgs)), dim3(256), lds, s, a);

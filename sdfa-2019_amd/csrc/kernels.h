@@ -122,9 +122,11 @@ struct TimeLstmArgs {
     int64_t Nc, Mc;
     const void *Wb;      // mixed-precision modes: per direction bf16x8 [hi | lo][32 octets][1024 rows] (lstm.hip)
     int terms;           // 0 = fp32 MFMA; 1 = bf16; 3 = split-bf16
-    unsigned *flags;     // small-batch form (time_lstm_split_kernel): [0] timeout word, [4 ..] one flag per workgroup; null = never split
+    unsigned *flags;     // small-batch form (time_lstm_split_kernel): [0] this launch's time-out word, [4 ..] one flag per workgroup; null = never split
     int64_t flag_words;  // words available at `flags`
     const float *W16;    // time_lstm_split16_kernel: per direction float4 [16 K16][4 g][1024 rows] (api.cpp pack_rec_16x16x4); null = not packed
+    unsigned *status;    // word 0 of the workspace's status block: counts the waits of the small-batch form that expired (null = not counted)
+    int reserve_cus;     // the small-batch form is used while its grid fits (CUs - reserve_cus)
 };
 hipError_t sdfa_launch_time_lstm(const TimeLstmArgs &a, hipStream_t s);
 
@@ -194,7 +196,7 @@ hipError_t sdfa_launch_mesh_scatter(const MeshArgs &a, hipStream_t s);
 hipError_t sdfa_launch_seek_plan(const int32_t *tslist, const int64_t *frame_off, const int64_t *query_off, int n_clips, double fps,
                                  int64_t n_queries, int64_t *src, float *w, hipStream_t s);
 hipError_t sdfa_launch_seek_rows(const float *rows, int64_t width, const int64_t *src, const float *w, int64_t nq, float *out, hipStream_t s);
-// test-time ensembling: out = (a + b) / 2, element-wise, float32 roundings of numpy's `sum += x; sum / 2.0` (16-byte aligned pointers)
+// test-time ensembling: out = (a + b) / 2, element-wise, float32 roundings of numpy's `sum += x; sum / 2.0` (vector path for 16-byte aligned pointers)
 hipError_t sdfa_launch_ensemble_mean(const float *a, const float *b, int64_t n, float *out, hipStream_t s);
 
 // ---- audio ingest: kaiser_best resampling (resample.hip) --------------------------------------------------------

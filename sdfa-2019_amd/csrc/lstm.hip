@@ -697,7 +697,7 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_bf16_kernel(FreqLstmArgs a) 
 // NT = 32-frame column tiles per workgroup: 2 (64 frames, the throughput shape) or 1 (32 frames: twice the
 // workgroups, used when a chunk would otherwise leave CUs idle).
 template <int NT>
-__global__ __launch_bounds__(512, 2) void time_lstm_kernel(TimeLstmArgs a) {
+__device__ __forceinline__ void time_lstm_body(const TimeLstmArgs &a) {
     extern __shared__ float4 sHt[];   // [2][64 k-quads][32*NT sequences]
     constexpr int BT = 32 * NT;
 
@@ -825,6 +825,18 @@ __global__ __launch_bounds__(512, 2) void time_lstm_kernel(TimeLstmArgs a) {
 #undef TL_W1
 }
 
+template <int NT>
+__global__ __launch_bounds__(512, 2) void time_lstm_kernel(TimeLstmArgs a) { time_lstm_body<NT>(a); }
+
+// The same recurrence as a REPAIR pass behind a launch of the cooperating-workgroup kernels below: every workgroup reads that launch's
+// time-out word and exits at once unless a workgroup of it gave up waiting for its partner -- in which case this pass, which needs no
+// co-residency and cannot time out, recomputes the layer's H rows from the (untouched) input projections.  So a time-out costs time,
+// never a wrong row, and nothing has to travel to the host to decide it.  (3 - 4 us per layer when there is nothing to repair.)
+__global__ __launch_bounds__(512, 2) void time_lstm_repair_kernel(TimeLstmArgs a, const unsigned *timed_out) {
+    if (__hip_atomic_load(timed_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    time_lstm_body<1>(a);
+}
+
 // ---------------------------------------------------------------------------- time LSTM, small batches
 // A single utterance (156 - 640 frames) gives time_lstm_kernel<1> only 10 - 40 workgroups, each alone on its CU for 64 sequential
 // steps of 16.8 MFLOP: two waves per SIMD, 27 us per step, 1.9 ms per layer whatever the clip length -- the largest stage of a
@@ -835,19 +847,57 @@ __global__ __launch_bounds__(512, 2) void time_lstm_kernel(TimeLstmArgs a) {
 //     WRITE-THROUGH (sc1) stores, which is what makes the H rows themselves the hand-off buffer;
 //   * every storing wave drains its stores (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, ONE lane publishes the step
 //     number in the workgroup's flag word (relaxed agent-scope atomic store);
-//   * wave 0 polls the partner's flag word (relaxed, s_sleep between polls, BOUNDED: a timeout sets a word in the workspace and the
-//     kernel runs on with whatever it has -- it must never hang), the workgroup meets again, and every thread fetches its share
+//   * wave 0 polls the partner's flag word (relaxed, s_sleep between polls, BOUNDED in wall-clock time: on expiry the launch's
+//     time-out word is set and the kernel runs on with whatever it has -- it must never hang; time_lstm_repair_kernel, launched
+//     behind every launch of this kernel, then redoes the layer with the single-workgroup recurrence, so a time-out never reaches
+//     the caller as a wrong row), the workgroup meets again, and every thread fetches its share
 //     of the partner's slice with sc1 loads (they bypass this CU's L1, which another CU's stores never refresh) into LDS.
 // That is the publish / consume form MI355X_MICROARCH.md (visibility, "Valid forms", first table row) lists as measured for
 // hipMalloc'ed memory with one workgroup per CU (the launch asks for 96 KiB of LDS so that two never share one): no agent-scope
 // fence on either side.  The "time_lstm_handoff" option switches either side to the always-valid form (plain stores + agent release,
 // agent acquire + plain loads: 4 - 15 % slower, same bits).  Results do not depend on placement; the workgroups of a tile are
 // given block ids 8 apart only because such blocks were observed to share an XCD (its L2 then serves the exchange).  All workgroups
-// must be resident together: the launcher uses this kernel only while the grid fits the CUs.  Same k order and cell arithmetic as
+// should be resident together for the form to pay: the launcher uses this kernel only while the grid fits the CUs it may use (correctness
+// does not depend on it: partners are 8 block ids apart and workgroups are dispatched in block order, so whatever else occupies the device
+// the resident pairs finish and make room; and a wait that does expire is repaired, see above).  Same k order and cell arithmetic as
 // time_lstm_kernel: bit-identical.  (The template also instantiates for G = 4 -- two waves per workgroup -- which measured no
 // faster: a wave's matrix work per step does not change.  profiles/r03_time_lstm_split.txt)
+struct SplitCtl {
+    unsigned *flags;       // one word per workgroup, zeroed by the launcher: the last step whose slice of h the workgroup has published
+    unsigned *timed_out;   // this LAUNCH's time-out word (zeroed by the launcher; read by time_lstm_repair_kernel behind it)
+    unsigned *status;      // word 0 of the workspace's status block: time-outs since the block was zeroed (only ever incremented)
+    unsigned ticks;        // bound of one wait, in ticks of the 100 MHz wall clock (s_memrealtime)
+    int mode;              // bit 0 / 1: hand-off form ("time_lstm_handoff"); bit 2 (tests only): part 1 never publishes
+};
+
+// Bounded wait of wave 0 for its partners' flag words.  The bound is WALL-CLOCK time (read every 256th poll, so the common case -- the
+// partner is a few hundred nanoseconds behind -- pays nothing for it); on expiry the launch's time-out word and the workspace's
+// counter are set and the workgroup stops waiting for good: its rows are wrong from here on and time_lstm_repair_kernel redoes the layer.
+__device__ __forceinline__ bool split_wait(const unsigned *pf, unsigned want, const SplitCtl &ctl, int lane) {
+    unsigned spins = 0;
+    unsigned long long t0 = 0;
+    for (;;) {
+        const unsigned v = __hip_atomic_load(pf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all((int)(v >= want))) return false;
+        if ((++spins & 255u) == 0u) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > (unsigned long long)ctl.ticks) {
+                if (lane == 0) {
+                    __hip_atomic_store(ctl.timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (ctl.status) __hip_atomic_fetch_add(ctl.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                return true;
+            }
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
 template <int G>
-__global__ __launch_bounds__(512 / G) void time_lstm_split_kernel(TimeLstmArgs a, unsigned *flags, unsigned *timeout_word, int mode) {
+__global__ __launch_bounds__(512 / G) void time_lstm_split_kernel(TimeLstmArgs a, SplitCtl ctl) {
+    unsigned *const flags = ctl.flags;
+    const int mode = ctl.mode;
     extern __shared__ float4 sHs[];   // [2][64 k-quads][32 sequences]
     constexpr int BT = 32, NW = 8 / G, NTHR = 64 * NW;
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -964,7 +1014,7 @@ __global__ __launch_bounds__(512 / G) void time_lstm_split_kernel(TimeLstmArgs a
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
-                __hip_atomic_store(my_flag, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!((mode & 4) && part == 1)) __hip_atomic_store(my_flag, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             // the next step's input projection seeds the accumulators (requested now: its HBM latency runs under the hand-off)
             TS_GX_ALL(tn)
@@ -972,18 +1022,7 @@ __global__ __launch_bounds__(512 / G) void time_lstm_split_kernel(TimeLstmArgs a
             if (wave == 0 && !dead) {
                 const int pl = lane < G - 1 ? lane : 0;
                 const int partner = pl >= part ? pl + 1 : pl;
-                const unsigned *pf = flags + (size_t)td * G + partner;
-                unsigned spins = 0;
-                for (;;) {
-                    const unsigned v = __hip_atomic_load(pf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__all((int)(v >= (unsigned)(s + 1)))) break;
-                    if (++spins > (1u << 20)) {                      // ~1 s: a partner is not running -- give up for good, say so, never hang
-                        if (lane == 0) __hip_atomic_store(timeout_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        dead = true;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                }
+                dead = split_wait(flags + (size_t)td * G + partner, (unsigned)(s + 1), ctl, lane);   // a partner is not running: give up for good, say so, never hang
             }
             if (mode & 2) {      // plain loads below: ONE agent-scope acquire by the polling wave, drained before the barrier lets the others load
                 if (wave == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -1048,7 +1087,9 @@ __device__ __forceinline__ void lstm_cell_4(const f32x4v &ai, const f32x4v &af, 
     hq = make_float4(hv[0].x, hv[0].y, hv[1].x, hv[1].y);
 }
 
-__global__ __launch_bounds__(256) void time_lstm_split16_kernel(TimeLstmArgs a, unsigned *flags, unsigned *timeout_word, int mode) {
+__global__ __launch_bounds__(256) void time_lstm_split16_kernel(TimeLstmArgs a, SplitCtl ctl) {
+    unsigned *const flags = ctl.flags;
+    const int mode = ctl.mode;
     extern __shared__ float4 sH16[];   // [2 buffers][16 K16][4 g][16 frames] float4 (j = 0..3): 2 x 16 KiB
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1140,22 +1181,10 @@ __global__ __launch_bounds__(256) void time_lstm_split16_kernel(TimeLstmArgs a, 
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
-                __hip_atomic_store(my_flag, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!((mode & 4) && part == 1)) __hip_atomic_store(my_flag, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             T16_GX_ALL(tn)
-            if (wave == 0 && !dead) {
-                unsigned spins = 0;
-                for (;;) {
-                    const unsigned v = __hip_atomic_load(partner_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__all((int)(v >= (unsigned)(s + 1)))) break;
-                    if (++spins > (1u << 20)) {
-                        if (lane == 0) __hip_atomic_store(timeout_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        dead = true;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-            }
+            if (wave == 0 && !dead) dead = split_wait(partner_flag, (unsigned)(s + 1), ctl, lane);
             if (mode & 2) {
                 if (wave == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             } else {
@@ -1405,7 +1434,22 @@ static hipError_t launch_time_bf16(const TimeLstmArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-extern thread_local int g_sdfa_time_lstm_handoff;   // api.cpp ("time_lstm_handoff"): bit 0 = plain stores + agent release, bit 1 = agent acquire + plain loads
+extern thread_local int g_sdfa_time_lstm_handoff;   // api.cpp ("time_lstm_handoff"): bit 0 = plain stores + agent release, bit 1 = agent acquire + plain loads; bit 2 (tests) = part 1 never publishes
+extern thread_local int g_sdfa_time_lstm_timeout_us; // api.cpp ("time_lstm_timeout_us"): bound of one wait for a partner workgroup
+
+// Behind every launch of a cooperating-workgroup kernel: the repair pass (exits at once unless that launch timed out).
+static hipError_t launch_time_repair(const TimeLstmArgs &a, hipStream_t s) {
+    const size_t lds = 2 * 64 * 32 * sizeof(float4);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(time_lstm_repair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(time_lstm_repair_kernel, dim3((unsigned)(a.Nc / 32 * 2)), dim3(512), lds, s, a, a.flags);
+    return hipGetLastError();
+}
+
+static SplitCtl split_ctl(const TimeLstmArgs &a) {
+    const long long us = g_sdfa_time_lstm_timeout_us > 0 ? g_sdfa_time_lstm_timeout_us : 200000;   // default 0.2 s: four times the longest kernel of this library
+    return SplitCtl{a.flags + 4, a.flags, a.status, (unsigned)std::min<long long>(us * 100, 0xffffffffll), g_sdfa_time_lstm_handoff};
+}
 
 template <int G>
 static hipError_t launch_time_split(const TimeLstmArgs &a, hipStream_t s) {
@@ -1413,11 +1457,12 @@ static hipError_t launch_time_split(const TimeLstmArgs &a, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(time_lstm_split_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const unsigned grid = (unsigned)(a.Nc / 32 * 2 * G);
-    // flag words (one per workgroup) + the timeout word, zeroed every launch: a block of its own, a multiple of 16 bytes
+    // this launch's time-out word + flag words (one per workgroup), zeroed every launch: a block of its own, a multiple of 16 bytes
     e = hipMemsetAsync(a.flags, 0, ((size_t)grid + 4) * sizeof(unsigned), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(time_lstm_split_kernel<G>, dim3(grid), dim3(512 / G), lds, s, a, a.flags + 4, a.flags, g_sdfa_time_lstm_handoff);
-    return hipGetLastError();
+    hipLaunchKernelGGL(time_lstm_split_kernel<G>, dim3(grid), dim3(512 / G), lds, s, a, split_ctl(a));
+    e = hipGetLastError();
+    return e != hipSuccess ? e : launch_time_repair(a, s);
 }
 
 static hipError_t launch_time_split16(const TimeLstmArgs &a, hipStream_t s) {
@@ -1427,8 +1472,9 @@ static hipError_t launch_time_split16(const TimeLstmArgs &a, hipStream_t s) {
     const unsigned grid = (unsigned)(a.Nc / 16 * 2 * 2);
     e = hipMemsetAsync(a.flags, 0, ((size_t)grid + 4) * sizeof(unsigned), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(time_lstm_split16_kernel, dim3(grid), dim3(256), lds, s, a, a.flags + 4, a.flags, g_sdfa_time_lstm_handoff);
-    return hipGetLastError();
+    hipLaunchKernelGGL(time_lstm_split16_kernel, dim3(grid), dim3(256), lds, s, a, split_ctl(a));
+    e = hipGetLastError();
+    return e != hipSuccess ? e : launch_time_repair(a, s);
 }
 
 extern thread_local int g_sdfa_time_lstm_split;   // api.cpp ("time_lstm_split" option): 0 = by size, 1 = never
@@ -1438,9 +1484,11 @@ hipError_t sdfa_launch_time_lstm(const TimeLstmArgs &a, hipStream_t s) {
     const bool big = (a.Nc / 64) * 2 >= 256;
     if (!a.terms && a.flags && g_sdfa_time_lstm_split != 1) {
         // small batches: the gate rows of a tile split over G cooperating workgroups (time_lstm_split_kernel).  They exchange h
-        // every step, so ALL of them must be resident at once: only while the grid fits the CUs (one workgroup per CU)
+        // every step, so all of them should be resident at once: only while the grid fits the CUs this model may use (one
+        // workgroup per CU; sdfa_model_set_reserved_cus leaves some to other streams)
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        cus -= a.reserve_cus;
         const int64_t wg1 = a.Nc / 32 * 2;                       // workgroups of time_lstm_kernel<1>
         const bool range_ok = (int64_t)64 * a.Mc * 16 + (int64_t)a.Mc * 16 < 0x7fffffff && a.Nc % 128 == 0 && a.flag_words >= wg1 * 2 + 4;   // buffer offsets; 8-block groups
         // G = 2: four waves per workgroup, one per SIMD.  (G = 4 -- two waves per workgroup -- was measured too: no faster, a wave's

@@ -159,16 +159,24 @@ __global__ __launch_bounds__(256) void seek_rows_kernel(const float *__restrict_
 
 // Test-time ensembling (speech_anime/model/model.py:369-403): `anime_sum += second_pass; anime_sum / 2.0` on float32 arrays =
 // one rounded add and one (exact) division per element.  In place when out == a.
+// VEC = 4: 16-byte aligned operands; VEC = 1: any 4-byte alignment (the offsets head's 60,276-byte rows put the second pass of a
+// launch group at a 16-byte boundary only every fourth row).
+template <int VEC>
 __global__ __launch_bounds__(256) void ensemble_mean_kernel(const float *a, const float *__restrict__ b, int64_t n, float *out) {
-    const int64_t nq = n / 4;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (int64_t)gridDim.x * blockDim.x) {
-        const float4 x = ld4(a + 4 * i), y = ld4(b + 4 * i);
-        st4(out + 4 * i, make_float4(__fdiv_rn(fadd_exact(x.x, y.x), 2.0f), __fdiv_rn(fadd_exact(x.y, y.y), 2.0f),
-                                     __fdiv_rn(fadd_exact(x.z, y.z), 2.0f), __fdiv_rn(fadd_exact(x.w, y.w), 2.0f)));
-    }
-    if (blockIdx.x == 0 && threadIdx.x < n % 4) {
-        const int64_t i = nq * 4 + threadIdx.x;
-        out[i] = __fdiv_rn(fadd_exact(a[i], b[i]), 2.0f);
+    if (VEC == 4) {
+        const int64_t nq = n / 4;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (int64_t)gridDim.x * blockDim.x) {
+            const float4 x = ld4(a + 4 * i), y = ld4(b + 4 * i);
+            st4(out + 4 * i, make_float4(__fdiv_rn(fadd_exact(x.x, y.x), 2.0f), __fdiv_rn(fadd_exact(x.y, y.y), 2.0f),
+                                         __fdiv_rn(fadd_exact(x.z, y.z), 2.0f), __fdiv_rn(fadd_exact(x.w, y.w), 2.0f)));
+        }
+        if (blockIdx.x == 0 && threadIdx.x < n % 4) {
+            const int64_t i = nq * 4 + threadIdx.x;
+            out[i] = __fdiv_rn(fadd_exact(a[i], b[i]), 2.0f);
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+            out[i] = __fdiv_rn(fadd_exact(a[i], b[i]), 2.0f);
     }
 }
 
@@ -211,8 +219,10 @@ hipError_t sdfa_launch_seek_rows(const float *rows, int64_t width, const int64_t
 }
 
 hipError_t sdfa_launch_ensemble_mean(const float *a, const float *b, int64_t n, float *out, hipStream_t s) {
-    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n / 4 + 255) / 256, 256 * 32));
-    hipLaunchKernelGGL(ensemble_mean_kernel, dim3(grid), dim3(256), 0, s, a, b, n, out);
+    const bool vec = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(((vec ? n / 4 : n) + 255) / 256, 256 * 32));
+    if (vec) hipLaunchKernelGGL(ensemble_mean_kernel<4>, dim3(grid), dim3(256), 0, s, a, b, n, out);
+    else hipLaunchKernelGGL(ensemble_mean_kernel<1>, dim3(grid), dim3(256), 0, s, a, b, n, out);
     return hipGetLastError();
 }
 

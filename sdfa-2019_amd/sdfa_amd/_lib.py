@@ -48,7 +48,9 @@ SYMBOLS = {
     "sdfa_debug_keep_intermediates": (C.c_int, [_p, C.c_int]),
     "sdfa_debug_distinct_columns": (_i64, [_p, _i64, _p, _p]),
     "sdfa_debug_tap": (C.c_int, [_p, C.c_int, _i64, _p, _p, _p]),
-    "sdfa_debug_time_lstm_timeout": (C.c_int, [_p, _i64, _p, _p]),
+    "sdfa_workspace_init": (C.c_int, [_p, _i64, _p]),
+    "sdfa_workspace_status_async": (C.c_int, [_p, _p, _p]),
+    "sdfa_workspace_status": (_i64, [_p, C.c_int, _p]),
     "sdfa_mesh_create": (_p, [_p, _i64, _p, _i64, _p, _i64, C.c_double, _p]),
     "sdfa_mesh_destroy": (None, [_p]),
     "sdfa_mesh_workspace_bytes": (_i64, [_p, _i64]),

@@ -152,6 +152,10 @@ class Engine(FrontendOnly):
         self.max_frames = int(max_frames)
         self._ws = None
         self._id_checks = []            # (pinned [min, max], event) of device-resident speaker-id tensors not yet looked at
+        self._status_reads = []         # (pinned status-block copy, event) of forward_host calls not yet looked at
+        self._status_free = []          # pinned slots to reuse
+        self._repairs_carried = 0       # time-LSTM repairs counted in workspaces this engine has since replaced
+        self.repairs_seen = 0           # ... and the last count a status read showed (host_wait / check_pending keep it current)
         self._host = None               # HostPipeline, created by the first forward_host call
         self.set_precision(precision)
 
@@ -177,9 +181,30 @@ class Engine(FrontendOnly):
     def workspace(self, n_frames):
         need = check(lib.sdfa_workspace_bytes(self._m, min(int(n_frames), self.max_frames)))
         if self._ws is None or self._ws.numel() < need:
+            if self._ws is not None:
+                self._repairs_carried += self.time_lstm_repairs()      # the old block's count (a sync; regrowth is rare)
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            check(lib.sdfa_workspace_init(_ptr(self._ws), self._ws.numel(), _stream()))    # zero the status block, once
         return self._ws
+
+    def time_lstm_repairs(self):
+        """Waits of the cooperating-workgroup time-LSTM kernels that expired since this engine was made (include/sdfa_hip.h, "Status
+        block").  Every one was repaired on the device before anything read the layer -- rows are right either way; the count says
+        that the device was so oversubscribed that a single-clip call lost about 0.2 s.  Synchronises the stream."""
+        if self._ws is None:
+            return self._repairs_carried
+        return self._repairs_carried + int(check(lib.sdfa_workspace_status(_ptr(self._ws), 0, _stream())))
+
+    def _status_async(self, stream_ptr=None):
+        """Enqueues a copy of the workspace's status block to a pinned slot (no sync); `check_pending` looks at it later."""
+        if self._ws is None:
+            return
+        slot = self._status_free.pop() if self._status_free else torch.zeros(4, dtype=torch.int32, pin_memory=True)
+        check(lib.sdfa_workspace_status_async(_ptr(self._ws), _ptr(slot), stream_ptr if stream_ptr is not None else _stream()))
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._status_reads.append((slot, ev))
 
     def autotune(self, n_frames=None):
         """Measures the launch forms of the frequency-LSTM kernel on `n_frames` (default max_frames) frames and keeps the
@@ -249,6 +274,21 @@ class Engine(FrontendOnly):
 
     def check_pending(self, block=True):
         """Raises for any device-resident speaker-id tensor of an earlier call that held an id outside [0, 8)."""
+        still = []
+        for slot, ev in self._status_reads:
+            if block:
+                ev.synchronize()
+            elif not ev.query():
+                still.append((slot, ev))
+                continue
+            n = self._repairs_carried + int(slot[0])
+            self._status_free.append(slot)
+            if n > self.repairs_seen:
+                import warnings
+                warnings.warn(f"sdfa_amd: {n - self.repairs_seen} time-LSTM launch(es) of a single-clip call waited out their partner workgroups "
+                              "(device oversubscribed) and were recomputed on the device; results are unaffected", RuntimeWarning, stacklevel=2)
+                self.repairs_seen = n
+        self._status_reads = still
         keep = []
         for slot, ev in self._id_checks:
             if block:
@@ -321,7 +361,7 @@ class Engine(FrontendOnly):
         check(lib.sdfa_ensemble_mean(_ptr(a), _ptr(b), a.numel(), _ptr(out), _stream()))
         return out
 
-    def forward_host(self, feat, speaker_id, out=None, table=None, piece=None, wait=True, want_z=False, ops_key=None, ensemble=False):
+    def forward_host(self, feat, speaker_id, out=None, table=None, piece=None, wait=True, want_z=False, ops_key=None, ensemble=False, z=None):
         """The whole model for `n` frames with the output rows delivered to PINNED HOST memory: rows (n, out_dim) as a CPU
         tensor (`.numpy()` is a view).  Frames are processed in pieces of `piece` (default max_frames) frames; piece i's rows
         are copied device -> host on a copy stream while piece i+1 computes (two device staging buffers), so for more than one
@@ -336,10 +376,14 @@ class Engine(FrontendOnly):
                       distinct column (bitwise identical, sdfa_encoder_forward_shared)
           out         pinned float32 CPU tensor (n, out_dim) to fill (allocated from PyTorch's pinned-memory cache otherwise)
           wait        False: return as soon as everything is enqueued; call `host_wait()` before reading `out`
+          z           encoder output of exactly these frames from an earlier call (`last_z()`): the encoder is skipped and only the
+                      regressor runs -- the same signal with another speaker (the reference keeps the features of the last signal
+                      for this, model.py:364-367,409-416; here everything up to z is speaker-independent).  `feat` may be None
           ops_key     key of this engine in sdfa_amd.ops' registry: the kernels are then called through the dispatcher-visible
                       PyTorch-ROCm custom operators torch.ops.sdfa.{encoder, encoder_shared, regress_into} (same C ABI calls)"""
-        n = int(feat.shape[0]) // (2 if ensemble else 1)
-        assert feat.shape[0] == (2 * n if ensemble else n)
+        src = feat if z is None else z
+        n = int(src.shape[0]) // (2 if ensemble else 1)
+        assert src.shape[0] == (2 * n if ensemble else n)
         self._validate_ids(speaker_id, None)
         if not torch.is_tensor(speaker_id):
             speaker_id = torch.full((n,), int(speaker_id), dtype=torch.int64, device=self.device)
@@ -354,7 +398,7 @@ class Engine(FrontendOnly):
         piece = int(piece or self.max_frames)
         if ensemble:
             piece = max(1, piece // 2)                  # a piece holds both passes of its frames
-        zs = self._host.run(feat, speaker_id, out, table, piece, want_z, ops_key, ensemble)
+        zs = self._host.run(feat, speaker_id, out, table, piece, want_z, ops_key, ensemble, z)
         if wait:
             self.host_wait()
         return (out, zs) if want_z else out
@@ -370,12 +414,17 @@ class Engine(FrontendOnly):
         """Blocks until every device -> host copy enqueued by forward_host has landed."""
         if self._host is not None:
             self._host.wait()
-        self.check_pending(block=False)
+        self.check_pending(block=False)      # speaker ids of device tensors; status blocks (time-LSTM repairs) of the calls that have landed
 
     def last_device_rows(self, n):
         """The device copy of the rows the LAST forward_host call produced, when all `n` of them went through one piece (a
         view into a staging buffer: valid until the next forward_host call); None otherwise."""
         return None if self._host is None else self._host.last_rows(n)
+
+    def last_z(self):
+        """Encoder output (n, 512) -- (2n, 512), pass 1 then pass 2, for an ensembling call -- of the LAST forward_host call when all
+        its frames went through one piece; None otherwise.  Feed it back as `z=` to re-run only the regressor."""
+        return None if self._host is None else self._host.last_z
 
     def forward(self, audio_feat, speaker_id, want_coef=False):
         z, align = self.encoder(audio_feat)
@@ -385,10 +434,6 @@ class Engine(FrontendOnly):
     def distinct_columns(self, n_frames):
         """Distinct columns evaluated by the last shared encoder call on a chunk of n_frames (reporting only)."""
         return int(check(lib.sdfa_debug_distinct_columns(self._m, int(n_frames), _ptr(self._ws), _stream())))
-
-    def time_lstm_timeout(self, n_frames):
-        """1 if the small-batch time-LSTM kernel gave up waiting for a partner workgroup in the last encoder call (tests)."""
-        return int(check(lib.sdfa_debug_time_lstm_timeout(self._m, int(n_frames), _ptr(self._ws), _stream())))
 
     def tap(self, what, n_frames):
         shapes = {0: (32, 64, 64), 1: (64, 32, 64), 2: (256, 64), 3: (64, 512)}
@@ -425,21 +470,27 @@ class HostPipeline:
         self.done = [None, None]        # copy-done event of the last copy out of each buffer
         self.extra = []                 # copy-done events of stage_out copies
         self._last = None
+        self.last_z = None              # encoder output of the last call when it was one piece
         self._next = 0                  # running piece counter: staging buffer = parity
 
     def _buf(self, slot, rows):
         b = self.bufs[slot]
         if b is None or b.shape[0] < rows:
-            self.bufs[slot] = None
+            if b is not None:
+                # a device -> host copy on the copy stream may still be reading the old block: the caching allocator must not hand
+                # it to the next kernels' temporaries before that copy has run
+                b.record_stream(self.copy_stream)
+            self.bufs[slot] = b = None
             self.bufs[slot] = b = torch.empty((rows, self.eng.out_dim), dtype=torch.float32, device=self.eng.device)
         return b
 
-    def run(self, feat, spk, out, table, piece, want_z, ops_key=None, ensemble=False):
+    def run(self, feat, spk, out, table, piece, want_z, ops_key=None, ensemble=False, z_in=None):
         eng = self.eng
         n = int(out.shape[0])
         cur = torch.cuda.current_stream(eng.device)
         zs = []
         self._last = None
+        self.last_z = None
         for f0 in range(0, n, piece):
             f1 = min(n, f0 + piece)
             m = f1 - f0
@@ -447,7 +498,7 @@ class HostPipeline:
             self._next += 1
             rows = self._buf(slot, min(piece, n))[:m]
             if ensemble:                                # pass 1 = frames [f0, f1), pass 2 = frames [n + f0, n + f1): ONE launch group for both
-                x = torch.cat((feat[f0:f1], feat[n + f0:n + f1]))
+                x = None if z_in is not None else torch.cat((feat[f0:f1], feat[n + f0:n + f1]))
                 t = None if table is None else (torch.cat((table[0][f0:f1], table[0][n + f0:n + f1])), torch.cat((table[1][f0:f1], table[1][n + f0:n + f1])), table[2])
                 ids = torch.cat((spk[f0:f1], spk[f0:f1]))
                 if self.tmp is None or self.tmp.shape[0] < 2 * m:
@@ -455,9 +506,11 @@ class HostPipeline:
                     self.tmp = torch.empty((2 * min(piece, n), eng.out_dim), dtype=torch.float32, device=eng.device)
                 dst = self.tmp[:2 * m]
             else:
-                x, ids, dst = feat[f0:f1], spk[f0:f1], rows
+                x, ids, dst = (None if z_in is not None else feat[f0:f1]), spk[f0:f1], rows
                 t = None if table is None else (table[0][f0:f1], table[1][f0:f1], table[2])
-            if ops_key is not None:                     # through the dispatcher (torch.ops.sdfa.*): same Engine methods underneath
+            if z_in is not None:                        # same signal, another speaker: z is speaker-independent, only the regressor runs
+                z = z_in[f0:f1] if not ensemble else (z_in if (f0 == 0 and f1 == n) else torch.cat((z_in[f0:f1], z_in[n + f0:n + f1])))
+            elif ops_key is not None:                   # through the dispatcher (torch.ops.sdfa.*): same Engine methods underneath
                 if t is None:
                     z, _ = torch.ops.sdfa.encoder(x, ops_key)
                 else:
@@ -490,6 +543,9 @@ class HostPipeline:
             self.done[slot] = done
             if f0 == 0 and f1 == n:
                 self._last = (slot, n)
+                self.last_z = z
+        with torch.cuda.stream(self.copy_stream):       # behind the call's last copy: the workspace's status block (time-LSTM repairs)
+            eng._status_async()
         return torch.cat(zs) if want_z and len(zs) != 1 else (zs[0] if want_z else None)
 
     def stage_out(self, t):

@@ -81,6 +81,7 @@ class SaberSpeechDrivenAnimation:
     # ---- weights ------------------------------------------------------------------------------
     def load_state_dict(self, state_dict, strict=True):
         self._model.load_state_dict(state_dict, strict)
+        self._signal_cache = None
         DatasetSlidingWindow.use_engine(self._model._engine)
         return self
 
@@ -184,9 +185,22 @@ class SaberSpeechDrivenAnimation:
         for spk in speakers:
             assert isinstance(spk, (int, np.integer)), f"given index is {spk}, {type(spk)}"
             eng.check_speaker_ids(int(spk))
+        ensemble = ensembling_ms is not None and ensembling_ms > 0
+        # The reference keeps the features of the LAST signal (model.py:364-367,409-416): the same audio with another speaker does
+        # not recompute the front end.  Here everything up to the encoder output z is speaker-independent, so the one-entry cache
+        # holds z: a speaker sweep over one clip re-runs only the regressor (bitwise the full call: same z, same kernels after it).
+        key = (sr, int(ensembling_ms) if ensemble else 0)
+        c = getattr(self, "_signal_cache", None)
+        if (len(signals) == 1 and c is not None and c["key"] == key and c["signal"].shape == signals[0].shape
+                and np.array_equal(c["signal"], signals[0])):
+            n = len(c["tslist"])
+            spk = torch.full((n,), int(speakers[0]), dtype=torch.int64, device=eng.device)
+            inputs_host = eng.to_host_async(c["feat"][:n].permute(0, 3, 2, 1)) if want_inputs else None
+            rows = eng.forward_host(None, spk, z=c["z"], ops_key=self._model._key, wait=True, ensemble=ensemble)
+            return [self._pack(rows.numpy(), None if inputs_host is None else inputs_host.numpy(), [c["tslist"]], [n])[0]]
+        self._signal_cache = None
         tables = [frame_index(len(s), sr) for s in signals]             # ONE enumeration per clip (starts, tslist)
         clips = list(signals)
-        ensemble = ensembling_ms is not None and ensembling_ms > 0
         if ensemble:                                                    # model.py:373-384: second pass on a delayed copy --
             pad = ensembling_ms * sr // 1000                            # here as further clips of the same launch group
             clips += [np.pad(s[:-pad], [[pad, 0]], "constant") for s in signals]
@@ -200,10 +214,13 @@ class SaberSpeechDrivenAnimation:
         if want_inputs:                                                 # others["inputs"] = audio_feat.permute(0, 3, 2, 1), model.py:463-466
             inputs_host = eng.to_host_async(feat[:n].permute(0, 3, 2, 1))
         rows = eng.forward_host(feat, spk, table=share, ops_key=self._model._key, wait=True, ensemble=ensemble)
+        if len(signals) == 1 and eng.last_z() is not None:               # one clip, one piece: remember (signal -> z) for a speaker sweep
+            self._signal_cache = {"key": key, "signal": signals[0].copy(), "tslist": tslists[0], "z": eng.last_z(), "feat": feat}
+        return self._pack(rows.numpy(), inputs_host.numpy() if inputs_host is not None else None, tslists, counts)
+
+    def _pack(self, rows_np, inputs_np, tslists, counts):
         shape = (-1, 9) if self._face_type == "dgrad_3d" else ()
         out, f0 = [], 0
-        rows_np = rows.numpy()
-        inputs_np = inputs_host.numpy() if inputs_host is not None else None
         for ci, c in enumerate(counts):
             animes = rows_np[f0:f0 + c].reshape((c,) + shape) if shape else rows_np[f0:f0 + c]
             others = {"inputs": inputs_np[f0:f0 + c] if inputs_np is not None else None,
@@ -235,11 +252,40 @@ class SaberSpeechDrivenAnimation:
 
     # ---- model.py:121-223 (host loop; rendering / mesh export replaced by a dgrad track dump) ----
     def evaluate(self, sources, experiment=None, in_trainer=False, **kwargs):
-        sr, fps = self.hp.audio.sample_rate, self.hp.anime.fps
+        """The reference's host loop over sources (model.py:152-212).  The reference calls generate_animation once per source; here
+        the sources are taken in LAUNCH GROUPS -- as many consecutive clips as fit one piece of the engine (`max_frames` animation
+        frames; kwargs["group_frames"] overrides) go through ONE generate_animation_batch call -- because frames are independent
+        and a clip's rows do not depend on what it is batched with (bitwise, tests/test_surface_fast.py), so every per-clip result
+        and every file written is exactly what the clip-by-clip loop produces, at the batch path's throughput."""
+        sr = self.hp.audio.sample_rate
         output_dir = kwargs.get("output_dir") or "evaluate_results"
         target_db = kwargs.get("audio_target_db", self.hp.dataset_anime.audio_target_db)
         export_frames = kwargs.get("export_mesh_frames", not in_trainer)
-        results = []
+        ens = kwargs.get("ensembling_ms")
+        if ens is None:
+            ens = self.hp.ensembling_ms
+        eng = self._model._engine
+        if eng is None:
+            raise RuntimeError("no weights loaded: call load_state_dict first")
+        from sdfa_amd.engine import frame_index
+        limit = int(kwargs.get("group_frames") or eng.max_frames) // (2 if (ens is not None and ens > 0) else 1)
+        results, group, group_frames = [], [], 0
+
+        def flush():
+            nonlocal group, group_frames
+            if not group:
+                return
+            outs = self.generate_animation_batch([g["signal"] for g in group], [g["spk"] for g in group], ensembling_ms=ens, want_inputs=False)
+            total = sum(len(o[0]) for o in outs)
+            track_all = eng.last_device_rows(total) if export_frames else None      # one piece: the rows are still on the device
+            f0 = 0
+            for g, (tslist, animes, _) in zip(group, outs):
+                track = None if track_all is None else track_all[f0:f0 + len(tslist)]
+                f0 += len(tslist)
+                self._write_result(g, tslist, animes, track, output_dir, export_frames)
+                results.append((g["path"], tslist, animes))
+            group, group_frames = [], 0
+
         for _, records in dict(sources).items():
             for rec in records:
                 path = rec[0]
@@ -247,39 +293,45 @@ class SaberSpeechDrivenAnimation:
                 for extra in rec[1:]:
                     if isinstance(extra, str) and extra.startswith("speaker="):
                         spk = extra.split("=", 1)[1]
-                name = os.path.splitext(os.path.basename(path))[0]
                 signal, sound_signal = _audio.load_source(path, sr, return_sound=True)         # eval_utils.py:76-86
                 signal = _audio.rms_normalize(signal, target_db).astype(np.float32)            # model.py:165
-                tslist, animes, _ = self.generate_animation(signal=signal, speaker=spk, emotion=0, frame_id=0,
-                                                            dataset_class=DatasetSlidingWindow, want_inputs=False,
-                                                            ensembling_ms=kwargs.get("ensembling_ms"))
-                out_dir = os.path.join(output_dir, name)
-                os.makedirs(out_dir, exist_ok=True)
-                np.save(os.path.join(out_dir, "tslist.npy"), np.asarray(tslist, np.int64))
-                np.save(os.path.join(out_dir, f"{self._face_type}.npy"), animes)
-                if export_frames:                                                              # model.py:201-212
-                    from .. import viewer
-                    from sdfa_amd.seek import SeekPlan
-                    if sound_signal is not None:
-                        _audio.write_wav(os.path.join(out_dir, "audio.wav"), sound_signal, _audio.SOUND_SR)   # model.py:203
-                    # stream.seek for every video frame i at i * 1000 / fps, i = 0 .. int(tslist[-1] * fps / 1000), as ONE
-                    # device stage; with a template the mesh solve is fused into it (the blended track is only
-                    # materialised for the NNNNNN_dgrad.npy dump the reference also writes)
-                    eng = self._model._engine
-                    plan = SeekPlan([tslist], fps, device=eng.device)
-                    track = eng.last_device_rows(len(tslist))           # the rows are still on the device: no re-upload (model.py:200)
-                    if track is None:
-                        track = torch.from_numpy(np.ascontiguousarray(animes, dtype=np.float32)).to(eng.device).reshape(len(tslist), -1)
-                    frames = plan.rows(track).cpu().numpy().reshape((plan.n_queries,) + animes.shape[1:])
-                    for i_frame, data_frame in enumerate(frames):
-                        np.save(os.path.join(out_dir, f"{i_frame:06d}_dgrad.npy"), data_frame)
-                    if viewer.has_template():          # --template_mesh given: seek + solve on the GPU, then .obj per frame
-                        if self._face_type == "dgrad_3d":
-                            verts, faces = viewer.track_to_mesh(track, plan).cpu().numpy(), viewer.template_faces()
-                        else:
-                            verts, faces = viewer.frames_to_mesh(frames.astype(np.float32), self._face_type)
-                        for i_frame in range(len(frames)):
-                            viewer.write_obj(os.path.join(out_dir, f"{i_frame:06d}.obj"), verts[i_frame], faces)
-                print(f"[speech_anime] {name}: {len(tslist)} animation frames -> {out_dir} (video rendering is outside this path)")
-                results.append((path, tslist, animes))
+                signal = self._check_signal(signal)
+                n = int(frame_index(len(signal), sr)[0].shape[0])
+                if group and group_frames + n > limit:
+                    flush()
+                group.append(dict(path=path, spk=spk, signal=signal, sound=sound_signal))
+                group_frames += n
+        flush()
         return results
+
+    def _write_result(self, g, tslist, animes, track, output_dir, export_frames):
+        """One source's files (model.py:195-212): tslist / track dumps, audio.wav, NNNNNN_dgrad.npy and, with a template, NNNNNN.obj."""
+        fps = self.hp.anime.fps
+        name = os.path.splitext(os.path.basename(g["path"]))[0]
+        out_dir = os.path.join(output_dir, name)
+        os.makedirs(out_dir, exist_ok=True)
+        np.save(os.path.join(out_dir, "tslist.npy"), np.asarray(tslist, np.int64))
+        np.save(os.path.join(out_dir, f"{self._face_type}.npy"), animes)
+        if export_frames:                                                              # model.py:201-212
+            from .. import viewer
+            from sdfa_amd.seek import SeekPlan
+            eng = self._model._engine
+            if g["sound"] is not None:
+                _audio.write_wav(os.path.join(out_dir, "audio.wav"), g["sound"], _audio.SOUND_SR)   # model.py:203
+            # stream.seek for every video frame i at i * 1000 / fps, i = 0 .. int(tslist[-1] * fps / 1000), as ONE
+            # device stage; with a template the mesh solve is fused into it (the blended track is only
+            # materialised for the NNNNNN_dgrad.npy dump the reference also writes)
+            plan = SeekPlan([tslist], fps, device=eng.device)
+            if track is None:                                       # the group took several pieces: re-upload this clip's rows (model.py:200)
+                track = torch.from_numpy(np.ascontiguousarray(animes, dtype=np.float32)).to(eng.device).reshape(len(tslist), -1)
+            frames = plan.rows(track).cpu().numpy().reshape((plan.n_queries,) + animes.shape[1:])
+            for i_frame, data_frame in enumerate(frames):
+                np.save(os.path.join(out_dir, f"{i_frame:06d}_dgrad.npy"), data_frame)
+            if viewer.has_template():          # --template_mesh given: seek + solve on the GPU, then .obj per frame
+                if self._face_type == "dgrad_3d":
+                    verts, faces = viewer.track_to_mesh(track, plan).cpu().numpy(), viewer.template_faces()
+                else:
+                    verts, faces = viewer.frames_to_mesh(frames.astype(np.float32), self._face_type)
+                for i_frame in range(len(frames)):
+                    viewer.write_obj(os.path.join(out_dir, f"{i_frame:06d}.obj"), verts[i_frame], faces)
+        print(f"[speech_anime] {name}: {len(tslist)} animation frames -> {out_dir} (video rendering is outside this path)")

@@ -170,7 +170,7 @@ def test_split_time_lstm_is_bitwise_the_single_workgroup_form(synth_sd):
             _lib.set_option("time_lstm_handoff", handoff)
             for rep in range(3):
                 z1, a1 = e.encoder(x)
-                assert e.time_lstm_timeout(n) == 0
+                assert e.time_lstm_repairs() == 0
                 assert torch.equal(z0, z1) and torch.equal(a0, a1), (n, split, handoff, rep)
         finally:
             _lib.set_option("time_lstm_split", 0)
@@ -200,3 +200,69 @@ def test_copy_stream_probe_and_ensembled_pipeline(eng):
     assert isinstance(host.copy_overlaps, bool) and len(host.copy_probe) >= 1
     assert all({"priority", "kernels_ms", "copy_end_ms", "overlaps"} <= set(p) for p in host.copy_probe)
     assert host.copy_probe[-1]["overlaps"] == host.copy_overlaps
+
+
+def test_speaker_sweep_reuses_the_encoder_output(synth_sd):
+    """The reference keeps the last signal's features (model.py:364-367,409-416); here the cache holds the speaker-independent
+    encoder output z, so the same clip with another speaker re-runs only the regressor.  Bitwise a fresh call."""
+    sr = 16000
+    hp, model = _model(synth_sd["dgrad"], sr)
+    hp2, fresh = _model(synth_sd["dgrad"], sr)
+    eng = model._model._engine
+    pcm = synth.make_pcm(12, int(2.4 * sr))
+    for ens in (0, 20):
+        ts0, a0, o0 = model.generate_animation(pcm, "m1", 0, 0, ensembling_ms=ens)
+        assert model._signal_cache is not None
+        eng.profile(True)
+        ts1, a1, o1 = model.generate_animation(pcm.copy(), "f0", 0, 0, ensembling_ms=ens)       # equal content, another array, another speaker
+        torch.cuda.synchronize()
+        with pytest.raises(Exception):
+            eng.profile_ms("freq_lstm")                                   # the encoder did not run
+        assert eng.profile_ms("pca") > 0
+        eng.profile(False)
+        tsf, af, of = fresh.generate_animation(pcm, "f0", 0, 0, ensembling_ms=ens)
+        fresh._signal_cache = None
+        assert ts1 == ts0 == tsf and np.array_equal(a1, af) and not np.array_equal(a1, a0)
+        assert np.array_equal(o1["inputs"], of["inputs"])
+        ts2, a2, _ = model.generate_animation(pcm, "m1", 0, 0, ensembling_ms=ens, want_inputs=False)   # back to the first speaker
+        assert np.array_equal(a2, a0)
+    other = synth.make_pcm(13, int(2.4 * sr))
+    ts3, a3, _ = model.generate_animation(other, "m1", 0, 0, ensembling_ms=20, want_inputs=False)      # another signal: recomputed
+    tsf, af, _ = fresh.generate_animation(other, "m1", 0, 0, ensembling_ms=20, want_inputs=False)
+    assert np.array_equal(a3, af)
+    ts4, a4, _ = model.generate_animation(other, "m1", 0, 0, ensembling_ms=0, want_inputs=False)       # same signal, other ensembling: recomputed
+    fresh._signal_cache = None
+    tsf, af, _ = fresh.generate_animation(other, "m1", 0, 0, ensembling_ms=0, want_inputs=False)
+    assert np.array_equal(a4, af)
+
+
+def test_evaluate_in_launch_groups_is_the_clip_by_clip_loop(tmp_path, synth_sd):
+    """evaluate() (model.py:152-212) takes its sources in launch groups through generate_animation_batch: every file it writes
+    is what the one-clip-at-a-time loop writes, bit for bit -- with groups of several clips, a group boundary, and ensembling."""
+    from scipy.io import wavfile
+    sr = 16000
+    hp, model = _model(synth_sd["dgrad"], sr)
+    lens = [1.0, 2.3, 0.8, 1.7, 1.2]
+    spks = ["m1", "f0", "m0", "m1", "f1"]
+    recs = []
+    for i, (s, k) in enumerate(zip(lens, spks)):
+        w = tmp_path / f"clip{i}.wav"
+        wavfile.write(str(w), sr, (synth.make_pcm(60 + i, int(s * sr), "speechlike") * 20000).astype(np.int16))
+        recs.append([str(w), f"speaker={k}"])
+    for ens in (None, 20):
+        a = model.evaluate({"test": recs}, output_dir=str(tmp_path / f"grouped{ens}"), export_mesh_frames=True, ensembling_ms=ens,
+                           group_frames=300 if ens is None else 600)      # 96 + 174 | 84 + 138 | 108 frames: three groups (a group holds both passes)
+        b = []
+        for r in recs:                                # one source per call = the reference's loop
+            b += model.evaluate({"test": [r]}, output_dir=str(tmp_path / f"single{ens}"), export_mesh_frames=True, ensembling_ms=ens)
+        assert [x[0] for x in a] == [x[0] for x in b] == [r[0] for r in recs]
+        for (pa, ta, ra), (pb, tb, rb) in zip(a, b):
+            assert list(ta) == list(tb) and np.array_equal(ra, rb)
+        import filecmp
+        import os
+        for i in range(len(recs)):
+            da, db = tmp_path / f"grouped{ens}" / f"clip{i}", tmp_path / f"single{ens}" / f"clip{i}"
+            names = sorted(os.listdir(da))
+            assert names == sorted(os.listdir(db)) and "audio.wav" in names and "000000_dgrad.npy" in names
+            match, mismatch, errors = filecmp.cmpfiles(str(da), str(db), names, shallow=False)
+            assert not mismatch and not errors, (i, mismatch, errors)

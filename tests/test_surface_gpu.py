@@ -151,3 +151,35 @@ def test_evaluate_with_template_mesh_writes_obj(tmp_path, synth_sd, golden):
     viewer.write_obj(str(p), verts[0], faces)
     rv, rf = viewer.read_obj(str(p))
     assert np.abs(rv - verts[0]).max() <= 1e-6 and np.array_equal(rf, faces)
+
+
+def test_evaluate_sh_command_line_as_a_process(tmp_path, synth_sd):
+    """`python3 -m speech_anime evaluate --load_from ... --custom_hparams ... --output_dir ... --eval_input ... --eval_spk_cond m1
+    --overwrite_video` (evaluate.sh:15-22) run as a fresh process: argparse Namespace -> evaluate_model -> checkpoint -> files."""
+    import subprocess
+    import sys
+    from scipy.io import wavfile
+    sr = 16000
+    pcm = synth.make_pcm(6, 2 * sr)
+    wav = tmp_path / "speech@clip0.wav"
+    wavfile.write(str(wav), sr, (pcm * 32767).astype(np.int16))
+    ck = tmp_path / "epoch0050-step086751.ckpt"
+    torch.save({"epoch": 50, "global_step": 86751, "state": {k: torch.from_numpy(np.array(v)) for k, v in synth_sd["dgrad"].items()}}, str(ck))
+    hpj = tmp_path / "hparams.json"
+    hpj.write_text('{"audio": {"sample_rate": 16000}}')
+    out = tmp_path / "results_flame"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=os.path.join(root, "sdfa-2019_amd") + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "speech_anime", "evaluate", "--load_from", str(ck), "--custom_hparams", str(hpj), "--output_dir", str(out),
+           "--eval_input", str(wav), "--eval_spk_cond", "m1", "--overwrite_video"]
+    r = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = out / "speech@clip0"
+    ts = np.load(d / "tslist.npy")
+    track = np.load(d / "dgrad_3d.npy")
+    assert len(ts) == 156 and track.shape == (156, 9976, 9)
+    # the same clip through the in-process surface: the process wrote the same rows
+    DatasetSlidingWindow.hparams = None
+    res = evaluate_model(dict(mode="evaluate", load_from=str(ck), custom_hparams=str(hpj), output_dir=str(tmp_path / "inproc"),
+                              eval_input=str(wav), eval_spk_cond="m1", overwrite_video=True))
+    assert list(res[0][1]) == list(ts) and np.array_equal(res[0][2], track)

@@ -30,7 +30,7 @@ for handoff in (0, 3):
         if not torch.equal(z, ref[n]):
             bad[n] += 1
         if i % 97 == 0:
-            timeouts += eng.time_lstm_timeout(n)
+            timeouts = eng.time_lstm_repairs()
     print(f"handoff {handoff}: {iters} calls, mismatches per size {bad}, timeouts {timeouts}", flush=True)
 _lib.set_option("time_lstm_handoff", 0)
 print("STRESS", "OK" if not any(bad.values()) and timeouts == 0 else "FAILED")
