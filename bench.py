@@ -72,7 +72,7 @@ def parse():
                     help="clip lengths uniform in [LO, HI] s instead of --seconds (a VOCASET-like stream of sentences)")
     ap.add_argument("--frontend", choices=["gather", "direct"], default="gather",
                     help="gather = each distinct STFT column once + per-frame gather (sdfa_mel_frontend_gather); direct = one FFT per window column")
-    ap.add_argument("--precision", choices=["fp32", "bf16_attention", "bf16x3", "bf16"], default="fp32",
+    ap.add_argument("--precision", choices=["fp32", "bf16_attention", "bf16x3", "bf16", "bf16x3_attention"], default="fp32",
                     help="matrix instruction of the headline run (fp32 = the reference's arithmetic; the others are BASELINE configs[3] modes)")
     ap.add_argument("--no-mixed-precision", action="store_true", help="skip the extra split-bf16 (configs[3]) measurement")
     ap.add_argument("--opt", action="append", default=[], help="library tuning switch name=value (A/B runs; sdfa_debug_set_option is THREAD-LOCAL: "
@@ -169,12 +169,22 @@ def surface_block(sd, head, sr, dev):
         return {"frames_per_s": round(frames * reps / dt, 1), "ms_per_call": round(dt / reps * 1e3, 3), "frames_per_call": frames, "calls": reps}
 
     STAGES = ("conv23", "freq_lstm", "freq_proj", "gx0", "lstm0", "gx1", "lstm1", "attn_proj", "attn", "mlp", "pca", "share_map", "share_expand")
+    class Alt:
+        """Two different clips of one length, taken in turn: every call is a NEW signal (the one-entry signal -> z cache of
+        generate_animation -- the reference's feature cache, model.py:364-367 -- must not flatter these numbers)."""
+        def __init__(self, seconds):
+            self.clips, self.i = [synth.make_pcm(k, int(seconds * sr)) for k in (0, 1)], 0
+
+        def __call__(self):
+            self.i += 1
+            return self.clips[self.i & 1]
+
     for name, seconds, reps in (("1x10s", 10.0, 10), ("1x2s", 2.0, 20)):
-        pcm = synth.make_pcm(0, int(seconds * sr))
-        frames = len(model.generate_animation(pcm, "m1", 0, 0, want_inputs=False)[0])
-        r = run(lambda: model.generate_animation(pcm, "m1", 0, 0, want_inputs=False), frames, reps)
+        pcm = Alt(seconds)
+        frames = len(model.generate_animation(pcm(), "m1", 0, 0, want_inputs=False)[0])
+        r = run(lambda: model.generate_animation(pcm(), "m1", 0, 0, want_inputs=False), frames, reps)
         eng.profile(True)
-        model.generate_animation(pcm, "m1", 0, 0, want_inputs=False)
+        model.generate_animation(pcm(), "m1", 0, 0, want_inputs=False)
         torch.cuda.synchronize()
         st = {}
         for k in STAGES:
@@ -187,8 +197,8 @@ def surface_block(sd, head, sr, dev):
         r["stage_ms"] = st
         out[name] = r
         if name == "1x10s":
-            out["1x10s_with_inputs"] = run(lambda: model.generate_animation(pcm, "m1", 0, 0), frames, 5)
-            out["1x10s_ensembling_20ms"] = run(lambda: model.generate_animation(pcm, "m1", 0, 0, ensembling_ms=20, want_inputs=False), frames, 5)
+            out["1x10s_with_inputs"] = run(lambda: model.generate_animation(pcm(), "m1", 0, 0), frames, 5)
+            out["1x10s_ensembling_20ms"] = run(lambda: model.generate_animation(pcm(), "m1", 0, 0, ensembling_ms=20, want_inputs=False), frames, 5)
     clips = [synth.make_pcm(c, int(10.0 * sr)) for c in range(32)]
     frames = sum(len(r[0]) for r in model.generate_animation_batch(clips, "m1"))
     out["32x10s_batch"] = run(lambda: model.generate_animation_batch(clips, "m1"), frames, 3, warm=1)
@@ -540,8 +550,10 @@ def main():
         eng.set_precision("bf16x3")
         dt_m, st_m = timed(False)
         dt_ms = None if a.no_column_sharing else timed(True)[0]
+        eng.set_precision("bf16x3_attention")                    # configs[3] literally: only the attention stage on (split-)bf16 MFMA
+        dt_a, st_a = timed(False)
         eng.set_precision("fp32")
-        mixed = (dt_m, st_m, dt_ms)
+        mixed = (dt_m, st_m, dt_ms, dt_a, st_a)
     # ---- PCIe-inclusive twin (SURVEY 8(d) "report both"): the same K steps with the PCM arriving from pinned host memory inside
     # the step (H2D) and every output row delivered to pinned host memory inside the step (D2H, 359 KB per frame): pieces of
     # `chunk` frames, piece i's copy on a copy stream under piece i+1's kernels (Engine.forward_host), two alternating host
@@ -643,7 +655,8 @@ def main():
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"fp32": "f32", "bf16_attention": "f32 (attention projections bf16)",
-                                           "bf16x3": "split-bf16 x3 (fp32 accumulate)", "bf16": "bf16 (fp32 accumulate)"}[a.precision],
+                                           "bf16x3": "split-bf16 x3 (fp32 accumulate)", "bf16": "bf16 (fp32 accumulate)",
+                                           "bf16x3_attention": "f32 (attention projections split-bf16 x3)"}[a.precision],
             "data": "synthetic",
             "config": {"workload": (f"batch={C} x {a.seconds:g} s@{sr} Hz synthetic PCM per GPU -> {a.head} (BASELINE configs[1])"
                                     if not a.ragged_seconds else
@@ -712,7 +725,7 @@ def main():
                 "distinct_column_fraction_last_chunk": round(distinct / (64.0 * last), 4),
                 "stage_ms_per_step": {k: round(v, 3) for k, v in st_s.items()}}
         if mixed is not None:
-            dt_m, st_m, dt_ms = mixed
+            dt_m, st_m, dt_ms, dt_a, st_a = mixed
             res["mixed_precision"] = {
                 "note": "BASELINE configs[3]: same workload with the frequency LSTM and every GEMM on split-bf16 MFMA (operands as "
                         "hi+lo bf16, three v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate/state/activations; front end, conv "
@@ -720,7 +733,11 @@ def main():
                 "mode": "bf16x3", "value": round(F_all * a.steps / dt_m, 1), "unit": "frames/s",
                 "ms_per_step": round(dt_m / a.steps * 1e3, 3),
                 "with_column_sharing": None if dt_ms is None else round(F_all * a.steps / dt_ms, 1),
-                "stage_ms_per_step": {k: round(v, 3) for k, v in st_m.items()}}
+                "stage_ms_per_step": {k: round(v, 3) for k, v in st_m.items()},
+                "bf16x3_attention": {"note": "configs[3] as worded -- 'bf16 attention with MFMA, fp32 mel front end': ONLY the attention stage "
+                                             "(key / query projections, query conv) on v_mfma_f32_32x32x16_bf16 with split-bf16 operands, the rest exact fp32",
+                                     "value": round(F_all * a.steps / dt_a, 1), "unit": "frames/s", "ms_per_step": round(dt_a / a.steps * 1e3, 3),
+                                     "attn_proj_ms_per_step": round(st_a.get("attn_proj", 0.0), 3), "attn_proj_ms_per_step_fp32": round(stages.get("attn_proj", 0.0), 3)}}
         if world == 1 and not a.no_cpu_baseline:
             try:
                 cb, gpu_err = cpu_baseline(sr, a.cpu_sample_seconds, eng, sd, a.head)
@@ -728,6 +745,7 @@ def main():
                 res["max_abs_dgrad_err_vs_cpu_ref"], res["tslist_bit_exact"] = gpu_err(a.precision)
                 if mixed is not None:
                     res["mixed_precision"]["max_abs_dgrad_err_vs_cpu_ref"] = gpu_err("bf16x3")[0]
+                    res["mixed_precision"]["bf16x3_attention"]["max_abs_dgrad_err_vs_cpu_ref"] = gpu_err("bf16x3_attention")[0]
             except Exception as e:      # the GPU measurement above stands on its own; say what went wrong with the CPU leg
                 res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": None, "nproc": int(os.cpu_count() or 0), "kind": "port",
                                        "sample": f"failed: {e!r}"}

@@ -134,11 +134,15 @@ int64_t     sdfa_model_coef_dim(const sdfa_model *m);         /* 265 (85 scale |
  *                             split-bf16: operands as hi + lo bf16 (16 significand bits), three
  *                             v_mfma_f32_32x32x16_bf16 per product
  *   SDFA_PREC_BF16            the same kernels on plain bf16 operands (8 bits) -- outside the 1e-4 budget,
- *                             kept as the far end of the sweep                                                      */
+ *                             kept as the far end of the sweep
+ *   SDFA_PREC_BF16X3_ATTENTION  configs[3]'s wording with a passing point: the attention stage alone (key / query projections,
+ *                             query conv) on bf16 MFMA with split-bf16 operands, everything else fp32 -- "bf16 attention with
+ *                             MFMA" inside the 1e-4 budget (plain bf16 operands there, SDFA_PREC_BF16_ATTENTION, are not)      */
 #define SDFA_PREC_FP32 0
 #define SDFA_PREC_BF16_ATTENTION 1
 #define SDFA_PREC_BF16X3 2
 #define SDFA_PREC_BF16 3
+#define SDFA_PREC_BF16X3_ATTENTION 4
 int         sdfa_model_set_precision(sdfa_model *m, int mode);
 int         sdfa_model_precision(const sdfa_model *m);
 
@@ -274,6 +278,8 @@ int sdfa_ensemble_mean(const float *d_a, const float *d_b, int64_t n, float *d_o
  *                      stores + agent-scope release; bit 1 = agent-scope acquire + plain loads (the always-valid form, slower);
  *                      bit 2 (tests only) = the second workgroup of every pair never publishes, so every wait of the first expires
  *   "time_lstm_timeout_us" bound of one such wait in microseconds (0 = the default, 200,000)
+ *   "share_gx0_off"    1 = sdfa_encoder_forward_shared expands the frequency projection to all columns before the layer-0 BiLSTM input
+ *                      projection (rounds 2-3) instead of projecting the distinct columns and letting the recurrence read them through the map
  *   "pca_unfused"      1 = the dgrad PCA expansion as two generic GEMM launches with the scatter epilogue (round-1 form)
  *   "conv_unfused"     1 = conv1_pool_kernel + conv23_kernel instead of the fused conv123_kernel (what the debug taps use)   */
 int sdfa_debug_set_option(const char *name, int value);

@@ -741,7 +741,9 @@ thread_local int g_sdfa_pca_lds = 0;
 thread_local int g_sdfa_time_lstm_split = 0;
 thread_local int g_sdfa_time_lstm_handoff = 0;
 thread_local int g_sdfa_time_lstm_timeout_us = 0;
+thread_local int g_sdfa_share_gx0_off = 0;
 int sdfa_debug_set_option(const char *name, int value) {
+    if (name && !strcmp(name, "share_gx0_off")) { g_sdfa_share_gx0_off = value; return SDFA_OK; }
     if (name && !strcmp(name, "time_lstm_timeout_us")) { g_sdfa_time_lstm_timeout_us = value; return SDFA_OK; }
     if (name && !strcmp(name, "time_lstm_handoff")) { g_sdfa_time_lstm_handoff = value; return SDFA_OK; }
     if (name && !strcmp(name, "time_lstm_split")) { g_sdfa_time_lstm_split = value; return SDFA_OK; }
@@ -797,6 +799,7 @@ enum { STAGE_BODY = 0, STAGE_ATTENTION = 1, STAGE_REGRESSOR = 2 };
 static int stage_terms(const sdfa_model *m, int stage) {
     switch (m->precision) {
     case SDFA_PREC_BF16_ATTENTION: return stage == STAGE_ATTENTION ? 1 : 0;
+    case SDFA_PREC_BF16X3_ATTENTION: return stage == STAGE_ATTENTION ? 3 : 0;
     case SDFA_PREC_BF16X3: return 3;
     case SDFA_PREC_BF16: return 1;
     default: return 0;
@@ -805,7 +808,7 @@ static int stage_terms(const sdfa_model *m, int stage) {
 
 int sdfa_model_set_precision(sdfa_model *m, int mode) {
     if (!m) return fail(SDFA_EINVAL, "null model");
-    if (mode < SDFA_PREC_FP32 || mode > SDFA_PREC_BF16) return fail(SDFA_EINVAL, "unknown precision mode %d", mode);
+    if (mode < SDFA_PREC_FP32 || mode > SDFA_PREC_BF16X3_ATTENTION) return fail(SDFA_EINVAL, "unknown precision mode %d", mode);
     m->precision = mode;
     return SDFA_OK;
 }
@@ -929,24 +932,33 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
         g.reserve_cus = m->reserved_cus.load();
         if (share) { g.D = ws + w.ZU; g.q_limit = d_ulimit; }
         pf.begin("freq_proj"); HIP_TRY(sdfa_launch_gemm(g, s)); pf.end();
-        if (share) {   // scatter every distinct column's 256 features to all the (t, n) columns that contain it
+        // Column sharing reaches one stage further (round 4): the layer-0 input projection of the BiLSTM (rnn.py:20-21) is per column
+        // too, so it runs over the DISTINCT columns and the layer-0 recurrence reads it through the share map -- the 256-feature
+        // projection is then never expanded at all.  (fp32 kernels; the bf16 recurrences and the debug taps, which read the
+        // expanded projection, keep the expand-then-project order.)  The projected columns live in the frequency LSTM's hidden-state
+        // region, which is dead once the projection above has read it.
+        const bool share_gx0 = share && !m->keep && stage_terms(m, STAGE_BODY) == 0 && !g_sdfa_share_gx0_off;
+        if (share && !share_gx0) {   // scatter every distinct column's 256 features to all the (t, n) columns that contain it
             pf.begin("share_expand"); HIP_TRY(sdfa_launch_expand_cols(ws + w.ZU, col_to_u, ws + w.Z, 64, Mc, s)); pf.end();
         }
 
-        const float *xin = ws + w.Z;
+        const float *xin = share_gx0 ? ws + w.ZU : ws + w.Z;
         float *hout[2] = {ws + w.H0, ws + w.H1};
         const char *gxn[2] = {"gx0", "gx1"}, *lsn[2] = {"lstm0", "lstm1"};
         for (int l = 0; l < 2; ++l) {
+            const bool mapped = share_gx0 && l == 0;
+            float *gx = mapped ? ws + w.HF : ws + w.GX;
             GemmArgs gi{};
-            gi.P = m->gx_w[l]; gi.Q = xin; gi.D = ws + w.GX;
+            gi.P = m->gx_w[l]; gi.Q = xin; gi.D = gx;
             gi.ldp = 2048; gi.ldq = Mc; gi.ldd = Mc; gi.Ppad = 2048; gi.Qpad = Mc; gi.Pstore = 2048; gi.Qreal = Mc;
             gi.K = l == 0 ? 256 : 512; gi.seg_k = gi.K; gi.act = ACT_NONE; gi.out_mode = OUT_K4;
             gi.terms = stage_terms(m, STAGE_BODY);
             gi.reserve_cus = m->reserved_cus.load();
+            if (mapped) gi.q_limit = d_ulimit;
             pf.begin(gxn[l]); HIP_TRY(sdfa_launch_gemm(gi, s)); pf.end();
-            TimeLstmArgs ta{ws + w.GX, m->tl_w[l], hout[l], Nc, Mc, m->tl_wb[l], stage_terms(m, STAGE_BODY),
+            TimeLstmArgs ta{gx, m->tl_w[l], hout[l], Nc, Mc, m->tl_wb[l], stage_terms(m, STAGE_BODY),
                             reinterpret_cast<unsigned *>(ws + w.CT) + CT_FLAGS, CT_WORDS - CT_FLAGS, m->tl_w16[l],
-                            reinterpret_cast<unsigned *>(ws), m->reserved_cus.load()};
+                            reinterpret_cast<unsigned *>(ws), m->reserved_cus.load(), mapped ? col_to_u : nullptr};
             pf.begin(lsn[l]); HIP_TRY(sdfa_launch_time_lstm(ta, s)); pf.end();
             xin = hout[l];
         }

@@ -127,6 +127,7 @@ struct TimeLstmArgs {
     const float *W16;    // time_lstm_split16_kernel: per direction float4 [16 K16][4 g][1024 rows] (api.cpp pack_rec_16x16x4); null = not packed
     unsigned *status;    // word 0 of the workspace's status block: counts the waits of the small-batch form that expired (null = not counted)
     int reserve_cus;     // the small-batch form is used while its grid fits (CUs - reserve_cus)
+    const int32_t *col_map;   // column sharing, layer 0: GX holds the DISTINCT columns; column (t, n) reads GX column col_map[t * Nc + n] (null = its own)
 };
 hipError_t sdfa_launch_time_lstm(const TimeLstmArgs &a, hipStream_t s);
 

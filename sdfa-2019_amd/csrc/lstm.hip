@@ -696,7 +696,11 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_bf16_kernel(FreqLstmArgs a) 
 // ----------------------------------------------------------------------------------------- time LSTM
 // NT = 32-frame column tiles per workgroup: 2 (64 frames, the throughput shape) or 1 (32 frames: twice the
 // workgroups, used when a chunk would otherwise leave CUs idle).
-template <int NT>
+// MAP (column sharing, layer 0): GX holds the input projection of the DISTINCT columns only (a.col_map[t * Nc + n] = its column), so a
+// lane's 32 quads of a step come from column u = col_map[...] instead of t * Nc + n.  Within a clip the frames of a tile map to one
+// run of consecutive u (they all shift by the same 12 frames / 25 hops), so the requests stay coalesced; u is fetched one step
+// further ahead than the quads it addresses, behind that step's requests, and costs no wait of its own.
+template <int NT, bool MAP = false>
 __device__ __forceinline__ void time_lstm_body(const TimeLstmArgs &a) {
     extern __shared__ float4 sHt[];   // [2][64 k-quads][32*NT sequences]
     constexpr int BT = 32 * NT;
@@ -722,8 +726,15 @@ __device__ __forceinline__ void time_lstm_body(const TimeLstmArgs &a) {
     // per-lane base + wave-uniform offsets (scalar registers) instead of 32 lane addresses the optimiser would hoist out of
     // the step loop and spill (the kernel sits at the 256-register limit)
     const float4 *__restrict__ GXl = GX + (int64_t)(dir * 256 + wave * 32 + h) * a.Mc + n0 + l31;
+    const float4 *__restrict__ GXr = GX + (int64_t)(dir * 256 + wave * 32 + h) * a.Mc;                    // MAP: row base, the column comes from the map
+    const int32_t *__restrict__ cmap = MAP ? a.col_map + n0 + l31 : nullptr;
+    int ucol[NT];                                                                                        // MAP: columns of the NEXT request
+    if (MAP) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) ucol[j] = cmap[(int64_t)(dir ? 63 : 0) * a.Nc + j * 32];
+    }
     float4 *__restrict__ Hl = H + (int64_t)(dir * 64 + wave * 8 + h) * a.Mc + n0 + l31;
-#define TL_GX(t_, gt, g, j) GXl[(int64_t)((gt) * 8 + 2 * (g)) * a.Mc + (int64_t)(t_) * a.Nc + (j) * 32]
+#define TL_GX(t_, gt, g, j) (MAP ? GXr[(int64_t)((gt) * 8 + 2 * (g)) * a.Mc + ucol[j]] : GXl[(int64_t)((gt) * 8 + 2 * (g)) * a.Mc + (int64_t)(t_) * a.Nc + (j) * 32])
 #pragma unroll
     for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
@@ -749,6 +760,10 @@ __device__ __forceinline__ void time_lstm_body(const TimeLstmArgs &a) {
 #define TL_LOAD(kb, W0, W1, W2, W3) { const unsigned so = (unsigned)(kb) * (2048 * 16); W0 = TL_W1(so, 0); W1 = TL_W1(so, 1); W2 = TL_W1(so, 2); W3 = TL_W1(so, 3); }
     float4 wn0, wn1, wn2, wn3;
     TL_LOAD(0, wn0, wn1, wn2, wn3)
+    if (MAP) {      // columns of step 1's request (behind step 0's quads, in front of the first weights)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) ucol[j] = cmap[(int64_t)(dir ? 62 : 1) * a.Nc + j * 32];
+    }
     for (int s = 0; s < 64; ++s) {
         const int t = dir ? 63 - s : s;
         const int tn = dir ? t - 1 : t + 1;
@@ -818,6 +833,11 @@ __device__ __forceinline__ void time_lstm_body(const TimeLstmArgs &a) {
                     }
                 }
             }
+        if (MAP && s + 2 < 64) {   // behind this step's requests: the columns of the step after next
+            const int t2 = dir ? t - 2 : t + 2;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) ucol[j] = cmap[(int64_t)t2 * a.Nc + j * 32];
+        }
         __syncthreads();   // h_s complete in sHn before anyone reads it; sHc free for step s+1's writes
     }
 #undef TL_GX
@@ -825,16 +845,17 @@ __device__ __forceinline__ void time_lstm_body(const TimeLstmArgs &a) {
 #undef TL_W1
 }
 
-template <int NT>
-__global__ __launch_bounds__(512, 2) void time_lstm_kernel(TimeLstmArgs a) { time_lstm_body<NT>(a); }
+template <int NT, bool MAP = false>
+__global__ __launch_bounds__(512, 2) void time_lstm_kernel(TimeLstmArgs a) { time_lstm_body<NT, MAP>(a); }
 
 // The same recurrence as a REPAIR pass behind a launch of the cooperating-workgroup kernels below: every workgroup reads that launch's
 // time-out word and exits at once unless a workgroup of it gave up waiting for its partner -- in which case this pass, which needs no
 // co-residency and cannot time out, recomputes the layer's H rows from the (untouched) input projections.  So a time-out costs time,
 // never a wrong row, and nothing has to travel to the host to decide it.  (3 - 4 us per layer when there is nothing to repair.)
+template <bool MAP>
 __global__ __launch_bounds__(512, 2) void time_lstm_repair_kernel(TimeLstmArgs a, const unsigned *timed_out) {
     if (__hip_atomic_load(timed_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
-    time_lstm_body<1>(a);
+    time_lstm_body<1, MAP>(a);
 }
 
 // ---------------------------------------------------------------------------- time LSTM, small batches
@@ -894,7 +915,7 @@ __device__ __forceinline__ bool split_wait(const unsigned *pf, unsigned want, co
     }
 }
 
-template <int G>
+template <int G, bool MAP = false>
 __global__ __launch_bounds__(512 / G) void time_lstm_split_kernel(TimeLstmArgs a, SplitCtl ctl) {
     unsigned *const flags = ctl.flags;
     const int mode = ctl.mode;
@@ -915,13 +936,17 @@ __global__ __launch_bounds__(512 / G) void time_lstm_split_kernel(TimeLstmArgs a
     for (int r = 0; r < 16; ++r) c[r] = 0.f;
     f32x16 acc[4][1];
     const float4 *__restrict__ GXl = GX + (int64_t)(dir * 256 + hb * 32 + h) * a.Mc + n0 + l31;
-#define TS_GX(t_, gt, g) GXl[(int64_t)((gt) * 8 + 2 * (g)) * a.Mc + (int64_t)(t_) * a.Nc]
+    const float4 *__restrict__ GXr = GX + (int64_t)(dir * 256 + hb * 32 + h) * a.Mc;      // MAP (column sharing): see time_lstm_body
+    const int32_t *__restrict__ cmap = MAP ? a.col_map + n0 + l31 : nullptr;
+    int ucol = MAP ? cmap[(int64_t)(dir ? 63 : 0) * a.Nc] : 0;
+#define TS_GX(t_, gt, g) (MAP ? GXr[(int64_t)((gt) * 8 + 2 * (g)) * a.Mc + ucol] : GXl[(int64_t)((gt) * 8 + 2 * (g)) * a.Mc + (int64_t)(t_) * a.Nc])
 #define TS_GX_ALL(t_)                                                                                               \
     _Pragma("unroll") for (int gt = 0; gt < 4; ++gt) _Pragma("unroll") for (int g = 0; g < 4; ++g) {                  \
         const float4 v = TS_GX(t_, gt, g);                                                                          \
         acc[gt][0][4 * g + 0] = v.x; acc[gt][0][4 * g + 1] = v.y; acc[gt][0][4 * g + 2] = v.z; acc[gt][0][4 * g + 3] = v.w; \
     }
     TS_GX_ALL(dir ? 63 : 0)
+    if (MAP) ucol = cmap[(int64_t)(dir ? 62 : 1) * a.Nc];
 
     // H rows of this direction as a buffer: write-through stores of the own slice, sc1 loads of the partners' slices
     const unsigned long long hptr = (unsigned long long)(reinterpret_cast<float4 *>(a.H) + (int64_t)dir * 64 * a.Mc);
@@ -1018,6 +1043,7 @@ __global__ __launch_bounds__(512 / G) void time_lstm_split_kernel(TimeLstmArgs a
             }
             // the next step's input projection seeds the accumulators (requested now: its HBM latency runs under the hand-off)
             TS_GX_ALL(tn)
+            if (MAP && s + 2 < 64) ucol = cmap[(int64_t)(dir ? t - 2 : t + 2) * a.Nc];
             // consume: wave 0 polls the partners' flags (lanes 0..G-2), bounded
             if (wave == 0 && !dead) {
                 const int pl = lane < G - 1 ? lane : 0;
@@ -1087,6 +1113,7 @@ __device__ __forceinline__ void lstm_cell_4(const f32x4v &ai, const f32x4v &af, 
     hq = make_float4(hv[0].x, hv[0].y, hv[1].x, hv[1].y);
 }
 
+template <bool MAP = false>
 __global__ __launch_bounds__(256) void time_lstm_split16_kernel(TimeLstmArgs a, SplitCtl ctl) {
     unsigned *const flags = ctl.flags;
     const int mode = ctl.mode;
@@ -1104,12 +1131,16 @@ __global__ __launch_bounds__(256) void time_lstm_split16_kernel(TimeLstmArgs a, 
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) c[hh] = f32x4v{0.f, 0.f, 0.f, 0.f};
     const float4 *__restrict__ GXl = reinterpret_cast<const float4 *>(a.GX) + (int64_t)(dir * 256 + hb * 32 + lg) * a.Mc + n0 + f;
+    const float4 *__restrict__ GXr = reinterpret_cast<const float4 *>(a.GX) + (int64_t)(dir * 256 + hb * 32 + lg) * a.Mc;   // MAP (column sharing): see time_lstm_body
+    const int32_t *__restrict__ cmap = MAP ? a.col_map + n0 + f : nullptr;
+    int ucol = MAP ? cmap[(int64_t)(dir ? 63 : 0) * a.Nc] : 0;
 #define T16_GX_ALL(t_)                                                                                              \
     _Pragma("unroll") for (int qg = 0; qg < 4; ++qg) _Pragma("unroll") for (int hh = 0; hh < 2; ++hh) {               \
-        const float4 v = GXl[(int64_t)(qg * 8 + 4 * hh) * a.Mc + (int64_t)(t_) * a.Nc];                            \
+        const float4 v = MAP ? GXr[(int64_t)(qg * 8 + 4 * hh) * a.Mc + ucol] : GXl[(int64_t)(qg * 8 + 4 * hh) * a.Mc + (int64_t)(t_) * a.Nc]; \
         acc[qg][hh] = f32x4v{v.x, v.y, v.z, v.w};                                                                   \
     }
     T16_GX_ALL(dir ? 63 : 0)
+    if (MAP) ucol = cmap[(int64_t)(dir ? 62 : 1) * a.Nc];
 
     const unsigned long long hptr = (unsigned long long)(reinterpret_cast<float4 *>(a.H) + (int64_t)dir * 64 * a.Mc);
     const unsigned long long huni = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(hptr >> 32)) << 32) |
@@ -1184,6 +1215,7 @@ __global__ __launch_bounds__(256) void time_lstm_split16_kernel(TimeLstmArgs a, 
                 if (!((mode & 4) && part == 1)) __hip_atomic_store(my_flag, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             T16_GX_ALL(tn)
+            if (MAP && s + 2 < 64) ucol = cmap[(int64_t)(dir ? t - 2 : t + 2) * a.Nc];
             if (wave == 0 && !dead) dead = split_wait(partner_flag, (unsigned)(s + 1), ctl, lane);
             if (mode & 2) {
                 if (wave == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -1410,15 +1442,15 @@ hipError_t sdfa_launch_freq_lstm(const FreqLstmArgs &a, hipStream_t s) {
     return a.col_limit ? launch_freq<true>(a, s) : launch_freq<false>(a, s);
 }
 
-template <int NT>
+template <int NT, bool MAP>
 static hipError_t launch_time(const TimeLstmArgs &a, hipStream_t s) {
     const size_t lds = 2 * 64 * 32 * NT * sizeof(float4);   // 128 KiB (NT 2) / 64 KiB (NT 1)
     {   // per launch: cheap, and correct for every device / thread the library is used from
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(time_lstm_kernel<NT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(time_lstm_kernel<NT, MAP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(time_lstm_kernel<NT>, dim3((unsigned)(a.Nc / (32 * NT) * 2)), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((time_lstm_kernel<NT, MAP>), dim3((unsigned)(a.Nc / (32 * NT) * 2)), dim3(512), lds, s, a);
     return hipGetLastError();
 }
 
@@ -1438,11 +1470,12 @@ extern thread_local int g_sdfa_time_lstm_handoff;   // api.cpp ("time_lstm_hando
 extern thread_local int g_sdfa_time_lstm_timeout_us; // api.cpp ("time_lstm_timeout_us"): bound of one wait for a partner workgroup
 
 // Behind every launch of a cooperating-workgroup kernel: the repair pass (exits at once unless that launch timed out).
+template <bool MAP>
 static hipError_t launch_time_repair(const TimeLstmArgs &a, hipStream_t s) {
     const size_t lds = 2 * 64 * 32 * sizeof(float4);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(time_lstm_repair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(time_lstm_repair_kernel<MAP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(time_lstm_repair_kernel, dim3((unsigned)(a.Nc / 32 * 2)), dim3(512), lds, s, a, a.flags);
+    hipLaunchKernelGGL(time_lstm_repair_kernel<MAP>, dim3((unsigned)(a.Nc / 32 * 2)), dim3(512), lds, s, a, a.flags);
     return hipGetLastError();
 }
 
@@ -1451,35 +1484,37 @@ static SplitCtl split_ctl(const TimeLstmArgs &a) {
     return SplitCtl{a.flags + 4, a.flags, a.status, (unsigned)std::min<long long>(us * 100, 0xffffffffll), g_sdfa_time_lstm_handoff};
 }
 
-template <int G>
+template <int G, bool MAP>
 static hipError_t launch_time_split(const TimeLstmArgs &a, hipStream_t s) {
     const size_t lds = 96 * 1024;      // 64 KiB used; 96 KiB requested so that two workgroups never share a CU (see the kernel)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(time_lstm_split_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(time_lstm_split_kernel<G, MAP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const unsigned grid = (unsigned)(a.Nc / 32 * 2 * G);
     // this launch's time-out word + flag words (one per workgroup), zeroed every launch: a block of its own, a multiple of 16 bytes
     e = hipMemsetAsync(a.flags, 0, ((size_t)grid + 4) * sizeof(unsigned), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(time_lstm_split_kernel<G>, dim3(grid), dim3(512 / G), lds, s, a, split_ctl(a));
+    hipLaunchKernelGGL((time_lstm_split_kernel<G, MAP>), dim3(grid), dim3(512 / G), lds, s, a, split_ctl(a));
     e = hipGetLastError();
-    return e != hipSuccess ? e : launch_time_repair(a, s);
+    return e != hipSuccess ? e : launch_time_repair<MAP>(a, s);
 }
 
+template <bool MAP>
 static hipError_t launch_time_split16(const TimeLstmArgs &a, hipStream_t s) {
     const size_t lds = 96 * 1024;      // 32 KiB used; 96 KiB requested: one workgroup per CU (hand-off form, see time_lstm_split_kernel)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(time_lstm_split16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(time_lstm_split16_kernel<MAP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const unsigned grid = (unsigned)(a.Nc / 16 * 2 * 2);
     e = hipMemsetAsync(a.flags, 0, ((size_t)grid + 4) * sizeof(unsigned), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(time_lstm_split16_kernel, dim3(grid), dim3(256), lds, s, a, split_ctl(a));
+    hipLaunchKernelGGL(time_lstm_split16_kernel<MAP>, dim3(grid), dim3(256), lds, s, a, split_ctl(a));
     e = hipGetLastError();
-    return e != hipSuccess ? e : launch_time_repair(a, s);
+    return e != hipSuccess ? e : launch_time_repair<MAP>(a, s);
 }
 
 extern thread_local int g_sdfa_time_lstm_split;   // api.cpp ("time_lstm_split" option): 0 = by size, 1 = never
 
-hipError_t sdfa_launch_time_lstm(const TimeLstmArgs &a, hipStream_t s) {
+template <bool MAP>
+static hipError_t launch_time_any(const TimeLstmArgs &a, hipStream_t s) {
     // 64-frame tiles while they fill the 256 CUs (one 8-wave workgroup per CU); otherwise 32-frame tiles
     const bool big = (a.Nc / 64) * 2 >= 256;
     if (!a.terms && a.flags && g_sdfa_time_lstm_split != 1) {
@@ -1495,14 +1530,18 @@ hipError_t sdfa_launch_time_lstm(const TimeLstmArgs &a, hipStream_t s) {
         // matrix work per step is the same; profiles/r03_time_lstm_split.txt.)
         const int G = (range_ok && wg1 * 2 <= cus) ? 2 : 0;
         // 16-frame tiles (time_lstm_split16_kernel) while even their grid -- twice the workgroups -- fits the CUs; option 16 / 32 force one
-        if (range_ok && a.W16 && g_sdfa_time_lstm_split != 32 && wg1 * 4 <= cus && a.flag_words >= wg1 * 4 + 4) return launch_time_split16(a, s);
+        if (range_ok && a.W16 && g_sdfa_time_lstm_split != 32 && wg1 * 4 <= cus && a.flag_words >= wg1 * 4 + 4) return launch_time_split16<MAP>(a, s);
         if (g_sdfa_time_lstm_split == 16) return hipErrorInvalidValue;      // asked for, not possible at this size
-        if (G == 2) return launch_time_split<2>(a, s);
+        if (G == 2) return launch_time_split<2, MAP>(a, s);
     }
     if (a.terms) {
-        if (!a.Wb) return hipErrorInvalidValue;
+        if (!a.Wb || MAP) return hipErrorInvalidValue;      // the bf16 recurrences read un-shared input projections (api.cpp expands first)
         if (a.terms == 1) return big ? launch_time_bf16<2, 1>(a, s) : launch_time_bf16<1, 1>(a, s);
         return big ? launch_time_bf16<2, 3>(a, s) : launch_time_bf16<1, 3>(a, s);
     }
-    return big ? launch_time<2>(a, s) : launch_time<1>(a, s);
+    return big ? launch_time<2, MAP>(a, s) : launch_time<1, MAP>(a, s);
+}
+
+hipError_t sdfa_launch_time_lstm(const TimeLstmArgs &a, hipStream_t s) {
+    return a.col_map ? launch_time_any<true>(a, s) : launch_time_any<false>(a, s);
 }

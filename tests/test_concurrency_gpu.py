@@ -70,6 +70,7 @@ def test_product_path_reports_a_repair_and_returns_the_right_rows(synth_sd):
         _lib.set_option("time_lstm_handoff", 4)
         with warnings.catch_warnings(record=True) as w:
             warnings.simplefilter("always")
+            model._signal_cache = None                                     # a fresh call: the encoder must run (same signal = cached z otherwise)
             ts2, got, _ = model.generate_animation(pcm, "m1", 0, 0, want_inputs=False)
             eng.check_pending(block=True)
         assert ts2 == ts and np.array_equal(got, want)

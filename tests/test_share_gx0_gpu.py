@@ -1,0 +1,55 @@
+"""Round 4: column sharing one stage further -- the layer-0 BiLSTM input projection (speech_anime/layers/rnn.py:20-21 is per column at
+layer 0) runs over the DISTINCT columns and every time-LSTM kernel form reads it through the share map.  Bitwise: against the
+expand-then-project order of rounds 2-3 ("share_gx0_off") and against the un-shared encoder, at sizes that take each kernel."""
+import numpy as np
+import pytest
+import torch
+
+from sdfa_amd import synth, _lib
+from sdfa_amd.engine import Engine
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seconds,max_frames", [
+    ([2.0], 8192),                        # 156 frames: time_lstm_split16_kernel
+    ([10.0, 3.1], 8192),                  # 844 frames, two clips: split16, a tile that crosses a clip boundary
+    ([10.0, 10.0, 4.0], 8192),            # 1,528 frames: time_lstm_split_kernel (32-frame tiles)
+    ([10.0] * 5 + [1.3], 8192),           # 3,290 frames: time_lstm_kernel<1>
+    ([10.0] * 14, 16384),                 # 8,904 frames in one chunk: time_lstm_kernel<2>
+    ([10.0] * 4, 1024),                   # several workspace chunks per call
+])
+def test_shared_gx0_is_bitwise(synth_sd, seconds, max_frames):
+    sr = 16000
+    e = Engine(synth_sd["dgrad"], max_frames=max_frames)
+    clips = [synth.make_pcm(70 + i, int(s * sr), "speechlike" if i % 2 else "uniform") for i, s in enumerate(seconds)]
+    feat, _, counts = e.mel_frontend(clips, sr)
+    fc, fs, hop = e.last_frame_table
+    z0, a0 = e.encoder(feat)                                             # every column of every frame
+    try:
+        _lib.set_option("share_gx0_off", 1)
+        z1, a1 = e.encoder(feat, frame_clip=fc, frame_start=fs, hop=hop)  # rounds 2-3: expand the projection, then project all columns
+        _lib.set_option("share_gx0_off", 0)
+        z2, a2 = e.encoder(feat, frame_clip=fc, frame_start=fs, hop=hop)  # round 4: project the distinct columns, recurrence reads through the map
+    finally:
+        _lib.set_option("share_gx0_off", 0)
+    assert torch.equal(z0, z1) and torch.equal(a0, a1)
+    assert torch.equal(z0, z2) and torch.equal(a0, a2)
+    assert e.time_lstm_repairs() == 0
+
+
+def test_shared_gx0_with_forced_repair(synth_sd):
+    """The repair pass of the cooperating-workgroup kernels reads the mapped projection too."""
+    sr = 16000
+    e = Engine(synth_sd["dgrad"])
+    feat, _, _ = e.mel_frontend([synth.make_pcm(5, 10 * sr)], sr)
+    fc, fs, hop = e.last_frame_table
+    z0, a0 = e.encoder(feat)
+    try:
+        _lib.set_option("time_lstm_timeout_us", 2000)
+        _lib.set_option("time_lstm_handoff", 4)
+        z1, a1 = e.encoder(feat, frame_clip=fc, frame_start=fs, hop=hop)
+    finally:
+        _lib.set_option("time_lstm_handoff", 0)
+        _lib.set_option("time_lstm_timeout_us", 0)
+    assert e.time_lstm_repairs() > 0 and torch.equal(z0, z1) and torch.equal(a0, a1)
