@@ -499,7 +499,12 @@ def main():
         if dist_on:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         # per-kernel device times: HIP events recorded by the library on the launch stream inside the timed region
-        st = {k: eng.profile_ms(k) / a.steps for k in STAGES + (("share_map", "share_expand") if share else ())}
+        st = {k: eng.profile_ms(k) / a.steps for k in STAGES + (("share_map",) if share else ())}
+        if share:
+            try:        # only when the frequency projection is expanded before the layer-0 input projection ("share_gx0_off", bf16 modes)
+                st["share_expand"] = eng.profile_ms("share_expand") / a.steps
+            except Exception:
+                pass
         eng.profile(False)
         return float(tmax.item()), st
 

@@ -278,6 +278,8 @@ int sdfa_ensemble_mean(const float *d_a, const float *d_b, int64_t n, float *d_o
  *                      stores + agent-scope release; bit 1 = agent-scope acquire + plain loads (the always-valid form, slower);
  *                      bit 2 (tests only) = the second workgroup of every pair never publishes, so every wait of the first expires
  *   "time_lstm_timeout_us" bound of one such wait in microseconds (0 = the default, 200,000)
+ *   "frontend_t_major" 1 = sdfa_mel_frontend_gather numbers its distinct STFT columns time-step-major (rounds 2-3) instead of clip by clip,
+ *                      hop by hop (same features, bit for bit; only the order of the mel table's rows differs)
  *   "share_gx0_off"    1 = sdfa_encoder_forward_shared expands the frequency projection to all columns before the layer-0 BiLSTM input
  *                      projection (rounds 2-3) instead of projecting the distinct columns and letting the recurrence read them through the map
  *   "pca_unfused"      1 = the dgrad PCA expansion as two generic GEMM launches with the scatter epilogue (round-1 form)

@@ -19,6 +19,7 @@
 namespace {
 
 thread_local std::string g_err;
+thread_local int g_sdfa_frontend_t_major = 0;   // "frontend_t_major" option: the front end's distinct columns numbered time-step-major (rounds 2-3)
 
 int fail(int code, const char *fmt, ...) {
     char buf[512];
@@ -409,6 +410,7 @@ int sdfa_mel_frontend_gather(const float *d_pcm, const int64_t *d_clip_off, cons
     ShareArgs sa{};
     sa.frame_clip = d_frame_clip; sa.frame_start = d_frame_start; sa.hop = c.hop;
     sa.t_lo = 1; sa.t_hi = 63;          // every window column but the first (raw first sample) is a function of (clip, position)
+    sa.frame_major = g_sdfa_frontend_t_major ? 0 : 1;      // distinct columns numbered clip by clip, hop by hop (share.hip: scan_pos)
     sa.N = n_frames; sa.Nc = w.Nc; sa.Mc = w.Mc;
     sa.counts = reinterpret_cast<int64_t *>(sh);
     sa.prev = sh + 16; sa.shift = sa.prev + w.Nc;
@@ -744,6 +746,7 @@ thread_local int g_sdfa_time_lstm_timeout_us = 0;
 thread_local int g_sdfa_share_gx0_off = 0;
 int sdfa_debug_set_option(const char *name, int value) {
     if (name && !strcmp(name, "share_gx0_off")) { g_sdfa_share_gx0_off = value; return SDFA_OK; }
+    if (name && !strcmp(name, "frontend_t_major")) { g_sdfa_frontend_t_major = value; return SDFA_OK; }
     if (name && !strcmp(name, "time_lstm_timeout_us")) { g_sdfa_time_lstm_timeout_us = value; return SDFA_OK; }
     if (name && !strcmp(name, "time_lstm_handoff")) { g_sdfa_time_lstm_handoff = value; return SDFA_OK; }
     if (name && !strcmp(name, "time_lstm_split")) { g_sdfa_time_lstm_split = value; return SDFA_OK; }

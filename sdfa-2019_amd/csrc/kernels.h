@@ -161,6 +161,7 @@ struct ShareArgs {
     const int64_t *frame_start;  // [N] window start sample inside its clip
     int hop;
     int t_lo, t_hi;              // window columns t_lo..t_hi are shareable between hop-aligned frames of a clip
+    int frame_major;             // numbering order of the distinct columns: 0 = time-step-major (t, then n), 1 = frame-major (n, then t)
     int64_t N, Nc, Mc;
     int32_t *prev, *shift;       // [Nc]
     int32_t *owner, *flag, *uid; // [Mc]

@@ -36,13 +36,20 @@ __global__ void share_prev_kernel(ShareArgs a) {
     a.shift[n] = shift;
 }
 
-// owner[m] = canonical column (index m' = t'*Nc + n') holding the same feature vector; flag[m] = 1 if m is its own owner
+// Position of column m = t*Nc + n in the numbering scan.  Time-step-major (the encoder's map: consecutive distinct columns are
+// consecutive FRAMES at one time step, which is what the time-LSTM kernels read through the map) or frame-major (the front end's map:
+// consecutive distinct columns are consecutive HOPS of one clip, so that mel_columns_kernel walks the PCM front to back and a frame's
+// table rows are three contiguous runs).  Mc = 64 * Nc either way.
+__device__ __forceinline__ int64_t scan_pos(const ShareArgs &a, int64_t m) { return a.frame_major ? (m % a.Nc) * 64 + m / a.Nc : m; }
+__device__ __forceinline__ int64_t scan_col(const ShareArgs &a, int64_t i) { return a.frame_major ? (i & 63) * a.Nc + (i >> 6) : i; }
+
+// owner[m] = canonical column (index m' = t'*Nc + n') holding the same feature vector; flag[scan_pos(m)] = 1 if m is its own owner
 __global__ void share_owner_kernel(ShareArgs a) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= a.Mc) return;
     int64_t n = m % a.Nc;
     int t = (int)(m / a.Nc);
-    if (n >= a.N) { a.owner[m] = -1; a.flag[m] = 0; return; }     // padding frame: never computed
+    if (n >= a.N) { a.owner[m] = -1; a.flag[scan_pos(a, m)] = 0; return; }     // padding frame: never computed
     while (t >= a.t_lo && t <= a.t_hi) {
         const int p = a.prev[n];
         if (p < 0) break;
@@ -52,7 +59,7 @@ __global__ void share_owner_kernel(ShareArgs a) {
     }
     const int64_t o = (int64_t)t * a.Nc + n;
     a.owner[m] = (int)o;
-    a.flag[m] = o == m ? 1 : 0;
+    a.flag[scan_pos(a, m)] = o == m ? 1 : 0;
 }
 
 // Exclusive scan of flag[0..Mc) -> uid in three small launches: per-tile (1024 columns) scan + tile sums, a
@@ -103,7 +110,8 @@ __global__ __launch_bounds__(1024) void share_scan_fix_kernel(ShareArgs a) {
     if (i < a.Mc) {
         const int u = a.uid[i] + a.tile_sum[blockIdx.x];
         a.uid[i] = u;
-        if (a.flag[i]) a.col_src[u] = (int)((i % a.Nc) * 64 + i / a.Nc);     // row of audio_feat viewed as [N*64][384]
+        const int64_t m = scan_col(a, i);
+        if (a.flag[i]) a.col_src[u] = (int)((m % a.Nc) * 64 + m / a.Nc);     // row of audio_feat viewed as [N*64][384]
     }
     if (i >= mu && i < pad) a.col_src[i] = -1;        // padding columns read zeros (disjoint from the writes above: u < mu)
 }
@@ -112,7 +120,7 @@ __global__ void share_assign_kernel(ShareArgs a) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= a.Mc) return;
     const int o = a.owner[m];
-    a.col_to_u[m] = o >= 0 ? a.uid[o] : 0;
+    a.col_to_u[m] = o >= 0 ? a.uid[scan_pos(a, o)] : 0;
 }
 
 // Z[q][m] = Zu[q][col_to_u[m]]  (K4 quads, ld = Mc on both sides)

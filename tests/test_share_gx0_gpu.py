@@ -53,3 +53,24 @@ def test_shared_gx0_with_forced_repair(synth_sd):
         _lib.set_option("time_lstm_handoff", 0)
         _lib.set_option("time_lstm_timeout_us", 0)
     assert e.time_lstm_repairs() > 0 and torch.equal(z0, z1) and torch.equal(a0, a1)
+
+
+@pytest.mark.parametrize("sr", [8000, 16000])
+def test_frontend_column_numbering_does_not_change_a_bit(sr):
+    """Round 4: the spectral-gather front end numbers its distinct STFT columns clip by clip, hop by hop (the PCM is then walked front
+    to back and a frame's table rows are contiguous runs) instead of time-step-major.  A column's features depend on its samples
+    only, so the features are the same bits in either order -- and the same as the one-FFT-per-window-column kernel's to rounding."""
+    from sdfa_amd.engine import FrontendOnly
+    fe = FrontendOnly()
+    clips = [synth.make_pcm(3, int(2.7 * sr), "speechlike"), synth.make_pcm(4, int(0.9 * sr)), np.zeros(sr, np.float32), synth.make_pcm(5, 10 * sr)]
+    try:
+        _lib.set_option("frontend_t_major", 1)
+        a, ts_a, _ = fe.mel_frontend(clips, sr)
+        a = a.clone()
+        _lib.set_option("frontend_t_major", 0)
+        b, ts_b, _ = fe.mel_frontend(clips, sr)
+    finally:
+        _lib.set_option("frontend_t_major", 0)
+    assert ts_a == ts_b and torch.equal(a, b)
+    c, _, _ = fe.mel_frontend(clips, sr, gather=False)
+    assert float((b - c).abs().max()) <= 5e-5
