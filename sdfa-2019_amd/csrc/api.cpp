@@ -16,10 +16,12 @@
 #include <string>
 #include <vector>
 
+thread_local int g_sdfa_mel_fft_radix4 = 0;     // "mel_fft_radix4" option (read by frontend.hip)
+thread_local int g_sdfa_frontend_t_major = 0;   // "frontend_t_major" option: the front end's distinct columns numbered time-step-major (rounds 2-3)
+
 namespace {
 
 thread_local std::string g_err;
-thread_local int g_sdfa_frontend_t_major = 0;   // "frontend_t_major" option: the front end's distinct columns numbered time-step-major (rounds 2-3)
 
 int fail(int code, const char *fmt, ...) {
     char buf[512];
@@ -746,6 +748,7 @@ thread_local int g_sdfa_time_lstm_timeout_us = 0;
 thread_local int g_sdfa_share_gx0_off = 0;
 int sdfa_debug_set_option(const char *name, int value) {
     if (name && !strcmp(name, "share_gx0_off")) { g_sdfa_share_gx0_off = value; return SDFA_OK; }
+    if (name && !strcmp(name, "mel_fft_radix4")) { g_sdfa_mel_fft_radix4 = value; return SDFA_OK; }
     if (name && !strcmp(name, "frontend_t_major")) { g_sdfa_frontend_t_major = value; return SDFA_OK; }
     if (name && !strcmp(name, "time_lstm_timeout_us")) { g_sdfa_time_lstm_timeout_us = value; return SDFA_OK; }
     if (name && !strcmp(name, "time_lstm_handoff")) { g_sdfa_time_lstm_handoff = value; return SDFA_OK; }

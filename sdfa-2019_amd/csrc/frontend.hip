@@ -388,6 +388,169 @@ __global__ __launch_bounds__(64 * MC_WAVES) void mel_columns_kernel(FrontendCons
     }
 }
 
+// ---------------------------------------------------------------------------- radix-8, register-resident (round 4, WIN = 1024)
+// The 512-point complex FFT of a column as THREE radix-8 passes on the 8 values a lane holds (512 = 8^3), with two transpositions
+// through the wave's LDS buffer in between -- instead of four radix-4 passes and a radix-2 pass that each go through LDS (the
+// kernel was bound by its vector-ALU / LDS instruction count: about 1,000 instructions per column, 700 of them the FFT).
+//   pass 1  lane l holds z[l + 64 r], r = 0..7: DFT-8 over r, times W_512^(l q)             -> 8 sub-problems (q) of 64 points over l
+//   x-pose  lane l = l1 + 8 l2, value q   ->  lane l1 + 8 q, value l2
+//   pass 2  DFT-8 over l2, times W_64^(l1 q2)                                                 -> 64 sub-problems (q, q2) of 8 points over l1
+//   x-pose  lane l1 + 8 q, value q2  ->  lane q + 8 q2, value l1
+//   pass 3  DFT-8 over l1: value q3 of lane q + 8 q2 is Z[q + 8 q2 + 64 q3] = Z[lane + 64 q3]  (natural order, no bit reversal)
+// LDS layouts are padded (rows of 72 / 68 float2) so that both sides of each transposition are bank-conflict-free.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 cmul2(f32x2 a, f32x2 b) { return f32x2{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ f32x2 mul_mi(f32x2 a) { return f32x2{a.y, -a.x}; }          // (-i) * a
+
+// forward DFT of 8 values in place: x[q] <- sum_r x[r] exp(-2 pi i r q / 8)   (decimation in frequency: 4 + 4, then two 4-point DFTs)
+__device__ __forceinline__ void dft8(f32x2 (&x)[8]) {
+    constexpr float R = 0.70710678118654752440f;
+    const f32x2 a0 = x[0] + x[4], a4 = x[0] - x[4];
+    const f32x2 a1 = x[1] + x[5], d5 = x[1] - x[5];
+    const f32x2 a2 = x[2] + x[6], d6 = x[2] - x[6];
+    const f32x2 a3 = x[3] + x[7], d7 = x[3] - x[7];
+    const f32x2 a5 = f32x2{(d5.x + d5.y) * R, (d5.y - d5.x) * R};      // * W8^1 = (1 - i) / sqrt 2
+    const f32x2 a6 = mul_mi(d6);                                       // * W8^2 = -i
+    const f32x2 a7 = f32x2{(d7.y - d7.x) * R, -(d7.x + d7.y) * R};     // * W8^3 = (-1 - i) / sqrt 2
+    const f32x2 b0 = a0 + a2, b2 = a0 - a2, b1 = a1 + a3, b3 = mul_mi(a1 - a3);
+    const f32x2 c0 = a4 + a6, c2 = a4 - a6, c1 = a5 + a7, c3 = mul_mi(a5 - a7);
+    x[0] = b0 + b1; x[4] = b0 - b1; x[2] = b2 + b3; x[6] = b2 - b3;
+    x[1] = c0 + c1; x[5] = c0 - c1; x[3] = c2 + c3; x[7] = c2 - c3;
+}
+
+constexpr int MC8_BUF = 8 * 72;      // float2 per wave: the larger of the two padded transposition layouts (also >= 512 for the final spectrum)
+
+// v: z[lane + 64 r] (windowed, .x = even sample, .y = odd sample).  Returns mel[bb] for band = lane + 64 bb.
+__device__ __forceinline__ void fft512_r8_to_mel(f32x2 (&v)[8], f32x2 *buf, const float2 *sTw, const int *sBin0, const float (*sW8)[128], int lane,
+                                                 float (&mel)[2]) {
+    const int l1 = lane & 7, hi3 = lane >> 3;
+    // ---- pass 1 + twiddle W_512^(lane q) = sTw[2 lane q] (table of W_1024)
+    dft8(v);
+#pragma unroll
+    for (int q = 1; q < 8; ++q) { const float2 w = sTw[(2 * lane * q) & 1023]; v[q] = cmul2(v[q], f32x2{w.x, w.y}); }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) buf[q * 72 + lane] = v[q];
+    WAVE_SYNC()
+    // this lane is now (l1, q = hi3): values l2 = 0..7
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = buf[hi3 * 72 + l1 + 8 * r];
+    WAVE_SYNC()      // every read done before the second layout overwrites the buffer
+    // ---- pass 2 + twiddle W_64^(l1 q2) = sTw[16 l1 q2]
+    dft8(v);
+#pragma unroll
+    for (int q2 = 1; q2 < 8; ++q2) { const float2 w = sTw[16 * l1 * q2]; v[q2] = cmul2(v[q2], f32x2{w.x, w.y}); }
+#pragma unroll
+    for (int q2 = 0; q2 < 8; ++q2) buf[l1 * 68 + hi3 + 8 * q2] = v[q2];
+    WAVE_SYNC()
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = buf[r * 68 + lane];       // lane = q + 8 q2, value l1 = r
+    WAVE_SYNC()
+    // ---- pass 3: v[i] = Z[lane + 64 i]
+    dft8(v);
+    // ---- real-FFT recombination for bins k = lane + 64 i < 256: needs Z[(512 - k) & 511], another lane's value -> through the buffer
+#pragma unroll
+    for (int i = 0; i < 8; ++i) buf[lane + 64 * i] = v[i];
+    WAVE_SYNC()
+    float p[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = lane + 64 * i;
+        const f32x2 zk = v[i], zn = buf[(512 - k) & 511];
+        const f32x2 e = f32x2{0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y)};     // E = (Z[k] + conj Z[M-k]) / 2
+        const f32x2 o = f32x2{0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x)};    // O = (Z[k] - conj Z[M-k]) / (2i)
+        const float2 w = sTw[k];
+        const f32x2 x = e + cmul2(o, f32x2{w.x, w.y});                         // X[k] = E + W_1024^k O
+        p[i] = __fadd_rn(__fmul_rn(x.x, x.x), __fmul_rn(x.y, x.y));
+    }
+    WAVE_SYNC()
+    float *pw = reinterpret_cast<float *>(buf);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pw[lane + 64 * i] = p[i];
+    WAVE_SYNC()
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+        const int band = lane + 64 * bb;
+        float m = 0.f;
+        const int b0 = sBin0[band];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m += sW8[e][band] * pw[b0 + e];
+        // 10 log10(max(m, eps)) as 10 log10(2) * v_log_f32 (the argument is a normal number >= 2^-23: no denormal handling needed;
+        // 1 ulp of the hardware logarithm is 1e-5 dB, the feature tolerance corresponds to 4e-3 dB), then (dB - 20 + 80) / 80
+        const float db = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(m, 1.1920929e-07f));
+        const float nv = __fadd_rn(__fsub_rn(db, 20.0f), 80.0f) * 0.0125f;
+        mel[bb] = fminf(fmaxf(nv, 0.f), 1.f);
+    }
+    WAVE_SYNC()
+}
+
+__global__ __launch_bounds__(64 * MC_WAVES) void mel_columns_r8_kernel(FrontendConsts c, const float *__restrict__ pcm,
+                                                                       const int64_t *__restrict__ clip_off, const int64_t *__restrict__ clip_len,
+                                                                       const int32_t *__restrict__ frame_clip, const int64_t *__restrict__ frame_start,
+                                                                       const int32_t *__restrict__ col_src, const int64_t *__restrict__ n_distinct,
+                                                                       float *__restrict__ mel_table) {
+    constexpr int WIN = 1024, HOP = WIN / 8;
+    __shared__ f32x2 sFft[MC_WAVES][MC8_BUF];
+    __shared__ float2 sTw[WIN];
+    __shared__ float sHamm[WIN];
+    __shared__ int sBin0[128];
+    __shared__ float sW8[8][128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < WIN; i += 64 * MC_WAVES) { sTw[i] = c.twiddle[i]; sHamm[i] = c.hamm[i]; }
+    for (int i = tid; i < 128; i += 64 * MC_WAVES) sBin0[i] = c.mel_bin0[i];
+    for (int i = tid; i < 1024; i += 64 * MC_WAVES) sW8[i >> 7][i & 127] = c.mel_w8[i];
+    __syncthreads();
+
+    const int64_t nd = *n_distinct;
+    f32x2 *buf = sFft[wave];
+    for (int64_t u = (int64_t)blockIdx.x * MC_WAVES + wave; u < nd; u += (int64_t)gridDim.x * MC_WAVES) {
+        const int row = col_src[u], n = row >> 6, t = row & 63, clip = frame_clip[n];
+        // the clip as a buffer, zero padding explicit: see mel_columns_kernel
+        const int64_t len64 = clip_len[clip], p = frame_start[n] + (int64_t)t * HOP;
+        const int len = (int)(len64 > 0x1fffffff ? 0x1fffffff : len64);
+        const unsigned long long xb = (unsigned long long)(pcm + clip_off[clip]);
+        const unsigned long long xuni = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(xb >> 32)) << 32) |
+                                        (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xb);
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)xuni, 0, __builtin_amdgcn_readfirstlane(len * 4), 0x00020000);
+        const bool raw0 = t == 0;
+        f32x2 v[8];
+        // A column that lies inside its clip with one sample to spare in front (all but the first / last few of a clip: a wave-uniform
+        // test) needs no clamping and no zero fill: its three samples per element come as ONE 12-byte request (g0 - 1, g0, g0 + 1).
+        const bool inside = __builtin_amdgcn_readfirstlane((int)(p >= 1 && p + WIN < (int64_t)len)) != 0;
+        if (inside) {
+            typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+            const unsigned voff = (unsigned)((int)p - 1 + 2 * lane) * 4u;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int i = 2 * (lane + 64 * r);
+                const u32x3 q = __builtin_amdgcn_raw_buffer_load_b96(xrs, voff + 512u * r, 0, 0);
+                const float xm = __builtin_bit_cast(float, q.x), x0 = __builtin_bit_cast(float, q.y), x1 = __builtin_bit_cast(float, q.z);
+                const float y0 = (raw0 && i == 0) ? x0 : __fsub_rn(x0, __fmul_rn(0.65f, xm));
+                const float y1 = __fsub_rn(x1, __fmul_rn(0.65f, x0));
+                const float2 hw = *reinterpret_cast<const float2 *>(&sHamm[i]);
+                v[r] = f32x2{hw.x * y0, hw.y * y1};
+            }
+        } else
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i = 2 * (lane + 64 * r);                             // even sample of z[lane + 64 r]
+            const int g0 = (int)(p + i), last = len - 1;
+#define MC_REQ(idx) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (unsigned)((idx) < 0 ? 0 : ((idx) > last ? last : (idx))) * 4u, 0, 0))
+            const float rm = MC_REQ(g0 - 1), r0 = MC_REQ(g0), r1 = MC_REQ(g0 + 1);
+#undef MC_REQ
+            const float xm = (unsigned)(g0 - 1) < (unsigned)len ? rm : 0.f;
+            const float x0 = (unsigned)g0 < (unsigned)len ? r0 : 0.f;
+            const float x1 = (unsigned)(g0 + 1) < (unsigned)len ? r1 : 0.f;
+            const float y0 = (raw0 && i == 0) ? x0 : __fsub_rn(x0, __fmul_rn(0.65f, xm));
+            const float y1 = __fsub_rn(x1, __fmul_rn(0.65f, x0));
+            v[r] = f32x2{sHamm[i] * y0, sHamm[i + 1] * y1};
+        }
+        float mel[2];
+        fft512_r8_to_mel(v, buf, sTw, sBin0, sW8, lane, mel);
+        mel_table[u * 128 + lane] = mel[0];
+        mel_table[u * 128 + 64 + lane] = mel[1];
+    }
+}
+
 __global__ __launch_bounds__(256) void gather_features_kernel(const float4 *__restrict__ mel_table, const int32_t *__restrict__ col_to_u,
                                                               int64_t Nc, float *__restrict__ out) {
     __shared__ float sMel[64][128];
@@ -441,6 +604,8 @@ __global__ __launch_bounds__(256) void gather_features_kernel(const float4 *__re
 
 }  // namespace
 
+extern thread_local int g_sdfa_mel_fft_radix4;   // api.cpp ("mel_fft_radix4"): 1 = the radix-4 / LDS-staged column FFT of rounds 2-3 at 16 kHz too
+
 hipError_t sdfa_launch_frontend(const FrontendConsts &c, const float *pcm, const int64_t *clip_off,
                                 const int64_t *clip_len, const int32_t *frame_clip, const int64_t *frame_start,
                                 int64_t n_frames, float *audio_feat, hipStream_t s) {
@@ -462,7 +627,10 @@ hipError_t sdfa_launch_mel_columns(const FrontendConsts &c, const float *pcm, co
                                    const int64_t *n_distinct, float *mel_table, hipStream_t s) {
     if (c.nbins_used > 256) return hipErrorInvalidValue;
     const unsigned grid = 256 * 6;      // persistent waves: each takes column pairs round-robin until the device-side count runs out
-    if (c.win == 1024)
+    if (c.win == 1024 && !g_sdfa_mel_fft_radix4)
+        hipLaunchKernelGGL(mel_columns_r8_kernel, dim3(grid), dim3(64 * MC_WAVES), 0, s, c, pcm, clip_off, clip_len, frame_clip, frame_start, col_src,
+                           n_distinct, mel_table);
+    else if (c.win == 1024)
         hipLaunchKernelGGL(mel_columns_kernel<1024>, dim3(grid), dim3(64 * MC_WAVES), 0, s, c, pcm, clip_off, clip_len, frame_clip,
                            frame_start, col_src, n_distinct, mel_table);
     else if (c.win == 512)
