@@ -514,16 +514,19 @@ __global__ __launch_bounds__(64 * MC_WAVES) void mel_columns_r8_kernel(FrontendC
         const bool raw0 = t == 0;
         f32x2 v[8];
         // A column that lies inside its clip with one sample to spare in front (all but the first / last few of a clip: a wave-uniform
-        // test) needs no clamping and no zero fill: its three samples per element come as ONE 12-byte request (g0 - 1, g0, g0 + 1).
+        // test) needs no clamping and no zero fill: its three samples per element come as ONE request of four dwords (g0 - 1 .. g0 + 2,
+        // dword-aligned; the compiler keeps the three that are used: buffer_load_dwordx3).  NB the whole vector is bit-cast to float4:
+        // __builtin_bit_cast(float, q.y) on an ELEMENT of the integer vector compiles to element 0 with this clang (ROCm 7.2) -- the
+        // first build loaded one dword per element and returned garbage; found by reading the ISA.
         const bool inside = __builtin_amdgcn_readfirstlane((int)(p >= 1 && p + WIN < (int64_t)len)) != 0;
         if (inside) {
-            typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
             const unsigned voff = (unsigned)((int)p - 1 + 2 * lane) * 4u;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int i = 2 * (lane + 64 * r);
-                const u32x3 q = __builtin_amdgcn_raw_buffer_load_b96(xrs, voff + 512u * r, 0, 0);
-                const float xm = __builtin_bit_cast(float, q.x), x0 = __builtin_bit_cast(float, q.y), x1 = __builtin_bit_cast(float, q.z);
+                const float4 q = __builtin_bit_cast(float4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(xrs, voff + 512u * r, 0, 0));
+                const float xm = q.x, x0 = q.y, x1 = q.z;
                 const float y0 = (raw0 && i == 0) ? x0 : __fsub_rn(x0, __fmul_rn(0.65f, xm));
                 const float y1 = __fsub_rn(x1, __fmul_rn(0.65f, x0));
                 const float2 hw = *reinterpret_cast<const float2 *>(&sHamm[i]);
