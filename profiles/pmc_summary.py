@@ -119,7 +119,7 @@ def main():
         frames = int(sys.argv[sys.argv.index("--frames") + 1])
         fe = {}
         for k in M:
-            for stem in ("mel_columns_kernel", "gather_features_kernel"):
+            for stem in ("mel_columns", "gather_features"):          # mel_columns_kernel<WIN> / mel_columns_r8_kernel, gather_features_kernel
                 if k[0].startswith(stem) and F.get(k) and W.get(k):
                     fe[stem] = {"read_bytes": F[k][-1] * 1024 * FETCH_CORRECTION, "write_bytes": W[k][-1] * 1024, "grid": k[1]}
         if len(fe) == 2:
