@@ -278,6 +278,9 @@ int sdfa_ensemble_mean(const float *d_a, const float *d_b, int64_t n, float *d_o
  *                      stores + agent-scope release; bit 1 = agent-scope acquire + plain loads (the always-valid form, slower);
  *                      bit 2 (tests only) = the second workgroup of every pair never publishes, so every wait of the first expires
  *   "time_lstm_timeout_us" bound of one such wait in microseconds (0 = the default, 200,000)
+ *   "mel_fft_radix4"   1 = the 16 kHz column FFT as four LDS-staged radix-4 passes + a radix-2 pass (rounds 2-3) instead of three register-resident
+ *                      radix-8 passes (NOT bit-identical: another order of additions; both inside the 5e-5 feature tolerance)
+ *   "gather_plain_order" 1 = workgroup b of the feature gather takes frame b (rounds 2-3) instead of the XCD-aware chain order (same bits)
  *   "frontend_t_major" 1 = sdfa_mel_frontend_gather numbers its distinct STFT columns time-step-major (rounds 2-3) instead of clip by clip,
  *                      hop by hop (same features, bit for bit; only the order of the mel table's rows differs)
  *   "share_gx0_off"    1 = sdfa_encoder_forward_shared expands the frequency projection to all columns before the layer-0 BiLSTM input

@@ -17,6 +17,7 @@
 #include <vector>
 
 thread_local int g_sdfa_mel_fft_radix4 = 0;     // "mel_fft_radix4" option (read by frontend.hip)
+thread_local int g_sdfa_gather_plain_order = 0; // "gather_plain_order" option (read by frontend.hip)
 thread_local int g_sdfa_frontend_t_major = 0;   // "frontend_t_major" option: the front end's distinct columns numbered time-step-major (rounds 2-3)
 
 namespace {
@@ -421,7 +422,7 @@ int sdfa_mel_frontend_gather(const float *d_pcm, const int64_t *d_clip_off, cons
     HIP_TRY(sdfa_launch_share_map(sa, s));
     float *table = reinterpret_cast<float *>(reinterpret_cast<char *>(d_workspace) + w.table_off);
     HIP_TRY(sdfa_launch_mel_columns(c, d_pcm, d_clip_off, d_clip_len, d_frame_clip, d_frame_start, sa.col_src, sa.counts, table, s));
-    HIP_TRY(sdfa_launch_gather_features(table, sa.col_to_u, n_frames, w.Nc, d_audio_feat, s));
+    HIP_TRY(sdfa_launch_gather_features(table, sa.col_to_u, n_frames, w.Nc, sa.frame_major, d_audio_feat, s));
     return SDFA_OK;
 }
 
@@ -748,6 +749,7 @@ thread_local int g_sdfa_time_lstm_timeout_us = 0;
 thread_local int g_sdfa_share_gx0_off = 0;
 int sdfa_debug_set_option(const char *name, int value) {
     if (name && !strcmp(name, "share_gx0_off")) { g_sdfa_share_gx0_off = value; return SDFA_OK; }
+    if (name && !strcmp(name, "gather_plain_order")) { g_sdfa_gather_plain_order = value; return SDFA_OK; }
     if (name && !strcmp(name, "mel_fft_radix4")) { g_sdfa_mel_fft_radix4 = value; return SDFA_OK; }
     if (name && !strcmp(name, "frontend_t_major")) { g_sdfa_frontend_t_major = value; return SDFA_OK; }
     if (name && !strcmp(name, "time_lstm_timeout_us")) { g_sdfa_time_lstm_timeout_us = value; return SDFA_OK; }

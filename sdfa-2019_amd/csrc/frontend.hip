@@ -554,18 +554,38 @@ __global__ __launch_bounds__(64 * MC_WAVES) void mel_columns_r8_kernel(FrontendC
     }
 }
 
+// Which frame a workgroup takes.  Frames 12 apart (25 hops at 60 fps: the hop-aligned ones) share 39 of their 64 table rows, and a
+// row is read by up to three frames (n, n + 12, n + 24).  Workgroups go to the XCDs round-robin (block b -> XCD b % 8, each with
+// its own L2), so in plain order the three readers of a row sit on different XCDs or far apart in time and every read came from
+// beyond the L2 (counters: 30.6 KB fetched per frame for 32 KB requested).  Here XCD x takes a CONTIGUOUS range of the "chain
+// order" c = (n % 12) * ceil(F / 12) + n / 12, so that consecutive workgroups of one XCD are frames 12 apart: a frame finds its
+// predecessors' rows in that XCD's L2.  Any period gives correct results (this is a permutation of the frames); 12 is the
+// locality of the 8 kHz / 16 kHz, 60 fps geometry.
+__device__ __forceinline__ int64_t gather_frame_of_block(int64_t b, int64_t n_frames) {
+    constexpr int PERIOD = 12, XCDS = 8;
+    const int64_t per_class = (n_frames + PERIOD - 1) / PERIOD, total = per_class * PERIOD;
+    const int64_t span = (total + XCDS - 1) / XCDS;
+    const int64_t c = (b % XCDS) * span + b / XCDS;
+    if (c >= total) return -1;
+    const int64_t n = (c % per_class) * PERIOD + c / per_class;
+    return n < n_frames ? n : -1;
+}
+
 __global__ __launch_bounds__(256) void gather_features_kernel(const float4 *__restrict__ mel_table, const int32_t *__restrict__ col_to_u,
-                                                              int64_t Nc, float *__restrict__ out) {
+                                                              int64_t Nc, int64_t n_frames, int frame_major, int chain_order,
+                                                              float *__restrict__ out) {
     __shared__ float sMel[64][128];
     const int tid = threadIdx.x;
-    const int64_t frame = blockIdx.x;
+    const int64_t frame = chain_order ? gather_frame_of_block(blockIdx.x, n_frames) : (int64_t)blockIdx.x;
+    if (frame < 0 || frame >= n_frames) return;
+    const int64_t st = frame_major ? 1 : Nc, sf = frame_major ? 64 : 1;      // col_to_u[t * st + frame * sf]
     {   // the frame's 64 table rows: all eight index requests, then all eight row requests, then the LDS writes (as a rolled loop
         // this was eight dependent round-trip pairs in front of every workgroup's barrier)
         const int f4 = tid & 31;
         int32_t u[8];
         float4 row[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) u[i] = col_to_u[(int64_t)((tid >> 5) + 8 * i) * Nc + frame];
+        for (int i = 0; i < 8; ++i) u[i] = col_to_u[(int64_t)((tid >> 5) + 8 * i) * st + frame * sf];
 #pragma unroll
         for (int i = 0; i < 8; ++i) row[i] = mel_table[(int64_t)u[i] * 32 + f4];
 #pragma unroll
@@ -644,10 +664,16 @@ hipError_t sdfa_launch_mel_columns(const FrontendConsts &c, const float *pcm, co
     return hipGetLastError();
 }
 
-hipError_t sdfa_launch_gather_features(const float *mel_table, const int32_t *col_to_u, int64_t n_frames, int64_t Nc,
+extern thread_local int g_sdfa_gather_plain_order;   // api.cpp ("gather_plain_order"): 1 = workgroup b takes frame b (rounds 2-3)
+
+hipError_t sdfa_launch_gather_features(const float *mel_table, const int32_t *col_to_u, int64_t n_frames, int64_t Nc, int frame_major,
                                        float *audio_feat, hipStream_t s) {
     if (n_frames <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gather_features_kernel, dim3((unsigned)n_frames), dim3(256), 0, s, reinterpret_cast<const float4 *>(mel_table),
-                       col_to_u, Nc, audio_feat);
+    const int chain = g_sdfa_gather_plain_order ? 0 : 1;
+    // chain order: 8 XCD ranges of ceil(12 * ceil(F / 12) / 8) chain positions each (gather_frame_of_block); blocks past the end exit
+    const int64_t total = (n_frames + 11) / 12 * 12, span = (total + 7) / 8;
+    const int64_t grid = chain ? span * 8 : n_frames;
+    hipLaunchKernelGGL(gather_features_kernel, dim3((unsigned)grid), dim3(256), 0, s, reinterpret_cast<const float4 *>(mel_table),
+                       col_to_u, Nc, n_frames, frame_major, chain, audio_feat);
     return hipGetLastError();
 }

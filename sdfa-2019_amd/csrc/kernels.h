@@ -74,8 +74,8 @@ hipError_t sdfa_launch_frontend(const FrontendConsts &c, const float *pcm, const
 hipError_t sdfa_launch_mel_columns(const FrontendConsts &c, const float *pcm, const int64_t *clip_off, const int64_t *clip_len,
                                    const int32_t *frame_clip, const int64_t *frame_start, const int32_t *col_src,
                                    const int64_t *n_distinct, float *mel_table, hipStream_t s);
-hipError_t sdfa_launch_gather_features(const float *mel_table, const int32_t *col_to_u, int64_t n_frames, int64_t Nc,
-                                       float *audio_feat, hipStream_t s);
+hipError_t sdfa_launch_gather_features(const float *mel_table, const int32_t *col_to_u, int64_t n_frames, int64_t Nc, int frame_major,
+                                       float *audio_feat, hipStream_t s);   // frame_major: col_to_u is [n][t] (ShareArgs::frame_major)
 
 // ---- conv stack ----------------------------------------------------------------------------
 struct ConvArgs {
@@ -161,13 +161,14 @@ struct ShareArgs {
     const int64_t *frame_start;  // [N] window start sample inside its clip
     int hop;
     int t_lo, t_hi;              // window columns t_lo..t_hi are shareable between hop-aligned frames of a clip
-    int frame_major;             // numbering order of the distinct columns: 0 = time-step-major (t, then n), 1 = frame-major (n, then t)
+    int frame_major;             // index order of owner / flag / uid / col_to_u AND numbering order of the distinct columns: 0 = time-step-major
+                                 // (i = t * Nc + n), 1 = frame-major (i = n * 64 + t)
     int64_t N, Nc, Mc;
     int32_t *prev, *shift;       // [Nc]
     int32_t *owner, *flag, *uid; // [Mc]
     int32_t *tile_sum;           // [Mc/1024 + 1] scan scratch
     int32_t *col_src;            // [Mc] out: audio_feat row of each distinct column (-1 padding)
-    int32_t *col_to_u;           // [Mc] out: distinct-column index of every (t, n) column
+    int32_t *col_to_u;           // [Mc] out: distinct-column index of every column, in the index order above
     int64_t *counts;             // [2]  out: number of distinct columns, and that rounded up to 256
 };
 hipError_t sdfa_launch_share_map(const ShareArgs &a, hipStream_t s);

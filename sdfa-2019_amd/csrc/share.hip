@@ -36,20 +36,24 @@ __global__ void share_prev_kernel(ShareArgs a) {
     a.shift[n] = shift;
 }
 
-// Position of column m = t*Nc + n in the numbering scan.  Time-step-major (the encoder's map: consecutive distinct columns are
-// consecutive FRAMES at one time step, which is what the time-LSTM kernels read through the map) or frame-major (the front end's map:
-// consecutive distinct columns are consecutive HOPS of one clip, so that mel_columns_kernel walks the PCM front to back and a frame's
-// table rows are three contiguous runs).  Mc = 64 * Nc either way.
-__device__ __forceinline__ int64_t scan_pos(const ShareArgs &a, int64_t m) { return a.frame_major ? (m % a.Nc) * 64 + m / a.Nc : m; }
-__device__ __forceinline__ int64_t scan_col(const ShareArgs &a, int64_t i) { return a.frame_major ? (i & 63) * a.Nc + (i >> 6) : i; }
+// Index order of the per-column arrays (owner, flag, uid, col_to_u) and of the numbering scan: time-step-major, i = t * Nc + n (the
+// encoder's map: consecutive distinct columns are consecutive FRAMES at one time step, which is what the time-LSTM kernels read
+// through the map), or frame-major, i = n * 64 + t (the front end's map: consecutive distinct columns are consecutive HOPS of one
+// clip, so that mel_columns_kernel walks the PCM front to back, a frame's table rows are three contiguous runs and its 64 map
+// entries one 256-byte line).  Mc = 64 * Nc either way; every kernel below is coalesced in either order.
+__device__ __forceinline__ int64_t col_index(const ShareArgs &a, int64_t n, int t) { return a.frame_major ? n * 64 + t : (int64_t)t * a.Nc + n; }
+__device__ __forceinline__ void col_of(const ShareArgs &a, int64_t i, int64_t &n, int &t) {
+    if (a.frame_major) { n = i >> 6; t = (int)(i & 63); } else { n = i % a.Nc; t = (int)(i / a.Nc); }
+}
 
-// owner[m] = canonical column (index m' = t'*Nc + n') holding the same feature vector; flag[scan_pos(m)] = 1 if m is its own owner
+// owner[i] = index of the canonical column holding the same feature vector; flag[i] = 1 if column i is its own owner
 __global__ void share_owner_kernel(ShareArgs a) {
-    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= a.Mc) return;
-    int64_t n = m % a.Nc;
-    int t = (int)(m / a.Nc);
-    if (n >= a.N) { a.owner[m] = -1; a.flag[scan_pos(a, m)] = 0; return; }     // padding frame: never computed
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.Mc) return;
+    int64_t n;
+    int t;
+    col_of(a, i, n, t);
+    if (n >= a.N) { a.owner[i] = -1; a.flag[i] = 0; return; }     // padding frame: never computed
     while (t >= a.t_lo && t <= a.t_hi) {
         const int p = a.prev[n];
         if (p < 0) break;
@@ -57,9 +61,9 @@ __global__ void share_owner_kernel(ShareArgs a) {
         if (tt > a.t_hi) break;
         n = p; t = tt;
     }
-    const int64_t o = (int64_t)t * a.Nc + n;
-    a.owner[m] = (int)o;
-    a.flag[scan_pos(a, m)] = o == m ? 1 : 0;
+    const int64_t o = col_index(a, n, t);
+    a.owner[i] = (int)o;
+    a.flag[i] = o == i ? 1 : 0;
 }
 
 // Exclusive scan of flag[0..Mc) -> uid in three small launches: per-tile (1024 columns) scan + tile sums, a
@@ -110,8 +114,10 @@ __global__ __launch_bounds__(1024) void share_scan_fix_kernel(ShareArgs a) {
     if (i < a.Mc) {
         const int u = a.uid[i] + a.tile_sum[blockIdx.x];
         a.uid[i] = u;
-        const int64_t m = scan_col(a, i);
-        if (a.flag[i]) a.col_src[u] = (int)((m % a.Nc) * 64 + m / a.Nc);     // row of audio_feat viewed as [N*64][384]
+        int64_t n;
+        int t;
+        col_of(a, i, n, t);
+        if (a.flag[i]) a.col_src[u] = (int)(n * 64 + t);     // row of audio_feat viewed as [N*64][384]
     }
     if (i >= mu && i < pad) a.col_src[i] = -1;        // padding columns read zeros (disjoint from the writes above: u < mu)
 }
@@ -120,7 +126,7 @@ __global__ void share_assign_kernel(ShareArgs a) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= a.Mc) return;
     const int o = a.owner[m];
-    a.col_to_u[m] = o >= 0 ? a.uid[scan_pos(a, o)] : 0;
+    a.col_to_u[m] = o >= 0 ? a.uid[o] : 0;
 }
 
 // Z[q][m] = Zu[q][col_to_u[m]]  (K4 quads, ld = Mc on both sides)

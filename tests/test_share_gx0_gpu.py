@@ -74,3 +74,25 @@ def test_frontend_column_numbering_does_not_change_a_bit(sr):
     assert ts_a == ts_b and torch.equal(a, b)
     c, _, _ = fe.mel_frontend(clips, sr, gather=False)
     assert float((b - c).abs().max()) <= 5e-5
+
+
+def test_gather_chain_order_and_radix4_fft_options():
+    """The feature gather's XCD-aware workgroup -> frame permutation does not change a bit (ragged clips, frame counts that are not
+    multiples of 12 or 8); the radix-4 column FFT of rounds 2-3 and the radix-8 one agree to rounding."""
+    from sdfa_amd.engine import FrontendOnly
+    fe = FrontendOnly()
+    sr = 16000
+    clips = [synth.make_pcm(30 + i, int(s * sr), "speechlike" if i & 1 else "uniform") for i, s in enumerate((1.0, 0.37, 3.21, 2.0, 0.9))]
+    try:
+        a, _, counts = fe.mel_frontend(clips, sr)
+        a = a.clone()
+        assert sum(counts) % 12 != 0
+        _lib.set_option("gather_plain_order", 1)
+        b, _, _ = fe.mel_frontend(clips, sr)
+        assert torch.equal(a, b)
+        _lib.set_option("mel_fft_radix4", 1)
+        c, _, _ = fe.mel_frontend(clips, sr)
+        assert 0 < float((a - c).abs().max()) <= 2e-5
+    finally:
+        _lib.set_option("gather_plain_order", 0)
+        _lib.set_option("mel_fft_radix4", 0)
