@@ -502,7 +502,12 @@ __global__ __launch_bounds__(64 * MC_WAVES) void mel_columns_r8_kernel(FrontendC
 
     const int64_t nd = *n_distinct;
     f32x2 *buf = sFft[wave];
-    for (int64_t u = (int64_t)blockIdx.x * MC_WAVES + wave; u < nd; u += (int64_t)gridDim.x * MC_WAVES) {
+    // XCD x (= block % 8: workgroups go to the XCDs round-robin, each XCD has its own L2) takes a CONTIGUOUS eighth of the distinct
+    // columns -- which are numbered clip by clip, hop by hop -- so that the PCM an XCD's waves walk through stays in ITS L2; with
+    // columns dealt round-robin every XCD read all of the PCM (counters: 11.2 KB fetched per frame for 1.07 KB of new samples).
+    const int64_t span = ((nd + 7) / 8 + MC_WAVES - 1) / MC_WAVES * MC_WAVES;
+    const int64_t u_end = min(nd, ((int64_t)(blockIdx.x & 7) + 1) * span);
+    for (int64_t u = (int64_t)(blockIdx.x & 7) * span + (int64_t)(blockIdx.x >> 3) * MC_WAVES + wave; u < u_end; u += (int64_t)(gridDim.x >> 3) * MC_WAVES) {
         const int row = col_src[u], n = row >> 6, t = row & 63, clip = frame_clip[n];
         // the clip as a buffer, zero padding explicit: see mel_columns_kernel
         const int64_t len64 = clip_len[clip], p = frame_start[n] + (int64_t)t * HOP;
