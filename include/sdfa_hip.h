@@ -267,6 +267,8 @@ int sdfa_ensemble_mean(const float *d_a, const float *d_b, int64_t n, float *d_o
  *                      kernel (two-workgroups-per-CU fallback); 8 = fat wherever it fits; 5 = 256 x 256 tile wherever it fits;
  *                      6 / 2 = the 64 x 64-tile form of the LDS-tiled kernel wherever it applies / never (default: launches of at
  *                      most two 128 x 128 tiles per CU with K <= 512, and any launch of less than half a tile per CU);
+ *                      10 / 11 = the 64 x 128 tile of the LDS-tiled kernel never / wherever that kernel runs (default: the 8192-deep frequency
+ *                      projection while it has fewer than four 128 x 128 tiles per CU -- single-clip and few-clip calls);
  *                      4 = split-bf16 x3 products (NOT exact fp32)
  *   "pca_lds"          0 = pca_dgrad_res_kernel (basis slab resident in LDS, persistent); 4 = pca_dgrad_kernel (register-direct, two
  *                      workgroups per CU: the fallback that shares a CU)

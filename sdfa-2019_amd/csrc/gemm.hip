@@ -72,10 +72,15 @@ __device__ __forceinline__ void store_tile(const GemmArgs &a, const f32x16 &acc,
 // throughput problem -- profiles/r03_per_launch.txt: a 256-deep MLP GEMM took 43-45 us whether it had 8 or 256 workgroups, 5 us
 // per 32-deep stage for 1.7 us of MFMAs -- and four times as many workgroups of a quarter of the work overlap each other's
 // round trips.  Same k order per accumulator: bit-identical to the 128 x 128 tile.
-template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND, int WT>
-__global__ __launch_bounds__(256, WT == 2 ? 2 : 4) void gemm_k4_kernel(GemmArgs a) {
-    constexpr int TPW = 64 * WT, SH = WT == 2 ? 7 : 6, RPP = 256 >> SH;   // tile edge, log2 of it, k-quad rows per staging pass
-    __shared__ float4 sP[2][KQ][TPW];
+// WTP (round 4) = tiles per wave along P when it differs from WT: <WT 2, WTP 1> is a 64 (P) x 128 (Q) workgroup tile, 48 KiB of LDS,
+// three workgroups per CU -- for the 8192-deep frequency projection of a single clip, whose 364 tiles of 128 x 128 (at two per CU)
+// left 108 CUs with two tiles and 148 with one: the launch took two tiles' time for 1.4 tiles of work per CU.  728 half tiles at
+// three per CU are 2.8 per CU.  Same k order per accumulator again: bit-identical.
+template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND, int WT, int WTP = WT>
+__global__ __launch_bounds__(256, WTP != WT ? 3 : (WT == 2 ? 2 : 4)) void gemm_k4_kernel(GemmArgs a) {
+    constexpr int TPW = 64 * WT, SH = WT == 2 ? 7 : 6, RPP = 256 >> SH;       // Q: tile edge, log2 of it, k-quad rows per staging pass
+    constexpr int TPWP = 64 * WTP, SHP = WTP == 2 ? 7 : 6, RPPP = 256 >> SHP;  // P: the same
+    __shared__ float4 sP[2][KQ][TPWP];
     __shared__ float4 sQ[2][KQ][TPW];
 
     const int tid = threadIdx.x;
@@ -85,10 +90,10 @@ __global__ __launch_bounds__(256, WT == 2 ? 2 : 4) void gemm_k4_kernel(GemmArgs 
 
     // tile order: all p-tiles of one q-tile are dispatched together, so the streamed activation tile (Q) comes
     // from HBM once and from L2 for the other row blocks; the weight slab (P) is small and L2-resident anyway
-    const int64_t ntp = a.Ppad / TPW;
+    const int64_t ntp = a.Ppad / TPWP;
     const int64_t bid = blockIdx.x;
     const int64_t tp = bid % ntp, tq = bid / ntp;
-    const int64_t p0 = tp * TPW, q0 = tq * TPW;
+    const int64_t p0 = tp * TPWP, q0 = tq * TPW;
     if (a.q_limit && q0 >= *a.q_limit) return;
 
     const float4 *__restrict__ P = reinterpret_cast<const float4 *>(a.P);
@@ -101,14 +106,14 @@ __global__ __launch_bounds__(256, WT == 2 ? 2 : 4) void gemm_k4_kernel(GemmArgs 
     const float4 *Pn = P + p0;
     const float4 *Qn = a.q_tile_major ? Q + (q0 >> 7) * (int64_t)a.q_slab_rows * 128 : Q + q0;
     int kin_n = 0;
-    const unsigned boffP = (unsigned)(((tid >> SH) * a.ldp + (tid & (TPW - 1))) * 16);
+    const unsigned boffP = (unsigned)(((tid >> SHP) * a.ldp + (tid & (TPWP - 1))) * 16);
     const unsigned boffQ = (unsigned)(((tid >> SH) * qrow + (tid & (TPW - 1))) * 16);
 
     // Register staging runs TWO tiles ahead of the MFMAs: while tile st is multiplied out of LDS, tile st+1 sits
     // in one register set (written to the other LDS buffer at the end of the stage) and the loads of tile st+2 are
     // in flight into the second set.  One stage is ~4,100 MFMA cycles per wave; an HBM-streamed operand (the 8192-deep
     // frequency projection) takes longer than that to arrive, which held the kernel at 76 % with a single tile ahead.
-    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;   // set A: P quads ra*, Q quads rb*   (WT = 1: two quads per operand)
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;   // set A: P quads ra*, Q quads rb*   (one tile per wave along an operand: two quads of it)
     float4 rc0, rc1, rc2, rc3, rd0, rd1, rd2, rd3;   // set B
     // Addressing of the staging loads: a UNIFORM running base per operand (scalar registers, advanced by scalar adds)
     // plus one loop-invariant 32-bit byte offset per thread -- the global_load "saddr + voffset" form, so a load costs
@@ -116,11 +121,8 @@ __global__ __launch_bounds__(256, WT == 2 ? 2 : 4) void gemm_k4_kernel(GemmArgs 
     // tools/mfma_valu.hip, every VALU instruction takes ~4 cycles away from the matrix pipe.  The first version of
     // this kernel recomputed 64-bit addresses and the segment division per load: ~170 VALU instructions per stage of
     // 64 MFMAs, i.e. 15 % of the pipe.)
-#define GEMM_GLOAD1(i, RP, RQ)                                                                          \
-    {                                                                                                   \
-        RP = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Pn + (i) * RPP * a.ldp) + boffP); \
-        RQ = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Qn + (i) * RPP * qrow) + boffQ);  \
-    }
+#define GEMM_PLOAD1(i, RP) RP = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Pn + (i) * RPPP * a.ldp) + boffP);
+#define GEMM_QLOAD1(i, RQ) RQ = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Qn + (i) * RPP * qrow) + boffQ);
 #define GEMM_ADVANCE()                                                                                  \
     {                                                                                                   \
         Pn += KQ * a.ldp;                                                                               \
@@ -129,29 +131,36 @@ __global__ __launch_bounds__(256, WT == 2 ? 2 : 4) void gemm_k4_kernel(GemmArgs 
         else Qn += KQ * qrow;                                                                           \
     }
     // stages are requested strictly in order (0, 1, 2, ...), so the bases just run forward
-#define GEMM_GLOAD_A(st) { GEMM_GLOAD1(0, ra0, rb0) GEMM_GLOAD1(1, ra1, rb1) if constexpr (WT == 2) { GEMM_GLOAD1(2, ra2, rb2) GEMM_GLOAD1(3, ra3, rb3) } GEMM_ADVANCE() }
-#define GEMM_GLOAD_B(st) { GEMM_GLOAD1(0, rc0, rd0) GEMM_GLOAD1(1, rc1, rd1) if constexpr (WT == 2) { GEMM_GLOAD1(2, rc2, rd2) GEMM_GLOAD1(3, rc3, rd3) } GEMM_ADVANCE() }
-#define GEMM_LSTORE1(buf, i, RP, RQ)                                          \
-    {                                                                         \
-        const int idx = (i)*256 + tid, kq = idx >> SH, c = idx & (TPW - 1);   \
-        sP[buf][kq][c] = RP;                                                  \
-        sQ[buf][kq][c] = RQ;                                                  \
+#define GEMM_GLOAD_SET(P0, P1, P2, P3, Q0, Q1, Q2, Q3)                                                   \
+    {                                                                                                   \
+        GEMM_PLOAD1(0, P0) GEMM_QLOAD1(0, Q0) GEMM_PLOAD1(1, P1) GEMM_QLOAD1(1, Q1)                     \
+        if constexpr (WTP == 2) { GEMM_PLOAD1(2, P2) } if constexpr (WT == 2) { GEMM_QLOAD1(2, Q2) }    \
+        if constexpr (WTP == 2) { GEMM_PLOAD1(3, P3) } if constexpr (WT == 2) { GEMM_QLOAD1(3, Q3) }    \
+        GEMM_ADVANCE()                                                                                  \
     }
-#define GEMM_LSTORE_A(buf) { GEMM_LSTORE1(buf, 0, ra0, rb0) GEMM_LSTORE1(buf, 1, ra1, rb1) if constexpr (WT == 2) { GEMM_LSTORE1(buf, 2, ra2, rb2) GEMM_LSTORE1(buf, 3, ra3, rb3) } }
-#define GEMM_LSTORE_B(buf) { GEMM_LSTORE1(buf, 0, rc0, rd0) GEMM_LSTORE1(buf, 1, rc1, rd1) if constexpr (WT == 2) { GEMM_LSTORE1(buf, 2, rc2, rd2) GEMM_LSTORE1(buf, 3, rc3, rd3) } }
+#define GEMM_GLOAD_A(st) GEMM_GLOAD_SET(ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3)
+#define GEMM_GLOAD_B(st) GEMM_GLOAD_SET(rc0, rc1, rc2, rc3, rd0, rd1, rd2, rd3)
+#define GEMM_PSTORE1(buf, i, RP) { const int idx = (i)*256 + tid; sP[buf][idx >> SHP][idx & (TPWP - 1)] = RP; }
+#define GEMM_QSTORE1(buf, i, RQ) { const int idx = (i)*256 + tid; sQ[buf][idx >> SH][idx & (TPW - 1)] = RQ; }
+#define GEMM_LSTORE_SET(buf, P0, P1, P2, P3, Q0, Q1, Q2, Q3)                                             \
+    {                                                                                                   \
+        GEMM_PSTORE1(buf, 0, P0) GEMM_QSTORE1(buf, 0, Q0) GEMM_PSTORE1(buf, 1, P1) GEMM_QSTORE1(buf, 1, Q1) \
+        if constexpr (WTP == 2) { GEMM_PSTORE1(buf, 2, P2) } if constexpr (WT == 2) { GEMM_QSTORE1(buf, 2, Q2) } \
+        if constexpr (WTP == 2) { GEMM_PSTORE1(buf, 3, P3) } if constexpr (WT == 2) { GEMM_QSTORE1(buf, 3, Q3) } \
+    }
+#define GEMM_LSTORE_A(buf) GEMM_LSTORE_SET(buf, ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3)
+#define GEMM_LSTORE_B(buf) GEMM_LSTORE_SET(buf, rc0, rc1, rc2, rc3, rd0, rd1, rd2, rd3)
 #define GEMM_COMPUTE(buf)                                                                                              \
     _Pragma("unroll") for (int kb = 0; kb < KQ / 2; ++kb) {                                                            \
-        float4 fa[WT], fb[WT];                                                                                         \
-        _Pragma("unroll") for (int i = 0; i < WT; ++i) {                                                               \
-            fa[i] = sP[buf][2 * kb + h][wp * 32 * WT + 32 * i + l31];                                                  \
-            fb[i] = sQ[buf][2 * kb + h][wq * 32 * WT + 32 * i + l31];                                                  \
-        }                                                                                                              \
-        mfma_block<WT, WT>(acc, fa, fb);                                                                               \
+        float4 fa[WTP], fb[WT];                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < WTP; ++i) fa[i] = sP[buf][2 * kb + h][wp * 32 * WTP + 32 * i + l31];     \
+        _Pragma("unroll") for (int i = 0; i < WT; ++i) fb[i] = sQ[buf][2 * kb + h][wq * 32 * WT + 32 * i + l31];       \
+        mfma_block<WTP, WT>(acc, fa, fb);                                                                              \
     }
 
-    f32x16 acc[WT][WT];
+    f32x16 acc[WTP][WT];
 #pragma unroll
-    for (int i = 0; i < WT; ++i)
+    for (int i = 0; i < WTP; ++i)
 #pragma unroll
         for (int j = 0; j < WT; ++j)
 #pragma unroll
@@ -201,10 +210,10 @@ __global__ __launch_bounds__(256, WT == 2 ? 2 : 4) void gemm_k4_kernel(GemmArgs 
 
     // ---------------------------------------------------------------- epilogue
 #pragma unroll
-    for (int i = 0; i < WT; ++i)
+    for (int i = 0; i < WTP; ++i)
 #pragma unroll
         for (int j = 0; j < WT; ++j)
-            store_tile<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, acc[i][j], p0 + wp * 32 * WT + i * 32, q0 + wq * 32 * WT + j * 32 + l31, h);
+            store_tile<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, acc[i][j], p0 + wp * 32 * WTP + i * 32, q0 + wq * 32 * WT + j * 32 + l31, h);
 }
 
 // Which launches take the 64 x 64 tile (gemm_k4_kernel<.., 1>): by the number of 128 x 128 tiles the problem has.  Fewer than half a
@@ -220,8 +229,22 @@ inline bool small_tile_pays(const GemmArgs &a) {
     return n128 * 2 < cus || (n128 <= 2 * cus && a.K <= 512);
 }
 
+// The 64 (P) x 128 (Q) tile: the tile-major 8192-deep frequency projection while its 128 x 128 tiles number fewer than four per CU
+// (a single clip, a few clips: most of the launched tiles exit at the device-side column limit in column-sharing mode, and what
+// is left quantises badly at two workgroups per CU).  "gemm_variant" 10 = never, 11 = wherever the LDS-tiled kernel runs.
+inline bool half_tile_pays(const GemmArgs &a) {
+    if (g_sdfa_gemm_variant == 10 || a.Ppad % 64) return false;
+    if (g_sdfa_gemm_variant == 11) return true;
+    return a.q_tile_major && (a.Ppad / TP) * (a.Qpad / TQ) < 4 * (int64_t)sdfa_cu_count();
+}
+
 template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
 hipError_t launch(const GemmArgs &a, hipStream_t s) {
+    if (half_tile_pays(a)) {
+        const int64_t nblk = (a.Ppad / 64) * (a.Qpad / TQ);
+        hipLaunchKernelGGL((gemm_k4_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 2, 1>), dim3((unsigned)nblk), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     if (small_tile_pays(a)) {
         const int64_t nblk = (a.Ppad / 64) * (a.Qpad / 64);
         hipLaunchKernelGGL((gemm_k4_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 1>), dim3((unsigned)nblk), dim3(256), 0, s, a);
@@ -875,7 +898,7 @@ thread_local int g_sdfa_gemm_variant = 0;
 
 template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
 hipError_t launch_any(const GemmArgs &a, hipStream_t s) {
-    const int variant = (g_sdfa_gemm_variant == 2 || g_sdfa_gemm_variant == 6) ? 0 : g_sdfa_gemm_variant;   // 2 / 6 only steer the small-tile choice (launch)
+    const int variant = (g_sdfa_gemm_variant == 2 || g_sdfa_gemm_variant == 6 || g_sdfa_gemm_variant == 10 || g_sdfa_gemm_variant == 11) ? 0 : g_sdfa_gemm_variant;   // 2 / 6 / 10 / 11 only steer the tile choice of the LDS-tiled kernel (launch)
     if (a.terms) {   // mixed-precision modes
         const bool big = a.Ppad % 256 == 0 && a.Qpad % 256 == 0 && variant != 7;
         if (a.terms == 1) return big ? launch_bf16_big<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 1>(a, s) : launch_bf16<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 1>(a, s);

@@ -96,3 +96,25 @@ def test_gather_chain_order_and_radix4_fft_options():
     finally:
         _lib.set_option("gather_plain_order", 0)
         _lib.set_option("mel_fft_radix4", 0)
+
+
+def test_half_tile_gemm_is_bitwise(synth_sd):
+    """The 64 x 128 tile of the LDS-tiled GEMM (the single-clip frequency projection): same k order per accumulator as the 128 x 128
+    tile and the persistent 256 x 256 kernels -- forced everywhere the LDS-tiled kernel runs (11), never (10), default."""
+    sr = 16000
+    e = Engine(synth_sd["dgrad"])
+    feat, _, _ = e.mel_frontend([synth.make_pcm(9, 10 * sr), synth.make_pcm(10, 2 * sr)], sr)
+    fc, fs, hop = e.last_frame_table
+    spk = torch.full((feat.shape[0],), 3, dtype=torch.int64)
+    outs = []
+    try:
+        for v in (10, 0, 11):
+            _lib.set_option("gemm_variant", v)
+            z, a = e.encoder(feat, frame_clip=fc, frame_start=fs, hop=hop)
+            z2, _ = e.encoder(feat[:700])
+            _, rows = e.regress(z, spk)
+            outs.append((z.clone(), a.clone(), z2.clone(), rows.clone()))
+    finally:
+        _lib.set_option("gemm_variant", 0)
+    for o in outs[1:]:
+        assert all(torch.equal(x, y) for x, y in zip(outs[0], o))
