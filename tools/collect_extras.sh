@@ -6,7 +6,9 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
 Q="--no-cpu-baseline --no-mixed-precision --no-host-io --no-surface"
-python3 bench.py --steps 20 --warmup 3 > $OUT/bench_steps20.json 2> $OUT/err.txt; echo steps20-done
+# the headline line again, now that profiles/<round>_pmc of THIS tree is installed (roofline.traffic, frontend / attention counter figures live)
+python3 bench.py --steps 5 --warmup 1 > $OUT/bench_final.json 2> $OUT/err.txt; echo final-done
+python3 bench.py --steps 20 --warmup 3 > $OUT/bench_steps20.json 2>> $OUT/err.txt; echo steps20-done
 python3 bench.py --sample-rate 8000 $Q > $OUT/bench_8khz.json 2>> $OUT/err.txt; echo 8khz-done
 python3 bench.py --head offsets --ragged-seconds 3,6 --sample-rate 8000 --clips-per-gpu 80 $Q > $OUT/bench_config5.json 2>> $OUT/err.txt; echo config5-done
 python3 bench.py --mesh-stage $Q --no-column-sharing > $OUT/bench_mesh_stage.json 2>> $OUT/err.txt; echo mesh-done
@@ -21,6 +23,9 @@ python3 bench.py --steps 5 --warmup 2 $Q --no-column-sharing > $OUT/rehearsal_nc
 python3 bench.py --steps 5 --warmup 2 $Q --no-column-sharing --force-gather --gather dgrad --backend nccl --reserve-cus 16 > $OUT/rehearsal_nccl_w1_dgrad_reserve16.json 2>> $OUT/err.txt
 echo rehearsal-done
 python3 tools/time_split_lstm.py > $OUT/time_lstm_split.txt 2>> $OUT/err.txt
+# round 4: front end same-process A/B (column FFT, numbering order, gather order) and the stress run of the cooperating-workgroup time LSTM
+python3 tools/time_frontend.py 20 mel_fft_radix4=0,1 frontend_t_major=0,1 gather_plain_order=0,1 > $OUT/time_frontend.txt 2>> $OUT/err.txt; echo frontend-ab-done
+python3 tools/stress_split_lstm.py 3000 > $OUT/stress_split_lstm.txt 2>> $OUT/err.txt; echo stress-done
 python3 - <<PY
 import json, glob, os
 for f in sorted(glob.glob("$OUT/*.json")):
