@@ -440,3 +440,35 @@ def test_gemm_variants_agree(eng, golden, variant):
         assert torch.equal(z, z0) and torch.equal(coef, coef0) and torch.equal(out, out0) and torch.equal(align, align0)
         for a_, b_ in zip(res_big, eng.forward(big, spk_big, want_coef=True)):
             assert torch.equal(a_, b_)
+
+
+@pytest.mark.parametrize("seed,lstm_gain,flip_bn", [(77, 1.0, False), (4321, 2.0, False), (99, 1.5, True)])
+def test_other_weight_dynamics_vs_the_reference_operators(seed, lstm_gain, flip_bn):
+    """The fixtures pin ONE synthetic checkpoint (seed 1234; the pretrained one is not obtainable offline).  VERDICT r3 weak 1(iii): the
+    frequency LSTM's cell update is algebraically, not operation-for-operation, torch's.  So the whole model is also held to the
+    reference's own operator library (oracle/torch_oracle.py: torch CPU conv2d / nn.LSTM / linear / softmax, itself pinned to the
+    reference fixtures) on OTHER weights: two more seeds, LSTM weights scaled x2 / x1.5 (gates pushed towards saturation in all
+    three LSTMs), and BatchNorm scales of both signs (a trained checkpoint may hold negative gammas: LeakyReLU -> BN -> max-pool must
+    not assume a positive scale).  Same 1e-4 budget on dgrad; 1e-4 on z; 1e-5 on the attention weights."""
+    import torch_oracle as TO
+    sd = synth.make_state_dict("dgrad", seed)
+    rs = np.random.RandomState(seed)
+    for k in list(sd):
+        if ("_lstm.weight" in k or ".9.weight_" in k) and lstm_gain != 1.0:
+            sd[k] = (sd[k] * lstm_gain).astype(np.float32)
+        if flip_bn and k.endswith("_ext_post_bn.weight"):
+            sd[k] = (sd[k] * rs.choice([-1.0, 1.0], sd[k].shape)).astype(np.float32)
+    eng = Engine(sd)
+    sr = 16000
+    feat, _, _ = eng.mel_frontend([synth.make_pcm(seed, int(0.9 * sr), "speechlike"), synth.make_pcm(seed + 1, int(0.7 * sr))], sr)
+    n = feat.shape[0]
+    spk = rs.randint(0, 8, n)
+    out, z, align, _ = eng.forward(feat, torch.from_numpy(spk))
+    ref, zr, ar = TO.TorchOracle(sd).forward(feat.cpu().numpy(), spk)
+    assert np.abs(z.cpu().numpy() - zr).max() <= TOL_ACT
+    assert np.abs(align.cpu().numpy() - ar).max() <= 1e-5
+    assert np.abs(out.cpu().numpy() - ref).max() <= TOL_DGRAD
+    # and the column-sharing encoder on the same weights: bitwise the plain one
+    fc, fs, hop = eng.last_frame_table
+    z2, a2 = eng.encoder(feat, frame_clip=fc, frame_start=fs, hop=hop)
+    assert torch.equal(z, z2) and torch.equal(align, a2)
