@@ -363,7 +363,8 @@ class Engine(FrontendOnly):
 
     def forward_host(self, feat, speaker_id, out=None, table=None, piece=None, wait=True, want_z=False, ops_key=None, ensemble=False, z=None):
         """The whole model for `n` frames with the output rows delivered to PINNED HOST memory: rows (n, out_dim) as a CPU
-        tensor (`.numpy()` is a view).  Frames are processed in pieces of `piece` (default max_frames) frames; piece i's rows
+        tensor (`.numpy()` is a view).  Frames are processed in pieces of `piece` frames (default: `piece_schedule` -- one piece up to
+        max_frames, otherwise a small first piece, max_frames-sized ones, and a ramp-down at the end); piece i's rows
         are copied device -> host on a copy stream while piece i+1 computes (two device staging buffers), so for more than one
         piece the PCIe transfer hides behind the kernels.  This is what SaberSpeechDrivenAnimation._feature_to_anime
         (speech_anime/model/model.py:428-489) does with `.cpu().numpy()` per batch of 100 frames.
@@ -395,10 +396,12 @@ class Engine(FrontendOnly):
         assert (not out.is_cuda) and out.is_pinned() and out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (n, self.out_dim)
         if self._host is None:
             self._host = HostPipeline(self)
-        piece = int(piece or self.max_frames)
-        if ensemble:
-            piece = max(1, piece // 2)                  # a piece holds both passes of its frames
-        zs = self._host.run(feat, speaker_id, out, table, piece, want_z, ops_key, ensemble, z)
+        if piece is None:
+            sizes = piece_schedule(n, max(1, self.max_frames // (2 if ensemble else 1)))      # a piece holds both passes of its frames
+        else:
+            p = max(1, int(piece) // (2 if ensemble else 1))
+            sizes = [min(p, n - f0) for f0 in range(0, n, p)]
+        zs = self._host.run(feat, speaker_id, out, table, sizes, want_z, ops_key, ensemble, z)
         if wait:
             self.host_wait()
         return (out, zs) if want_z else out
@@ -452,6 +455,28 @@ class Engine(FrontendOnly):
         return float(v)
 
 
+def piece_schedule(n, big, first=2048, last=512):
+    """Piece sizes of a pinned-output call of `n` frames (Engine.forward_host).  One piece while it fits `big` (= max_frames: the rows
+    then also stay on the device, Engine.last_device_rows).  Otherwise the call is a two-stage pipeline -- kernels, then the device ->
+    host copy of the piece's rows -- whose length is  max(first piece's kernels + all copies,  all kernels + last piece's copy):
+    measured on 32 x 10 s (tools/timeline_batch.py, 359 KB rows at 57 GB/s = 6.3 us per frame against 7.3 us of kernels) uniform
+    pieces of 8192 frames gave 62.8 ms before the first copy could start and a 25 ms copy after the last kernel, 199 ms in all.  So: a
+    small FIRST piece (the copies start early), `big` pieces in the middle (kernel efficiency), and a geometric ramp-down to `last`
+    frames at the end (the copy that nothing can hide is short): 20,352 frames -> [2048, 8192, 4096, 2432, 2048, 1024, 512].
+    Frames are independent, so the rows do not depend on the schedule (bitwise: tests/test_surface_fast.py)."""
+    n, big = int(n), int(big)
+    if n <= big:
+        return [n] if n else []
+    first = min(first, big)
+    tail, t = [], min(last, big)
+    while t < big and sum(tail) + t <= (n - first) // 2:
+        tail.append(t)
+        t *= 2
+    mid_total = n - first - sum(tail)
+    mids = [big] * (mid_total // big) + ([mid_total % big] if mid_total % big else [])
+    return [first] + sorted(mids + tail, reverse=True)
+
+
 class HostPipeline:
     """Pinned-output staging of Engine.forward_host: two device row buffers, one copy stream.
 
@@ -484,16 +509,18 @@ class HostPipeline:
             self.bufs[slot] = b = torch.empty((rows, self.eng.out_dim), dtype=torch.float32, device=self.eng.device)
         return b
 
-    def run(self, feat, spk, out, table, piece, want_z, ops_key=None, ensemble=False, z_in=None):
+    def run(self, feat, spk, out, table, sizes, want_z, ops_key=None, ensemble=False, z_in=None):
         eng = self.eng
         n = int(out.shape[0])
+        assert sum(sizes) == n
+        piece = max(sizes) if sizes else 0
         cur = torch.cuda.current_stream(eng.device)
         zs = []
         self._last = None
         self.last_z = None
-        for f0 in range(0, n, piece):
-            f1 = min(n, f0 + piece)
-            m = f1 - f0
+        f1 = 0
+        for m in sizes:
+            f0, f1 = f1, f1 + m
             slot = self._next & 1                       # alternates across calls too: a call's last copy overlaps the next call's first piece
             self._next += 1
             rows = self._buf(slot, min(piece, n))[:m]
