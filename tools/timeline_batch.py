@@ -17,12 +17,14 @@ table = eng.last_frame_table
 n = feat.shape[0]
 spk = torch.full((n,), 2, dtype=torch.int64, device="cuda")
 out = torch.empty((n, eng.out_dim), dtype=torch.float32, pin_memory=True)
-for piece in [int(a) for a in sys.argv[1:]] or [8192, 4096, 2048]:
+from sdfa_amd.engine import piece_schedule
+for piece in [int(a) for a in sys.argv[1:]] or [8192, 4096, 2048, 0]:      # 0 = the default ramp schedule
     for rep in range(3):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        eng.forward_host(feat, spk, out=out, table=table, piece=piece)
+        eng.forward_host(feat, spk, out=out, table=table, piece=piece or None)
         dt = (time.perf_counter() - t0) * 1e3
+    sizes = piece_schedule(n, eng.max_frames) if not piece else [min(piece, n - f) for f in range(0, n, piece)]
     # instrumented repeat: events after each piece's regress (compute stream) and after each copy
     host = eng._host
     marks = []
@@ -33,9 +35,9 @@ for piece in [int(a) for a in sys.argv[1:]] or [8192, 4096, 2048]:
     start.record()
     f0 = 0
     evs = []
-    while f0 < n:
-        f1 = min(n, f0 + piece)
-        eng.forward_host(feat[f0:f1], spk[f0:f1], out=out[f0:f1], table=(table[0][f0:f1], table[1][f0:f1], table[2]), piece=piece, wait=False)
+    for m in sizes:
+        f1 = f0 + m
+        eng.forward_host(feat[f0:f1], spk[f0:f1], out=out[f0:f1], table=(table[0][f0:f1], table[1][f0:f1], table[2]), piece=m, wait=False)
         ec = torch.cuda.Event(enable_timing=True); ec.record()
         ed = torch.cuda.Event(enable_timing=True); ed.record(host.copy_stream)
         evs.append((f1 - f0, ec, ed))
