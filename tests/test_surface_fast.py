@@ -269,20 +269,20 @@ def test_evaluate_in_launch_groups_is_the_clip_by_clip_loop(tmp_path, synth_sd):
 
 
 def test_default_piece_schedule_is_bitwise(eng):
-    """Calls larger than max_frames take the ramp schedule of Engine.forward_host (small first piece, max_frames-sized ones, halving
-    pieces at the end: sdfa_amd/engine.py piece_schedule); the rows do not depend on it."""
+    """Calls larger than max_frames take Engine.forward_host's default schedule (sdfa_amd/engine.py piece_schedule: uniform pieces of
+    4096 frames, the measured optimum of the kernels-then-copy pipeline); the rows do not depend on it."""
     from sdfa_amd.engine import piece_schedule
-    assert piece_schedule(20352, 8192) == [2048, 8192, 4096, 2432, 2048, 1024, 512] and piece_schedule(636, 8192) == [636]
+    assert piece_schedule(20352, 8192) == [4096] * 4 + [3968] and piece_schedule(636, 8192) == [636] and piece_schedule(8192, 8192) == [8192]
     for n, big in ((8193, 8192), (100000, 8192), (3000, 1024), (1, 8), (1025, 1024)):
         s = piece_schedule(n, big)
-        assert sum(s) == n and all(0 < x <= big for x in s) and s[0] <= 2048
+        assert sum(s) == n and all(0 < x <= min(big, 4096) for x in s)
     sr = 16000
     feat, _, counts = eng.mel_frontend([synth.make_pcm(50 + i, int(s * sr)) for i, s in enumerate((10.0, 6.5, 3.0, 4.2))], sr)
     n = feat.shape[0]
     assert n > 2 * eng.max_frames
     spk = torch.from_numpy(np.repeat(np.asarray([1, 2, 3, 4], np.int64), counts))
     ref, *_ = eng.forward(feat, spk)
-    got = eng.forward_host(feat, spk, table=eng.last_frame_table)                      # default schedule: several pieces of different sizes
+    got = eng.forward_host(feat, spk, table=eng.last_frame_table)                      # default schedule: several pieces
     assert torch.equal(got, ref.cpu())
     got2 = eng.forward_host(feat, spk, table=eng.last_frame_table, ensemble=False, piece=300)
     assert torch.equal(got2, got)

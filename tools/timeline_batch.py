@@ -18,7 +18,7 @@ n = feat.shape[0]
 spk = torch.full((n,), 2, dtype=torch.int64, device="cuda")
 out = torch.empty((n, eng.out_dim), dtype=torch.float32, pin_memory=True)
 from sdfa_amd.engine import piece_schedule
-for piece in [int(a) for a in sys.argv[1:]] or [8192, 4096, 2048, 0]:      # 0 = the default ramp schedule
+for piece in [int(a) for a in sys.argv[1:]] or [8192, 4096, 2048, 0]:      # 0 = the default schedule (piece_schedule)
     for rep in range(3):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
