@@ -364,7 +364,7 @@ class Engine(FrontendOnly):
     def forward_host(self, feat, speaker_id, out=None, table=None, piece=None, wait=True, want_z=False, ops_key=None, ensemble=False, z=None):
         """The whole model for `n` frames with the output rows delivered to PINNED HOST memory: rows (n, out_dim) as a CPU
         tensor (`.numpy()` is a view).  Frames are processed in pieces of `piece` frames (default: `piece_schedule` -- one piece up to
-        max_frames, otherwise pieces of 4096 frames); piece i's rows
+        max_frames, otherwise pieces of 3072 frames); piece i's rows
         are copied device -> host on a copy stream while piece i+1 computes (two device staging buffers), so for more than one
         piece the PCIe transfer hides behind the kernels.  This is what SaberSpeechDrivenAnimation._feature_to_anime
         (speech_anime/model/model.py:428-489) does with `.cpu().numpy()` per batch of 100 frames.
@@ -455,14 +455,14 @@ class Engine(FrontendOnly):
         return float(v)
 
 
-def piece_schedule(n, big, many=4096):
+def piece_schedule(n, big, many=3072):
     """Piece sizes of a pinned-output call of `n` frames (Engine.forward_host).  One piece while it fits `big` (= max_frames: the rows
     then also stay on the device, Engine.last_device_rows).  Otherwise the call is a two-stage pipeline -- kernels, then the device ->
     host copy of the piece's rows on ONE copy engine -- whose length is  max over k of (kernels of pieces 0..k + copies of pieces k..last).
     With 359 KB rows at 57 GB/s a frame's copy (6.3 us) is a little shorter than its kernels (7.3 us in pieces of 8192 frames, 7.7 in
     4096, 8.6 in 2048), so the call is  all kernels + the LAST piece's copy,  unless the first piece is so large that
     first kernels + all copies  is longer.  Measured on 32 x 10 s (tools/timeline_batch.py): uniform 8192 -> 199 ms (62 ms before
-    the first copy can start), 4096 -> 184 ms, 2048 -> 189 ms (kernel efficiency lost), and a ramp (small first piece, large middle
+    the first copy can start), 4096 -> 184 ms, 3072 -> 178 ms, 2048 -> 189 ms (kernel efficiency lost), and a ramp (small first piece, large middle
     ones, halving pieces at the end) 196 ms: the copies of the large pieces queue in front of the small pieces' copies, and with two
     staging buffers the small pieces' regressor waits for them.  So: uniform pieces of `many` frames.  Frames are independent: the
     rows do not depend on the schedule (bitwise: tests/test_surface_fast.py)."""

@@ -270,12 +270,12 @@ def test_evaluate_in_launch_groups_is_the_clip_by_clip_loop(tmp_path, synth_sd):
 
 def test_default_piece_schedule_is_bitwise(eng):
     """Calls larger than max_frames take Engine.forward_host's default schedule (sdfa_amd/engine.py piece_schedule: uniform pieces of
-    4096 frames, the measured optimum of the kernels-then-copy pipeline); the rows do not depend on it."""
+    3072 frames, the measured optimum of the kernels-then-copy pipeline); the rows do not depend on it."""
     from sdfa_amd.engine import piece_schedule
-    assert piece_schedule(20352, 8192) == [4096] * 4 + [3968] and piece_schedule(636, 8192) == [636] and piece_schedule(8192, 8192) == [8192]
+    assert piece_schedule(20352, 8192) == [3072] * 6 + [1920] and piece_schedule(636, 8192) == [636] and piece_schedule(8192, 8192) == [8192]
     for n, big in ((8193, 8192), (100000, 8192), (3000, 1024), (1, 8), (1025, 1024)):
         s = piece_schedule(n, big)
-        assert sum(s) == n and all(0 < x <= min(big, 4096) for x in s)
+        assert sum(s) == n and all(0 < x <= min(big, 3072) for x in s)
     sr = 16000
     feat, _, counts = eng.mel_frontend([synth.make_pcm(50 + i, int(s * sr)) for i, s in enumerate((10.0, 6.5, 3.0, 4.2))], sr)
     n = feat.shape[0]
