@@ -397,7 +397,10 @@ class Engine(FrontendOnly):
         if self._host is None:
             self._host = HostPipeline(self)
         if piece is None:
-            sizes = piece_schedule(n, max(1, self.max_frames // (2 if ensemble else 1)))      # a piece holds both passes of its frames
+            # a piece holds both passes of its frames; short rows (the offsets head: 60 KB, 1 us of copy per frame) hide behind any
+            # piece's kernels, so they keep the kernel-efficient max_frames-sized pieces
+            big = max(1, self.max_frames // (2 if ensemble else 1))
+            sizes = piece_schedule(n, big, many=3072 if self.out_dim * 4 > 150_000 else big)
         else:
             p = max(1, int(piece) // (2 if ensemble else 1))
             sizes = [min(p, n - f0) for f0 in range(0, n, p)]
