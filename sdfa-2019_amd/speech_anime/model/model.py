@@ -189,7 +189,7 @@ class SaberSpeechDrivenAnimation:
         # The reference keeps the features of the LAST signal (model.py:364-367,409-416): the same audio with another speaker does
         # not recompute the front end.  Here everything up to the encoder output z is speaker-independent, so the one-entry cache
         # holds z: a speaker sweep over one clip re-runs only the regressor (bitwise the full call: same z, same kernels after it).
-        key = (sr, int(ensembling_ms) if ensemble else 0)
+        key = (sr, int(ensembling_ms) if ensemble else 0, eng.precision)
         c = getattr(self, "_signal_cache", None)
         if (len(signals) == 1 and c is not None and c["key"] == key and c["signal"].shape == signals[0].shape
                 and np.array_equal(c["signal"], signals[0])):
