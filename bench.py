@@ -72,7 +72,7 @@ def parse():
                     help="clip lengths uniform in [LO, HI] s instead of --seconds (a VOCASET-like stream of sentences)")
     ap.add_argument("--frontend", choices=["gather", "direct"], default="gather",
                     help="gather = each distinct STFT column once + per-frame gather (sdfa_mel_frontend_gather); direct = one FFT per window column")
-    ap.add_argument("--precision", choices=["fp32", "bf16_attention", "bf16x3", "bf16", "bf16x3_attention"], default="fp32",
+    ap.add_argument("--precision", choices=["fp32", "bf16_attention", "bf16x3", "bf16", "bf16x3_attention", "bf16x6"], default="fp32",
                     help="matrix instruction of the headline run (fp32 = the reference's arithmetic; the others are BASELINE configs[3] modes)")
     ap.add_argument("--no-mixed-precision", action="store_true", help="skip the extra split-bf16 (configs[3]) measurement")
     ap.add_argument("--opt", action="append", default=[], help="library tuning switch name=value (A/B runs; sdfa_debug_set_option is THREAD-LOCAL: "
@@ -557,8 +557,10 @@ def main():
         dt_ms = None if a.no_column_sharing else timed(True)[0]
         eng.set_precision("bf16x3_attention")                    # configs[3] literally: only the attention stage on (split-)bf16 MFMA
         dt_a, st_a = timed(False)
+        eng.set_precision("bf16x6")                              # the six-product split: fp32-equivalent products on bf16 MFMA
+        dt_6, st_6 = timed(False)
         eng.set_precision("fp32")
-        mixed = (dt_m, st_m, dt_ms, dt_a, st_a)
+        mixed = (dt_m, st_m, dt_ms, dt_a, st_a, dt_6, st_6)
     # ---- PCIe-inclusive twin (SURVEY 8(d) "report both"): the same K steps with the PCM arriving from pinned host memory inside
     # the step (H2D) and every output row delivered to pinned host memory inside the step (D2H, 359 KB per frame): pieces of
     # `chunk` frames, piece i's copy on a copy stream under piece i+1's kernels (Engine.forward_host), two alternating host
@@ -661,7 +663,8 @@ def main():
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"fp32": "f32", "bf16_attention": "f32 (attention projections bf16)",
                                            "bf16x3": "split-bf16 x3 (fp32 accumulate)", "bf16": "bf16 (fp32 accumulate)",
-                                           "bf16x3_attention": "f32 (attention projections split-bf16 x3)"}[a.precision],
+                                           "bf16x3_attention": "f32 (attention projections split-bf16 x3)",
+                                           "bf16x6": "split-bf16 x6 (three terms per operand, fp32-equivalent products, fp32 accumulate)"}[a.precision],
             "data": "synthetic",
             "config": {"workload": (f"batch={C} x {a.seconds:g} s@{sr} Hz synthetic PCM per GPU -> {a.head} (BASELINE configs[1])"
                                     if not a.ragged_seconds else
@@ -730,7 +733,7 @@ def main():
                 "distinct_column_fraction_last_chunk": round(distinct / (64.0 * last), 4),
                 "stage_ms_per_step": {k: round(v, 3) for k, v in st_s.items()}}
         if mixed is not None:
-            dt_m, st_m, dt_ms, dt_a, st_a = mixed
+            dt_m, st_m, dt_ms, dt_a, st_a, dt_6, st_6 = mixed
             res["mixed_precision"] = {
                 "note": "BASELINE configs[3]: same workload with the frequency LSTM and every GEMM on split-bf16 MFMA (operands as "
                         "hi+lo bf16, three v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate/state/activations; front end, conv "
@@ -742,7 +745,11 @@ def main():
                 "bf16x3_attention": {"note": "configs[3] as worded -- 'bf16 attention with MFMA, fp32 mel front end': ONLY the attention stage "
                                              "(key / query projections, query conv) on v_mfma_f32_32x32x16_bf16 with split-bf16 operands, the rest exact fp32",
                                      "value": round(F_all * a.steps / dt_a, 1), "unit": "frames/s", "ms_per_step": round(dt_a / a.steps * 1e3, 3),
-                                     "attn_proj_ms_per_step": round(st_a.get("attn_proj", 0.0), 3), "attn_proj_ms_per_step_fp32": round(stages.get("attn_proj", 0.0), 3)}}
+                                     "attn_proj_ms_per_step": round(st_a.get("attn_proj", 0.0), 3), "attn_proj_ms_per_step_fp32": round(stages.get("attn_proj", 0.0), 3)},
+                "bf16x6": {"note": "six-product split: operands as three bf16 terms (24 significand bits), six v_mfma_f32_32x32x16_bf16 per product, "
+                                   "the same stages as bf16x3: fp32-equivalent products at 16 / 6 of the fp32 MFMA rate",
+                           "value": round(F_all * a.steps / dt_6, 1), "unit": "frames/s", "ms_per_step": round(dt_6 / a.steps * 1e3, 3),
+                           "stage_ms_per_step": {k: round(v, 3) for k, v in st_6.items()}}}
         if world == 1 and not a.no_cpu_baseline:
             try:
                 cb, gpu_err = cpu_baseline(sr, a.cpu_sample_seconds, eng, sd, a.head)
@@ -751,6 +758,7 @@ def main():
                 if mixed is not None:
                     res["mixed_precision"]["max_abs_dgrad_err_vs_cpu_ref"] = gpu_err("bf16x3")[0]
                     res["mixed_precision"]["bf16x3_attention"]["max_abs_dgrad_err_vs_cpu_ref"] = gpu_err("bf16x3_attention")[0]
+                    res["mixed_precision"]["bf16x6"]["max_abs_dgrad_err_vs_cpu_ref"] = gpu_err("bf16x6")[0]
             except Exception as e:      # the GPU measurement above stands on its own; say what went wrong with the CPU leg
                 res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": None, "nproc": int(os.cpu_count() or 0), "kind": "port",
                                        "sample": f"failed: {e!r}"}

@@ -143,6 +143,8 @@ int64_t     sdfa_model_coef_dim(const sdfa_model *m);         /* 265 (85 scale |
 #define SDFA_PREC_BF16X3 2
 #define SDFA_PREC_BF16 3
 #define SDFA_PREC_BF16X3_ATTENTION 4
+#define SDFA_PREC_BF16X6 5           /* the kernels of SDFA_PREC_BF16X3 with operands as THREE bf16 terms (24 significand bits = fp32's) and six
+                                        partial products per product: fp32-equivalent products at 16 / 6 = 2.7x the fp32 MFMA rate */
 int         sdfa_model_set_precision(sdfa_model *m, int mode);
 int         sdfa_model_precision(const sdfa_model *m);
 

@@ -219,7 +219,7 @@ float bf16_bits_to_float(uint16_t b) {
     return x;
 }
 
-// Frequency-LSTM weights for freq_lstm_bf16_kernel: per direction [plane hi | lo][24 octets][512 gate rows][8] bf16.
+// Frequency-LSTM weights for freq_lstm_bf16_kernel / freq_lstm_bf16x6_kernel: per direction [plane hi | mid | lo][24 octets][512 gate rows][8] bf16.
 // cat = [W_ih | W_hh] rows in torch order, perm = packed gate row -> torch row.  Octets 0..7 are the 64 input features
 // in order; octet 8 + o' (o' = 4w + 2q + hh) holds hidden units 32w+16q+4hh+{0..3} and 32w+16q+8+4hh+{0..3} -- the order
 // in which a lane of the kernel owns its accumulator rows (lstm.hip).
@@ -235,13 +235,16 @@ void pack_freq_lstm_bf16(uint16_t *dst, const float *cat, const int *perm) {
                 }
                 const float x = cat[(size_t)perm[p] * 192 + k];
                 const uint16_t hi = bf16_rne_bits(x);
-                const uint16_t lo = bf16_rne_bits(x - bf16_bits_to_float(hi));
+                const float r1 = x - bf16_bits_to_float(hi);
+                const uint16_t mid = bf16_rne_bits(r1);
+                const uint16_t lo = bf16_rne_bits(r1 - bf16_bits_to_float(mid));
                 dst[((size_t)O * 512 + p) * 8 + e] = hi;
-                dst[((size_t)(24 + O) * 512 + p) * 8 + e] = lo;
+                dst[((size_t)(24 + O) * 512 + p) * 8 + e] = mid;      // the "lo" plane of the three-product split
+                dst[((size_t)(48 + O) * 512 + p) * 8 + e] = lo;       // third term: six-product split only
             }
 }
 
-// Recurrent weights of one BiLSTM direction for time_lstm_bf16_kernel: [plane hi | lo][32 octets][1024 gate rows][8] bf16,
+// Recurrent weights of one BiLSTM direction for time_lstm_bf16_kernel: [plane hi | mid | lo][32 octets][1024 gate rows][8] bf16,
 // the K axis (256 hidden units) in the accumulator-row order of the kernel (same octet rule as above).
 void pack_rec_bf16(uint16_t *dst, const float *whh, const int *perm) {
     for (int o = 0; o < 32; ++o)
@@ -251,9 +254,12 @@ void pack_rec_bf16(uint16_t *dst, const float *whh, const int *perm) {
                 const int k = 32 * w + 16 * q + 4 * hh + (e & 3) + 8 * (e >> 2);
                 const float x = whh[(size_t)perm[p] * 256 + k];
                 const uint16_t hi = bf16_rne_bits(x);
-                const uint16_t lo = bf16_rne_bits(x - bf16_bits_to_float(hi));
+                const float r1 = x - bf16_bits_to_float(hi);
+                const uint16_t mid = bf16_rne_bits(r1);
+                const uint16_t lo = bf16_rne_bits(r1 - bf16_bits_to_float(mid));
                 dst[((size_t)o * 1024 + p) * 8 + e] = hi;
-                dst[((size_t)(32 + o) * 1024 + p) * 8 + e] = lo;
+                dst[((size_t)(32 + o) * 1024 + p) * 8 + e] = mid;
+                dst[((size_t)(64 + o) * 1024 + p) * 8 + e] = lo;
             }
 }
 
@@ -500,7 +506,7 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
     // ---- frequency LSTM: [W_ih | W_hh] concatenated along K, gate rows packed per wave; bias = b_ih + b_hh
     size_t o_flw = pk.add(0), o_flb, o_flwb;
     {
-        o_flwb = pk.add((size_t)2 * 2 * 24 * 512 * 8 / 2);   // bf16 planes, two per float slot
+        o_flwb = pk.add((size_t)2 * 3 * 24 * 512 * 8 / 2);   // two directions x three bf16 planes, two bf16 per float slot
         const auto perm = gate_perm(128);
         const char *suf[2] = {"", "_reverse"};
         std::vector<float> cat((size_t)512 * 192);
@@ -516,7 +522,7 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
                 memcpy(&cat[(size_t)r * 192 + 64], &(*whh)[(size_t)r * 128], 128 * 4);
             }
             size_t o = pack_k4(pk, cat.data(), 512, 192, 192, 0, 192, 512, perm.data());
-            pack_freq_lstm_bf16(reinterpret_cast<uint16_t *>(&pk.buf[o_flwb]) + (size_t)d * 2 * 24 * 512 * 8, cat.data(), perm.data());
+            pack_freq_lstm_bf16(reinterpret_cast<uint16_t *>(&pk.buf[o_flwb]) + (size_t)d * 3 * 24 * 512 * 8, cat.data(), perm.data());
             if (d == 0) first = o;
             else if (o != first + (size_t)48 * 512 * 4) return fail(SDFA_ESTATE, "internal: freq-lstm weights not contiguous");
             for (int p = 0; p < 512; ++p) bias[d * 512 + p] = (*bih)[perm[p]] + (*bhh)[perm[p]];
@@ -537,7 +543,7 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
     size_t o_gx[2], o_tl[2], o_tlb[2], o_tl16[2];
     {
         const auto perm = gate_perm(256);
-        for (int l = 0; l < 2; ++l) o_tlb[l] = pk.add((size_t)2 * 2 * 32 * 1024 * 8 / 2);   // bf16 planes, two per float slot
+        for (int l = 0; l < 2; ++l) o_tlb[l] = pk.add((size_t)2 * 3 * 32 * 1024 * 8 / 2);   // two directions x three bf16 planes, two bf16 per float slot
         for (int l = 0; l < 2; ++l) o_tl16[l] = pk.add((size_t)2 * 16 * 4 * 1024 * 4);      // two directions, 16x16x4 operand order
         const char *suf[2] = {"", "_reverse"};
         for (int l = 0; l < 2; ++l) {
@@ -550,7 +556,7 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
                 if (!wih || !whh) return SDFA_ESTATE;
                 for (int p = 0; p < 1024; ++p) memcpy(&both[((size_t)d * 1024 + p) * Kin], &(*wih)[(size_t)perm[p] * Kin], Kin * 4);
                 size_t o = pack_k4(pk, whh->data(), 1024, 256, 256, 0, 256, 1024, perm.data());
-                pack_rec_bf16(reinterpret_cast<uint16_t *>(&pk.buf[o_tlb[l]]) + (size_t)d * 2 * 32 * 1024 * 8, whh->data(), perm.data());
+                pack_rec_bf16(reinterpret_cast<uint16_t *>(&pk.buf[o_tlb[l]]) + (size_t)d * 3 * 32 * 1024 * 8, whh->data(), perm.data());
                 pack_rec_16x16x4(&pk.buf[o_tl16[l]] + (size_t)d * 16 * 4 * 1024 * 4, whh->data(), perm.data());
                 if (d == 0) first = o;
                 else if (o != first + (size_t)64 * 1024 * 4) return fail(SDFA_ESTATE, "internal: time-lstm weights not contiguous");
@@ -808,6 +814,7 @@ static int stage_terms(const sdfa_model *m, int stage) {
     switch (m->precision) {
     case SDFA_PREC_BF16_ATTENTION: return stage == STAGE_ATTENTION ? 1 : 0;
     case SDFA_PREC_BF16X3_ATTENTION: return stage == STAGE_ATTENTION ? 3 : 0;
+    case SDFA_PREC_BF16X6: return 6;
     case SDFA_PREC_BF16X3: return 3;
     case SDFA_PREC_BF16: return 1;
     default: return 0;
@@ -816,7 +823,7 @@ static int stage_terms(const sdfa_model *m, int stage) {
 
 int sdfa_model_set_precision(sdfa_model *m, int mode) {
     if (!m) return fail(SDFA_EINVAL, "null model");
-    if (mode < SDFA_PREC_FP32 || mode > SDFA_PREC_BF16X3_ATTENTION) return fail(SDFA_EINVAL, "unknown precision mode %d", mode);
+    if (mode < SDFA_PREC_FP32 || mode > SDFA_PREC_BF16X6) return fail(SDFA_EINVAL, "unknown precision mode %d", mode);
     m->precision = mode;
     return SDFA_OK;
 }

@@ -371,6 +371,124 @@ hipError_t launch_bf16(const GemmArgs &a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Six-product split (SDFA_PREC_BF16X6, round 4): operands as THREE bf16 terms, x = hi + mid + lo (24 significand bits = fp32's), and
+// every product as the six partial products down to 2^-16 of the leading one,
+//   a*b ~= a_hi*b_lo + a_mid*b_mid + a_lo*b_hi + a_hi*b_mid + a_mid*b_hi + a_hi*b_hi      (smallest first; the three dropped terms are
+// below 2^-24 relative), i.e. fp32-equivalent products at 16 / 6 = 2.7x the fp32 MFMA rate.  Same tile, staging and epilogue as
+// gemm_bf16_kernel; three planes per operand and buffer = 96 KiB of dynamic LDS, one workgroup per CU.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split8x3(const float4 &x0, const float4 &x1, bf16x8 &hi, bf16x8 &mid, bf16x8 &lo) {
+    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 hb = (__bf16)x[e];
+        const float r1 = x[e] - (float)hb;
+        const __bf16 mb = (__bf16)r1;
+        hi[e] = hb;
+        mid[e] = mb;
+        lo[e] = (__bf16)(r1 - (float)mb);
+    }
+}
+
+template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
+__global__ __launch_bounds__(256) void gemm_bf16x6_kernel(GemmArgs a) {
+    extern __shared__ bf16x8 s6[];      // [2 buffers][P | Q][3 planes][4 octets][128]
+    auto S6 = [&](int buf, int pq, int plane, int oct) { return s6 + (((size_t)(buf * 2 + pq) * 3 + plane) * 4 + oct) * 128; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave >> 1, wq = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const int64_t ntp = a.Ppad / TP, bid = blockIdx.x;
+    const int64_t p0 = (bid % ntp) * TP, q0 = (bid / ntp) * TQ;
+    if (a.q_limit && q0 >= *a.q_limit) return;
+
+    const float4 *__restrict__ P = reinterpret_cast<const float4 *>(a.P);
+    const float4 *__restrict__ Q = reinterpret_cast<const float4 *>(a.Q);
+    const int seg_kq = a.seg_k / 4, nstage = a.K / 32;
+
+    float4 rp[2][2], rq[2][2];   // [item][quad of the k-group]
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#define B6_GLOAD(st)                                                                              \
+    _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                            \
+        const int idx = it * 256 + tid, g = idx >> 7, c = idx & 127, gkq = (st)*8 + 2 * g;        \
+        const int seg = gkq / seg_kq, kin = gkq - seg * seg_kq;                                   \
+        rp[it][0] = P[(int64_t)gkq * a.ldp + p0 + c];                                             \
+        rp[it][1] = P[(int64_t)(gkq + 1) * a.ldp + p0 + c];                                       \
+        if (a.q_tile_major) {                                                                     \
+            rq[it][0] = Q[((q0 >> 7) * (int64_t)a.q_slab_rows + gkq) * 128 + c];                      \
+            rq[it][1] = Q[((q0 >> 7) * (int64_t)a.q_slab_rows + gkq + 1) * 128 + c];                  \
+        } else {                                                                                  \
+            rq[it][0] = Q[(int64_t)kin * a.ldq + (int64_t)seg * a.seg_col + q0 + c];              \
+            rq[it][1] = Q[(int64_t)(kin + 1) * a.ldq + (int64_t)seg * a.seg_col + q0 + c];        \
+        }                                                                                         \
+    }
+#define B6_LSTORE(buf)                                                                            \
+    _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                            \
+        const int idx = it * 256 + tid, g = idx >> 7, c = idx & 127;                              \
+        bf16x8 hi, mid, lo;                                                                       \
+        split8x3(rp[it][0], rp[it][1], hi, mid, lo); S6(buf, 0, 0, g)[c] = hi; S6(buf, 0, 1, g)[c] = mid; S6(buf, 0, 2, g)[c] = lo; \
+        split8x3(rq[it][0], rq[it][1], hi, mid, lo); S6(buf, 1, 0, g)[c] = hi; S6(buf, 1, 1, g)[c] = mid; S6(buf, 1, 2, g)[c] = lo; \
+    }
+
+    B6_GLOAD(0)
+    B6_LSTORE(0)
+    __syncthreads();
+    for (int st = 0; st < nstage; ++st) {
+        const int buf = st & 1;
+        const bool reload = st + 1 < nstage;
+        if (reload) { B6_GLOAD(st + 1) }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {   // two k-steps of 16
+            bf16x8 ap[3][2], bq[3][2];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    ap[pl][i] = S6(buf, 0, pl, 2 * m + h)[wp * 64 + i * 32 + l31];
+                    bq[pl][i] = S6(buf, 1, pl, 2 * m + h)[wq * 64 + i * 32 + l31];
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0][i], bq[2][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1][i], bq[1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2][i], bq[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0][i], bq[1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1][i], bq[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0][i], bq[0][j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (reload) { B6_LSTORE(buf ^ 1) }
+        __syncthreads();
+    }
+#undef B6_GLOAD
+#undef B6_LSTORE
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            store_tile<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, acc[i][j], p0 + wp * 64 + i * 32, q0 + wq * 64 + j * 32 + l31, h);
+}
+
+template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
+hipError_t launch_bf16x6(const GemmArgs &a, hipStream_t s) {
+    const size_t lds = (size_t)2 * 2 * 3 * 4 * 128 * sizeof(bf16x8);   // 96 KiB
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16x6_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int64_t nblk = (a.Ppad / TP) * (a.Qpad / TQ);
+    hipLaunchKernelGGL((gemm_bf16x6_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>), dim3((unsigned)nblk), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // bf16-MFMA GEMM, 256 x 256 tile (mixed-precision modes, P and Q multiples of 256): with the matrix work cut 5-16x the
 // 128 x 128 kernel above is bound by its operand stream (32 FLOP per staged byte: the 8192-deep frequency projection
 // took 44 ms in every mode); this tile stages half the bytes per FLOP.  8 waves (2 x 4, each 128 x 64 = 4 x 2 MFMA
@@ -899,6 +1017,7 @@ thread_local int g_sdfa_gemm_variant = 0;
 template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
 hipError_t launch_any(const GemmArgs &a, hipStream_t s) {
     const int variant = (g_sdfa_gemm_variant == 2 || g_sdfa_gemm_variant == 6 || g_sdfa_gemm_variant == 10 || g_sdfa_gemm_variant == 11) ? 0 : g_sdfa_gemm_variant;   // 2 / 6 / 10 / 11 only steer the tile choice of the LDS-tiled kernel (launch)
+    if (a.terms == 6) return launch_bf16x6<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);   // six-product split: one tile shape
     if (a.terms) {   // mixed-precision modes
         const bool big = a.Ppad % 256 == 0 && a.Qpad % 256 == 0 && variant != 7;
         if (a.terms == 1) return big ? launch_bf16_big<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 1>(a, s) : launch_bf16<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 1>(a, s);

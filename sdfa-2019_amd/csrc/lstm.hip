@@ -557,6 +557,165 @@ __device__ __forceinline__ void split_octet(const float4 &x0, const float4 &x1, 
     }
 }
 
+// x = hi + mid + lo, three bf16 terms (24 significand bits): the six-product split (SDFA_PREC_BF16X6)
+__device__ __forceinline__ void split_octet3(const float4 &x0, const float4 &x1, bf16x8 &hi, bf16x8 &mid, bf16x8 &lo) {
+    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 hb = (__bf16)x[e];
+        const float r1 = x[e] - (float)hb;
+        const __bf16 mb = (__bf16)r1;
+        hi[e] = hb;
+        mid[e] = mb;
+        lo[e] = (__bf16)(r1 - (float)mb);
+    }
+}
+
+// Packed bf16 weights hold BF16_PLANES = 3 planes per direction (hi, mid = bf16(x - hi), lo = bf16(x - hi - mid)); TERMS 1 reads the first,
+// TERMS 3 the first two (its "lo" is this mid: same bits as before the third plane existed), the six-product kernels all three.
+constexpr int BF16_PLANES = 3;
+
+// ------------------------------------------------------------------ frequency LSTM, six-product split (SDFA_PREC_BF16X6, round 4)
+// The recurrence of freq_lstm_bf16_kernel with operands as three bf16 terms and six partial products per product, smallest first:
+//   W_lo*b_hi, W_mid*b_mid, W_mid*b_hi, W_hi*b_lo, W_hi*b_mid, W_hi*b_hi        (dropped: the three below 2^-24 of the leading one)
+// -- fp32-equivalent products at 16 / 6 = 2.7x the fp32 MFMA rate.  The three weight planes of a k-step are streamed one after the
+// other (lo, mid, hi), each requested while the previous one multiplies, so only two planes are live; x_f and h are split into three
+// planes by the lanes that stage / produce them.  98 KiB of dynamic LDS, one workgroup per CU.
+template <bool SHARED>
+__global__ __launch_bounds__(256) void freq_lstm_bf16x6_kernel(FreqLstmArgs a) {
+    extern __shared__ bf16x8 sF6[];
+    bf16x8 *const sHp = sF6;                                   // [3 planes][16 octets][64 sequences]
+    bf16x8 *const sXp = sF6 + 3 * 16 * 64;                     // [2 buffers][3 planes][8 octets][64]
+    float *const sBias = reinterpret_cast<float *>(sF6 + 3 * 16 * 64 + 2 * 3 * 8 * 64);
+#define F6_H(pl, o) (sHp + ((pl) * 16 + (o)) * 64)
+#define F6_X(buf, pl, o) (sXp + (((buf) * 3 + (pl)) * 8 + (o)) * 64)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int dir = (blockIdx.x >> 3) & 1;
+    const int64_t m0 = (int64_t)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) * 64;
+    if (SHARED && m0 >= *a.col_limit) return;
+
+    const float4 *__restrict__ X3 = reinterpret_cast<const float4 *>(a.X3);
+    const bf16x8 *__restrict__ W0 = reinterpret_cast<const bf16x8 *>(a.Wb) + (size_t)dir * BF16_PLANES * 24 * 512 + wave * 128 + l31;
+#define F6_W(pl, ks, gt) W0[((size_t)(pl) * 24 + 2 * (ks) + h) * 512 + (gt) * 32]
+    float4 *__restrict__ HF = reinterpret_cast<float4 *>(a.HF);
+
+    sBias[tid] = a.bias[dir * 512 + tid];
+    sBias[256 + tid] = a.bias[dir * 512 + 256 + tid];
+
+    float4 xr0, xr1, xr2, xr3;
+#define F6_XLOAD(f)                                                                                \
+    {                                                                                              \
+        const int o0 = tid >> 6, o1 = 4 + (tid >> 6), col = tid & 63;                              \
+        xr0 = X3[(int64_t)((f)*16 + 2 * o0) * a.Mc + m0 + col];                                    \
+        xr1 = X3[(int64_t)((f)*16 + 2 * o0 + 1) * a.Mc + m0 + col];                                \
+        xr2 = X3[(int64_t)((f)*16 + 2 * o1) * a.Mc + m0 + col];                                    \
+        xr3 = X3[(int64_t)((f)*16 + 2 * o1 + 1) * a.Mc + m0 + col];                                \
+    }
+#define F6_XSTORE(buf)                                                                             \
+    {                                                                                              \
+        const int o0 = tid >> 6, o1 = 4 + (tid >> 6), col = tid & 63;                              \
+        bf16x8 hi, mid, lo;                                                                        \
+        split_octet3(xr0, xr1, hi, mid, lo); F6_X(buf, 0, o0)[col] = hi; F6_X(buf, 1, o0)[col] = mid; F6_X(buf, 2, o0)[col] = lo; \
+        split_octet3(xr2, xr3, hi, mid, lo); F6_X(buf, 0, o1)[col] = hi; F6_X(buf, 1, o1)[col] = mid; F6_X(buf, 2, o1)[col] = lo; \
+    }
+    F6_XLOAD(dir ? 31 : 0)
+    F6_XSTORE(0)
+    __syncthreads();
+
+    f32x16 c[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[j][r] = 0.f;
+
+    for (int s = 0; s < 32; ++s) {
+        const int f = dir ? 31 - s : s;
+        const int cur = s & 1;
+
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 b = *reinterpret_cast<const float4 *>(&sBias[wave * 128 + gt * 32 + 8 * g + 4 * h]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[gt][j][4 * g + 0] = b.x; acc[gt][j][4 * g + 1] = b.y;
+                    acc[gt][j][4 * g + 2] = b.z; acc[gt][j][4 * g + 3] = b.w;
+                }
+            }
+        const int nks = s > 0 ? 12 : 4;      // k-steps of 16: 0..3 = x_f, 4..11 = h_{s-1} (skipped on the first step)
+        bf16x8 wa[4], wb[4];
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt) wa[gt] = F6_W(2, 0, gt);                 // lo plane of k-step 0
+#pragma unroll 1
+        for (int ks = 0; ks < nks; ++ks) {
+            bf16x8 b[3][2];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    b[pl][j] = ks < 4 ? F6_X(cur, pl, 2 * ks + h)[j * 32 + l31] : F6_H(pl, 2 * (ks - 4) + h)[j * 32 + l31];
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt) wb[gt] = F6_W(1, ks, gt);            // mid plane, requested while lo multiplies
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[gt][j] = MFMA_BF16(wa[gt], b[0][j], acc[gt][j]);      // lo * hi
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt) wa[gt] = F6_W(0, ks, gt);            // hi plane, requested while mid multiplies
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[gt][j] = MFMA_BF16(wb[gt], b[1][j], acc[gt][j]);                              // mid * mid
+                    acc[gt][j] = MFMA_BF16(wb[gt], b[0][j], acc[gt][j]);                              // mid * hi
+                }
+            const int kn = ks + 1 < nks ? ks + 1 : 0;                           // branch-free: the last request is dropped
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt) wb[gt] = F6_W(2, kn, gt);            // next k-step's lo plane, requested while hi multiplies
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[gt][j] = MFMA_BF16(wa[gt], b[2][j], acc[gt][j]);                              // hi * lo
+                    acc[gt][j] = MFMA_BF16(wa[gt], b[1][j], acc[gt][j]);                              // hi * mid
+                    acc[gt][j] = MFMA_BF16(wa[gt], b[0][j], acc[gt][j]);                              // hi * hi
+                }
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt) wa[gt] = wb[gt];
+        }
+        __syncthreads();   // every wave has finished reading sH / sX[cur]
+        if (s + 1 < 32) { F6_XLOAD(dir ? 30 - s : s + 1) }   // lands while the cell update runs
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float4 hq[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                lstm_cell_quad<true>(acc[0][j], acc[1][j], acc[2][j], acc[3][j], c[j], g, hq[g]);
+                HF[((m0 >> 7) * (int64_t)HF_SLAB_ROWS + (f * 64 + dir * 32 + 8 * wave + 2 * g + h)) * 128 + (m0 & 127) + j * 32 + l31] = hq[g];
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                bf16x8 hi, mid, lo;
+                split_octet3(hq[2 * q], hq[2 * q + 1], hi, mid, lo);
+                F6_H(0, 4 * wave + 2 * q + h)[j * 32 + l31] = hi;
+                F6_H(1, 4 * wave + 2 * q + h)[j * 32 + l31] = mid;
+                F6_H(2, 4 * wave + 2 * q + h)[j * 32 + l31] = lo;
+            }
+        }
+        if (s + 1 < 32) { F6_XSTORE(cur ^ 1) }
+        __syncthreads();
+    }
+#undef F6_XLOAD
+#undef F6_XSTORE
+#undef F6_W
+#undef F6_H
+#undef F6_X
+}
+
 template <bool SHARED, int TERMS>
 __global__ __launch_bounds__(256, 2) void freq_lstm_bf16_kernel(FreqLstmArgs a) {
     constexpr bool LO = TERMS > 1;
@@ -573,7 +732,7 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_bf16_kernel(FreqLstmArgs a) 
 
     const float4 *__restrict__ X3 = reinterpret_cast<const float4 *>(a.X3);
     // per direction: [plane hi | lo][24 octets][512 gate rows]
-    const bf16x8 *__restrict__ Wh = reinterpret_cast<const bf16x8 *>(a.Wb) + (size_t)dir * 2 * 24 * 512 + wave * 128 + l31;
+    const bf16x8 *__restrict__ Wh = reinterpret_cast<const bf16x8 *>(a.Wb) + (size_t)dir * BF16_PLANES * 24 * 512 + wave * 128 + l31;
     const bf16x8 *__restrict__ Wl = Wh + 24 * 512;
     float4 *__restrict__ HF = reinterpret_cast<float4 *>(a.HF);
 
@@ -1255,8 +1414,8 @@ __global__ __launch_bounds__(256) void time_lstm_split16_kernel(TimeLstmArgs a, 
 // 32w+16q+4h+{0..3} and 32w+16q+8+4h+{0..3}; the host packs W_hh's K axis in that order (api.cpp: pack_rec_bf16).
 template <int NT, int TERMS>
 __global__ __launch_bounds__(512, 2) void time_lstm_bf16_kernel(TimeLstmArgs a) {
-    constexpr bool LO = TERMS > 1;
-    constexpr int NPL = LO ? 2 : 1, BT = 32 * NT;
+    constexpr bool LO = TERMS > 1, X6 = TERMS == 6;      // X6: the six-product split (see freq_lstm_bf16x6_kernel), NT = 1 only (96 KiB of LDS)
+    constexpr int NPL = X6 ? 3 : (LO ? 2 : 1), BT = 32 * NT;
     extern __shared__ bf16x8 sHb[];   // [2 buffers][NPL planes][32 octets][BT sequences]
     auto SH = [&](int buf, int plane) { return sHb + ((size_t)(buf * NPL + plane) * 32) * BT; };
 
@@ -1267,7 +1426,7 @@ __global__ __launch_bounds__(512, 2) void time_lstm_bf16_kernel(TimeLstmArgs a) 
 
     const float4 *__restrict__ GX = reinterpret_cast<const float4 *>(a.GX);
     // per direction: [plane hi | lo][32 octets][1024 gate rows]
-    const bf16x8 *__restrict__ Wh = reinterpret_cast<const bf16x8 *>(a.Wb) + (size_t)dir * 2 * 32 * 1024 + wave * 128 + l31;
+    const bf16x8 *__restrict__ Wh = reinterpret_cast<const bf16x8 *>(a.Wb) + (size_t)dir * BF16_PLANES * 32 * 1024 + wave * 128 + l31;
     const bf16x8 *__restrict__ Wl = Wh + 32 * 1024;
     float4 *__restrict__ H = reinterpret_cast<float4 *>(a.H);
 
@@ -1295,7 +1454,50 @@ __global__ __launch_bounds__(512, 2) void time_lstm_bf16_kernel(TimeLstmArgs a) 
         const int64_t mcol = (int64_t)t * a.Nc + n0 + l31;
         const int cur = s & 1;
 
-        if (s > 0) {
+        if (X6 && s > 0) {      // lo, mid, hi plane of each k-step in turn, the next one requested while this one multiplies
+#define T6_W(pl, ks, gt) Wh[((size_t)(pl) * 32 + 2 * (ks) + h) * 1024 + (gt) * 32]
+            bf16x8 wa[4], wb[4];
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt) wa[gt] = T6_W(2, 0, gt);
+#pragma unroll 1
+            for (int ks = 0; ks < 16; ++ks) {
+                bf16x8 b[3][NT];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) b[pl][j] = SH(cur, pl)[(2 * ks + h) * BT + j * 32 + l31];
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt) wb[gt] = T6_W(1, ks, gt);
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[gt][j] = MFMA_BF16(wa[gt], b[0][j], acc[gt][j]);      // lo * hi
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt) wa[gt] = T6_W(0, ks, gt);
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        acc[gt][j] = MFMA_BF16(wb[gt], b[1][j], acc[gt][j]);                              // mid * mid
+                        acc[gt][j] = MFMA_BF16(wb[gt], b[0][j], acc[gt][j]);                              // mid * hi
+                    }
+                const int kn = ks + 1 < 16 ? ks + 1 : 0;
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt) wb[gt] = T6_W(2, kn, gt);
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        acc[gt][j] = MFMA_BF16(wa[gt], b[2][j], acc[gt][j]);                              // hi * lo
+                        acc[gt][j] = MFMA_BF16(wa[gt], b[1][j], acc[gt][j]);                              // hi * mid
+                        acc[gt][j] = MFMA_BF16(wa[gt], b[0][j], acc[gt][j]);                              // hi * hi
+                    }
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt) wa[gt] = wb[gt];
+            }
+#undef T6_W
+        }
+        if (!X6 && s > 0) {
             bf16x8 whn[4];
 #pragma unroll
             for (int gt = 0; gt < 4; ++gt) whn[gt] = Wh[h * 1024 + gt * 32];
@@ -1348,10 +1550,18 @@ __global__ __launch_bounds__(512, 2) void time_lstm_bf16_kernel(TimeLstmArgs a) 
             }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                bf16x8 hi, lo;
-                split_octet(hq[2 * q], hq[2 * q + 1], hi, lo);
-                SH(cur ^ 1, 0)[(4 * wave + 2 * q + h) * BT + j * 32 + l31] = hi;
-                if (LO) SH(cur ^ 1, NPL - 1)[(4 * wave + 2 * q + h) * BT + j * 32 + l31] = lo;
+                if (X6) {
+                    bf16x8 hi, mid, lo;
+                    split_octet3(hq[2 * q], hq[2 * q + 1], hi, mid, lo);
+                    SH(cur ^ 1, 0)[(4 * wave + 2 * q + h) * BT + j * 32 + l31] = hi;
+                    SH(cur ^ 1, 1)[(4 * wave + 2 * q + h) * BT + j * 32 + l31] = mid;
+                    SH(cur ^ 1, NPL - 1)[(4 * wave + 2 * q + h) * BT + j * 32 + l31] = lo;
+                } else {
+                    bf16x8 hi, lo;
+                    split_octet(hq[2 * q], hq[2 * q + 1], hi, lo);
+                    SH(cur ^ 1, 0)[(4 * wave + 2 * q + h) * BT + j * 32 + l31] = hi;
+                    if (LO) SH(cur ^ 1, NPL - 1)[(4 * wave + 2 * q + h) * BT + j * 32 + l31] = lo;
+                }
             }
         }
         __syncthreads();   // h_s complete in the other buffer before anyone reads it; this one free for step s+1's writes
@@ -1430,6 +1640,13 @@ static hipError_t launch_freq(const FreqLstmArgs &a, hipStream_t s) {
 template <bool SHARED>
 static hipError_t launch_freq_bf16(const FreqLstmArgs &a, hipStream_t s) {
     if (!a.Wb) return hipErrorInvalidValue;
+    if (a.terms == 6) {
+        const size_t lds = (size_t)(3 * 16 * 64 + 2 * 3 * 8 * 64) * sizeof(bf16x8) + 512 * sizeof(float);      // 98 KiB
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(freq_lstm_bf16x6_kernel<SHARED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((freq_lstm_bf16x6_kernel<SHARED>), dim3((unsigned)(a.Mc / 64 * 2)), dim3(256), lds, s, a);
+        return hipGetLastError();
+    }
     if (a.terms == 1)
         hipLaunchKernelGGL((freq_lstm_bf16_kernel<SHARED, 1>), dim3((unsigned)(a.Mc / 64 * 2)), dim3(256), 0, s, a);
     else
@@ -1456,7 +1673,7 @@ static hipError_t launch_time(const TimeLstmArgs &a, hipStream_t s) {
 
 template <int NT, int TERMS>
 static hipError_t launch_time_bf16(const TimeLstmArgs &a, hipStream_t s) {
-    const size_t lds = (size_t)2 * (TERMS > 1 ? 2 : 1) * 32 * 32 * NT * sizeof(bf16x8);   // 128 KiB (NT 2, split) ... 32 KiB
+    const size_t lds = (size_t)2 * (TERMS == 6 ? 3 : (TERMS > 1 ? 2 : 1)) * 32 * 32 * NT * sizeof(bf16x8);   // 128 KiB (NT 2, split) ... 32 KiB; 96 KiB (NT 1, six-product)
     {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(time_lstm_bf16_kernel<NT, TERMS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1536,6 +1753,7 @@ static hipError_t launch_time_any(const TimeLstmArgs &a, hipStream_t s) {
     }
     if (a.terms) {
         if (!a.Wb || MAP) return hipErrorInvalidValue;      // the bf16 recurrences read un-shared input projections (api.cpp expands first)
+        if (a.terms == 6) return launch_time_bf16<1, 6>(a, s);      // three planes of h: 32-frame tiles only (96 KiB of LDS)
         if (a.terms == 1) return big ? launch_time_bf16<2, 1>(a, s) : launch_time_bf16<1, 1>(a, s);
         return big ? launch_time_bf16<2, 3>(a, s) : launch_time_bf16<1, 3>(a, s);
     }

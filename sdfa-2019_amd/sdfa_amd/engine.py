@@ -125,7 +125,7 @@ class FrontendOnly:
 class Engine(FrontendOnly):
     """One model replica on one GPU."""
 
-    PRECISIONS = {"fp32": 0, "bf16_attention": 1, "bf16x3": 2, "bf16": 3, "bf16x3_attention": 4}      # include/sdfa_hip.h SDFA_PREC_*
+    PRECISIONS = {"fp32": 0, "bf16_attention": 1, "bf16x3": 2, "bf16": 3, "bf16x3_attention": 4, "bf16x6": 5}      # include/sdfa_hip.h SDFA_PREC_*
 
     AUTOTUNE_MIN_FRAMES = 2048      # below this a launch is too short for the choice to matter (or to be measured)
 

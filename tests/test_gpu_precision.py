@@ -23,7 +23,9 @@ BUDGET = 1e-4      # north_star: max |dgrad - reference| on fp32 dgrad
 # fail if that ever changes, so the documented outcome of the sweep cannot go stale.
 # Round 4: "bf16x3_attention" -- configs[3]'s literal wording ("bf16 attention with MFMA ...") with a point INSIDE the budget: the
 # attention stage on bf16 MFMA with split-bf16 (hi + lo) operands, the rest exact fp32.
-BOUNDS = {"fp32": (5e-6, None), "bf16x3": (2e-5, None), "bf16x3_attention": (5e-6, None), "bf16_attention": (2e-3, BUDGET), "bf16": (2e-2, BUDGET)}
+# "bf16x6": the six-product split (three bf16 terms per operand, 24 significand bits): fp32-equivalent products on bf16 MFMA, held to
+# the SAME bound as exact fp32.
+BOUNDS = {"fp32": (5e-6, None), "bf16x6": (5e-6, None), "bf16x3": (2e-5, None), "bf16x3_attention": (5e-6, None), "bf16_attention": (2e-3, BUDGET), "bf16": (2e-2, BUDGET)}
 
 
 def _t(x):
@@ -54,7 +56,7 @@ def _errors(eng, golden):
 def test_precision_sweep(eng, golden):
     table = {}
     try:
-        for mode in ("fp32", "bf16x3_attention", "bf16_attention", "bf16x3", "bf16"):
+        for mode in ("fp32", "bf16x6", "bf16x3_attention", "bf16_attention", "bf16x3", "bf16"):
             eng.set_precision(mode)
             table[mode] = _errors(eng, golden)
     finally:
@@ -69,7 +71,7 @@ def test_precision_sweep(eng, golden):
         if lo is not None:
             assert worst > lo, (mode, table[mode])
     # more operand bits never hurt
-    assert table["bf16x3"]["dgrad"] < table["bf16"]["dgrad"]
+    assert table["bf16x6"]["dgrad"] < table["bf16x3"]["dgrad"] < table["bf16"]["dgrad"]
 
 
 def test_fp32_results_do_not_depend_on_mode_history(eng, golden):
@@ -84,6 +86,30 @@ def test_fp32_results_do_not_depend_on_mode_history(eng, golden):
     eng.set_precision("fp32")
     c = eng.forward(x, spk)[0]
     assert torch.equal(a, c) and not torch.equal(a, b)
+
+
+def test_six_product_split_on_other_shapes(eng, synth_sd):
+    """bf16x6 through the paths the sweep's fixture call does not take: column sharing (bitwise the unshared call in this mode too),
+    a single clip (small-tile GEMMs), the offsets head (row-major PCA epilogue)."""
+    sr = 16000
+    feat, _, _ = eng.mel_frontend([synth.make_pcm(0, 2 * sr), synth.make_pcm(21, 30011, "speechlike")], sr)
+    fc, fs, hop = eng.last_frame_table
+    spk = torch.full((feat.shape[0],), 2, dtype=torch.int64)
+    ref, z_ref, *_ = eng.forward(feat, spk)
+    try:
+        eng.set_precision("bf16x6")
+        z0, a0 = eng.encoder(feat)
+        z1, a1 = eng.encoder(feat, frame_clip=fc, frame_start=fs, hop=hop)
+        out, *_ = eng.forward(feat, spk)
+    finally:
+        eng.set_precision("fp32")
+    assert torch.equal(z0, z1) and torch.equal(a0, a1)
+    assert float((z0 - z_ref).abs().max()) <= 2e-5 and float((out - ref).abs().max()) <= 5e-6
+    e_off = Engine(synth_sd["offsets"], precision="bf16x6")
+    o6, *_ = e_off.forward(feat[:100], spk[:100])
+    e_off.set_precision("fp32")
+    o32, *_ = e_off.forward(feat[:100], spk[:100])
+    assert float((o6 - o32).abs().max()) <= 5e-6
 
 
 def test_column_sharing_is_exact_in_split_bf16(eng):
