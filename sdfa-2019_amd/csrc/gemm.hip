@@ -454,16 +454,15 @@ __global__ __launch_bounds__(256) void gemm_bf16x6_kernel(GemmArgs a) {
                     bq[pl][i] = S6(buf, 1, pl, 2 * m + h)[wq * 64 + i * 32 + l31];
                 }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            // one partial product over all four accumulators at a time (no two dependent MFMAs in a row), smallest products first
+            constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0][i], bq[2][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1][i], bq[1][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2][i], bq[0][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0][i], bq[1][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1][i], bq[0][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0][i], bq[0][j], acc[i][j], 0, 0, 0);
-                }
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[PA[t]][i], bq[PB[t]][j], acc[i][j], 0, 0, 0);
         }
         if (reload) { B6_LSTORE(buf ^ 1) }
         __syncthreads();

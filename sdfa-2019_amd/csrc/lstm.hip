@@ -672,20 +672,25 @@ __global__ __launch_bounds__(256) void freq_lstm_bf16x6_kernel(FreqLstmArgs a) {
 #pragma unroll
             for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[gt][j] = MFMA_BF16(wm[gt], b[1][j], acc[gt][j]);                              // mid * mid
-                    acc[gt][j] = MFMA_BF16(wm[gt], b[0][j], acc[gt][j]);                              // mid * hi
-                }
+                for (int j = 0; j < 2; ++j) acc[gt][j] = MFMA_BF16(wm[gt], b[1][j], acc[gt][j]);      // mid * mid  (one product over all eight
+#pragma unroll                                                                                         //  accumulators at a time: no two dependent MFMAs in a row)
+            for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[gt][j] = MFMA_BF16(wm[gt], b[0][j], acc[gt][j]);      // mid * hi
 #pragma unroll
             for (int gt = 0; gt < 4; ++gt) wm[gt] = F6_W(1, kn, gt);            // next k-step's mid plane: 32 MFMAs ahead
 #pragma unroll
             for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[gt][j] = MFMA_BF16(wh[gt], b[2][j], acc[gt][j]);                              // hi * lo
-                    acc[gt][j] = MFMA_BF16(wh[gt], b[1][j], acc[gt][j]);                              // hi * mid
-                    acc[gt][j] = MFMA_BF16(wh[gt], b[0][j], acc[gt][j]);                              // hi * hi
-                }
+                for (int j = 0; j < 2; ++j) acc[gt][j] = MFMA_BF16(wh[gt], b[2][j], acc[gt][j]);      // hi * lo
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[gt][j] = MFMA_BF16(wh[gt], b[1][j], acc[gt][j]);      // hi * mid
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[gt][j] = MFMA_BF16(wh[gt], b[0][j], acc[gt][j]);      // hi * hi
         }
         __syncthreads();   // every wave has finished reading sH / sX[cur]
         if (s + 1 < 32) { F6_XLOAD(dir ? 30 - s : s + 1) }   // lands while the cell update runs
@@ -1478,20 +1483,25 @@ __global__ __launch_bounds__(512, 2) void time_lstm_bf16_kernel(TimeLstmArgs a) 
 #pragma unroll
                 for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        acc[gt][j] = MFMA_BF16(wm[gt], b[1][j], acc[gt][j]);                              // mid * mid
-                        acc[gt][j] = MFMA_BF16(wm[gt], b[0][j], acc[gt][j]);                              // mid * hi
-                    }
+                    for (int j = 0; j < NT; ++j) acc[gt][j] = MFMA_BF16(wm[gt], b[1][j], acc[gt][j]);      // mid * mid
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[gt][j] = MFMA_BF16(wm[gt], b[0][j], acc[gt][j]);      // mid * hi
 #pragma unroll
                 for (int gt = 0; gt < 4; ++gt) wm[gt] = T6_W(1, kn, gt);
 #pragma unroll
                 for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        acc[gt][j] = MFMA_BF16(wh[gt], b[2][j], acc[gt][j]);                              // hi * lo
-                        acc[gt][j] = MFMA_BF16(wh[gt], b[1][j], acc[gt][j]);                              // hi * mid
-                        acc[gt][j] = MFMA_BF16(wh[gt], b[0][j], acc[gt][j]);                              // hi * hi
-                    }
+                    for (int j = 0; j < NT; ++j) acc[gt][j] = MFMA_BF16(wh[gt], b[2][j], acc[gt][j]);      // hi * lo
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[gt][j] = MFMA_BF16(wh[gt], b[1][j], acc[gt][j]);      // hi * mid
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[gt][j] = MFMA_BF16(wh[gt], b[0][j], acc[gt][j]);      // hi * hi
             }
 #undef T6_W
         }
