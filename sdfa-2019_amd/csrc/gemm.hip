@@ -453,7 +453,6 @@ __global__ __launch_bounds__(256) void gemm_bf16x6_kernel(GemmArgs a) {
                     ap[pl][i] = S6(buf, 0, pl, 2 * m + h)[wp * 64 + i * 32 + l31];
                     bq[pl][i] = S6(buf, 1, pl, 2 * m + h)[wq * 64 + i * 32 + l31];
                 }
-#pragma unroll
             // one partial product over all four accumulators at a time (no two dependent MFMAs in a row), smallest products first
             constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
