@@ -579,7 +579,7 @@ constexpr int BF16_PLANES = 3;
 // The recurrence of freq_lstm_bf16_kernel with operands as three bf16 terms and six partial products per product, smallest first:
 //   W_lo*b_hi, W_mid*b_mid, W_mid*b_hi, W_hi*b_lo, W_hi*b_mid, W_hi*b_hi        (dropped: the three below 2^-24 of the leading one)
 // -- fp32-equivalent products at 16 / 6 = 2.7x the fp32 MFMA rate.  The three weight planes of a k-step are streamed one after the
-// other (lo, mid, hi) through three register sets, each refilled two planes ahead of its use; x_f and h are split into three
+// other (lo, mid, hi), each requested while the previous one multiplies, so only two planes are live; x_f and h are split into three
 // planes by the lanes that stage / produce them.  98 KiB of dynamic LDS, one workgroup per CU.
 template <bool SHARED>
 __global__ __launch_bounds__(256) void freq_lstm_bf16x6_kernel(FreqLstmArgs a) {
@@ -647,11 +647,9 @@ __global__ __launch_bounds__(256) void freq_lstm_bf16x6_kernel(FreqLstmArgs a) {
                 }
             }
         const int nks = s > 0 ? 12 : 4;      // k-steps of 16: 0..3 = x_f, 4..11 = h_{s-1} (skipped on the first step)
-        // Three register sets, one per plane, each refilled TWO planes ahead of its use (the kernel runs one wave per SIMD: nothing
-        // else hides the L2 round trip of a weight plane): while a plane multiplies, the next two are in flight.
-        bf16x8 wl[4], wm[4], wh[4];
+        bf16x8 wa[4], wb[4];
 #pragma unroll
-        for (int gt = 0; gt < 4; ++gt) { wl[gt] = F6_W(2, 0, gt); wm[gt] = F6_W(1, 0, gt); }
+        for (int gt = 0; gt < 4; ++gt) wa[gt] = F6_W(2, 0, gt);                 // lo plane of k-step 0
 #pragma unroll 1
         for (int ks = 0; ks < nks; ++ks) {
             bf16x8 b[3][2];
@@ -660,37 +658,34 @@ __global__ __launch_bounds__(256) void freq_lstm_bf16x6_kernel(FreqLstmArgs a) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     b[pl][j] = ks < 4 ? F6_X(cur, pl, 2 * ks + h)[j * 32 + l31] : F6_H(pl, 2 * (ks - 4) + h)[j * 32 + l31];
-            const int kn = ks + 1 < nks ? ks + 1 : 0;                           // branch-free: the last requests are dropped
 #pragma unroll
-            for (int gt = 0; gt < 4; ++gt) wh[gt] = F6_W(0, ks, gt);            // hi plane of this k-step: needed 24 MFMAs from here
-#pragma unroll
-            for (int gt = 0; gt < 4; ++gt)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[gt][j] = MFMA_BF16(wl[gt], b[0][j], acc[gt][j]);      // lo * hi
-#pragma unroll
-            for (int gt = 0; gt < 4; ++gt) wl[gt] = F6_W(2, kn, gt);            // next k-step's lo plane: 40 MFMAs ahead
+            for (int gt = 0; gt < 4; ++gt) wb[gt] = F6_W(1, ks, gt);            // mid plane, requested while lo multiplies
 #pragma unroll
             for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[gt][j] = MFMA_BF16(wm[gt], b[1][j], acc[gt][j]);      // mid * mid  (one product over all eight
-#pragma unroll                                                                                         //  accumulators at a time: no two dependent MFMAs in a row)
-            for (int gt = 0; gt < 4; ++gt)
+                for (int j = 0; j < 2; ++j) acc[gt][j] = MFMA_BF16(wa[gt], b[0][j], acc[gt][j]);      // lo * hi
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[gt][j] = MFMA_BF16(wm[gt], b[0][j], acc[gt][j]);      // mid * hi
-#pragma unroll
-            for (int gt = 0; gt < 4; ++gt) wm[gt] = F6_W(1, kn, gt);            // next k-step's mid plane: 32 MFMAs ahead
+            for (int gt = 0; gt < 4; ++gt) wa[gt] = F6_W(0, ks, gt);            // hi plane, requested while mid multiplies
 #pragma unroll
             for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[gt][j] = MFMA_BF16(wh[gt], b[2][j], acc[gt][j]);      // hi * lo
+                for (int j = 0; j < 2; ++j) {
+                    acc[gt][j] = MFMA_BF16(wb[gt], b[1][j], acc[gt][j]);                              // mid * mid
+                    acc[gt][j] = MFMA_BF16(wb[gt], b[0][j], acc[gt][j]);                              // mid * hi
+                }
+            const int kn = ks + 1 < nks ? ks + 1 : 0;                           // branch-free: the last request is dropped
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt) wb[gt] = F6_W(2, kn, gt);            // next k-step's lo plane, requested while hi multiplies
 #pragma unroll
             for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[gt][j] = MFMA_BF16(wh[gt], b[1][j], acc[gt][j]);      // hi * mid
+                for (int j = 0; j < 2; ++j) {
+                    acc[gt][j] = MFMA_BF16(wa[gt], b[2][j], acc[gt][j]);                              // hi * lo
+                    acc[gt][j] = MFMA_BF16(wa[gt], b[1][j], acc[gt][j]);                              // hi * mid
+                    acc[gt][j] = MFMA_BF16(wa[gt], b[0][j], acc[gt][j]);                              // hi * hi
+                }
 #pragma unroll
-            for (int gt = 0; gt < 4; ++gt)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[gt][j] = MFMA_BF16(wh[gt], b[0][j], acc[gt][j]);      // hi * hi
+            for (int gt = 0; gt < 4; ++gt) wa[gt] = wb[gt];
         }
         __syncthreads();   // every wave has finished reading sH / sX[cur]
         if (s + 1 < 32) { F6_XLOAD(dir ? 30 - s : s + 1) }   // lands while the cell update runs
@@ -1461,9 +1456,9 @@ __global__ __launch_bounds__(512, 2) void time_lstm_bf16_kernel(TimeLstmArgs a) 
 
         if (X6 && s > 0) {      // lo, mid, hi plane of each k-step in turn, the next one requested while this one multiplies
 #define T6_W(pl, ks, gt) Wh[((size_t)(pl) * 32 + 2 * (ks) + h) * 1024 + (gt) * 32]
-            bf16x8 wl[4], wm[4], wh[4];      // one register set per plane, refilled two planes ahead (see freq_lstm_bf16x6_kernel)
+            bf16x8 wa[4], wb[4];
 #pragma unroll
-            for (int gt = 0; gt < 4; ++gt) { wl[gt] = T6_W(2, 0, gt); wm[gt] = T6_W(1, 0, gt); }
+            for (int gt = 0; gt < 4; ++gt) wa[gt] = T6_W(2, 0, gt);
 #pragma unroll 1
             for (int ks = 0; ks < 16; ++ks) {
                 bf16x8 b[3][NT];
@@ -1471,37 +1466,34 @@ __global__ __launch_bounds__(512, 2) void time_lstm_bf16_kernel(TimeLstmArgs a) 
                 for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
                     for (int j = 0; j < NT; ++j) b[pl][j] = SH(cur, pl)[(2 * ks + h) * BT + j * 32 + l31];
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt) wb[gt] = T6_W(1, ks, gt);
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[gt][j] = MFMA_BF16(wa[gt], b[0][j], acc[gt][j]);      // lo * hi
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt) wa[gt] = T6_W(0, ks, gt);
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        acc[gt][j] = MFMA_BF16(wb[gt], b[1][j], acc[gt][j]);                              // mid * mid
+                        acc[gt][j] = MFMA_BF16(wb[gt], b[0][j], acc[gt][j]);                              // mid * hi
+                    }
                 const int kn = ks + 1 < 16 ? ks + 1 : 0;
 #pragma unroll
-                for (int gt = 0; gt < 4; ++gt) wh[gt] = T6_W(0, ks, gt);
+                for (int gt = 0; gt < 4; ++gt) wb[gt] = T6_W(2, kn, gt);
 #pragma unroll
                 for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[gt][j] = MFMA_BF16(wl[gt], b[0][j], acc[gt][j]);      // lo * hi
+                    for (int j = 0; j < NT; ++j) {
+                        acc[gt][j] = MFMA_BF16(wa[gt], b[2][j], acc[gt][j]);                              // hi * lo
+                        acc[gt][j] = MFMA_BF16(wa[gt], b[1][j], acc[gt][j]);                              // hi * mid
+                        acc[gt][j] = MFMA_BF16(wa[gt], b[0][j], acc[gt][j]);                              // hi * hi
+                    }
 #pragma unroll
-                for (int gt = 0; gt < 4; ++gt) wl[gt] = T6_W(2, kn, gt);
-#pragma unroll
-                for (int gt = 0; gt < 4; ++gt)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[gt][j] = MFMA_BF16(wm[gt], b[1][j], acc[gt][j]);      // mid * mid
-#pragma unroll
-                for (int gt = 0; gt < 4; ++gt)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[gt][j] = MFMA_BF16(wm[gt], b[0][j], acc[gt][j]);      // mid * hi
-#pragma unroll
-                for (int gt = 0; gt < 4; ++gt) wm[gt] = T6_W(1, kn, gt);
-#pragma unroll
-                for (int gt = 0; gt < 4; ++gt)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[gt][j] = MFMA_BF16(wh[gt], b[2][j], acc[gt][j]);      // hi * lo
-#pragma unroll
-                for (int gt = 0; gt < 4; ++gt)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[gt][j] = MFMA_BF16(wh[gt], b[1][j], acc[gt][j]);      // hi * mid
-#pragma unroll
-                for (int gt = 0; gt < 4; ++gt)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[gt][j] = MFMA_BF16(wh[gt], b[0][j], acc[gt][j]);      // hi * hi
+                for (int gt = 0; gt < 4; ++gt) wa[gt] = wb[gt];
             }
 #undef T6_W
         }
