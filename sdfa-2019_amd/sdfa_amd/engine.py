@@ -182,7 +182,11 @@ class Engine(FrontendOnly):
         need = check(lib.sdfa_workspace_bytes(self._m, min(int(n_frames), self.max_frames)))
         if self._ws is None or self._ws.numel() < need:
             if self._ws is not None:
-                self._repairs_carried += self.time_lstm_repairs()      # the old block's count (a sync; regrowth is rare)
+                # a status copy of an earlier call may still be queued on the copy stream: let it read the old block before the
+                # allocator can hand the block out again, then carry the old block's count over (two syncs; regrowth is rare)
+                self.check_pending(block=True)
+                carried = self.time_lstm_repairs()
+                self._repairs_carried = carried
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
             check(lib.sdfa_workspace_init(_ptr(self._ws), self._ws.numel(), _stream()))    # zero the status block, once
