@@ -25,6 +25,7 @@ def build_model(hparams, state_dict=None):
 
 
 def evaluate_model(args):
+    from_cli = not isinstance(args, dict)          # python -m speech_anime evaluate: only the files are wanted
     args = args if isinstance(args, dict) else vars(args)
     hparams = configure(args)
     if hparams.eval_input is not None:                                  # api.py:83-87
@@ -42,7 +43,7 @@ def evaluate_model(args):
     model.current_epoch = ckpt.get("epoch", 0)
     return model.evaluate(hparams.trainer.evaluate, experiment=None, in_trainer=False,
                           overwrite_video=args.get("overwrite_video", False),
-                          export_mesh_frames=args.get("export_mesh_frames", False),
+                          export_mesh_frames=args.get("export_mesh_frames", False), keep_results=not from_cli,
                           output_dir=args.get("output_dir") or os.path.join(hparams.get("log_dir") or ".", "evaluate_videos"))
 
 

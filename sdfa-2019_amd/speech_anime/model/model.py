@@ -269,6 +269,9 @@ class SaberSpeechDrivenAnimation:
             raise RuntimeError("no weights loaded: call load_state_dict first")
         from sdfa_amd.engine import frame_index
         limit = int(kwargs.get("group_frames") or eng.max_frames) // (2 if (ens is not None and ens > 0) else 1)
+        # the reference's evaluate returns nothing; the mirror returns [(path, tslist, animes)] for callers that want the tracks (the
+        # rows are views of pinned host memory: a long evaluation that only wants the files passes keep_results=False, as the CLI does)
+        keep = bool(kwargs.get("keep_results", True))
         results, group, group_frames = [], [], 0
 
         def flush():
@@ -283,7 +286,8 @@ class SaberSpeechDrivenAnimation:
                 track = None if track_all is None else track_all[f0:f0 + len(tslist)]
                 f0 += len(tslist)
                 self._write_result(g, tslist, animes, track, output_dir, export_frames)
-                results.append((g["path"], tslist, animes))
+                if keep:
+                    results.append((g["path"], tslist, animes))
             group, group_frames = [], 0
 
         for _, records in dict(sources).items():
