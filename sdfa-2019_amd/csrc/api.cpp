@@ -517,15 +517,31 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
             auto *wih = get(m, k + "weight_ih_l0" + suf[d], 512 * 64), *whh = get(m, k + "weight_hh_l0" + suf[d], 512 * 128);
             auto *bih = get(m, k + "bias_ih_l0" + suf[d], 512), *bhh = get(m, k + "bias_hh_l0" + suf[d], 512);
             if (!wih || !whh || !bih || !bhh) return SDFA_ESTATE;
+            // The cell update needs its gate pre-activations as exponents of two: sigmoid(x) = 1 / (1 + 2^(-x log2 e)), tanh(g) through
+            // 2^(-2 g log2 e).  The scaling is folded into the weights and the bias here (rows i, f, o by log2 e, rows g by 2 log2 e:
+            // torch gate order i, f, g, o), so the kernel's accumulators ARE the exponents and the update has five vector multiplies
+            // per element pair less (round 4; lstm.hip: lstm_cell_quad<true>).  A weight picks up one more fp32 rounding; the stage
+            // stays inside its 1e-4 tap tolerance (tests/test_gpu_parity.py) and all launch forms share the packed weights.
             for (int r = 0; r < 512; ++r) {
-                memcpy(&cat[(size_t)r * 192], &(*wih)[(size_t)r * 64], 64 * 4);
-                memcpy(&cat[(size_t)r * 192 + 64], &(*whh)[(size_t)r * 128], 128 * 4);
+#ifdef SDFA_OLD_CELL   /* A/B build only (make EXP=OLD_CELL): round 3's unscaled weights + cell update */
+                const float k = 1.0f;
+#else
+                const float k = (r / 128 == 2) ? 2.8853900817779268f : 1.4426950408889634f;
+#endif
+                for (int j = 0; j < 64; ++j) cat[(size_t)r * 192 + j] = (*wih)[(size_t)r * 64 + j] * k;
+                for (int j = 0; j < 128; ++j) cat[(size_t)r * 192 + 64 + j] = (*whh)[(size_t)r * 128 + j] * k;
             }
             size_t o = pack_k4(pk, cat.data(), 512, 192, 192, 0, 192, 512, perm.data());
             pack_freq_lstm_bf16(reinterpret_cast<uint16_t *>(&pk.buf[o_flwb]) + (size_t)d * 3 * 24 * 512 * 8, cat.data(), perm.data());
             if (d == 0) first = o;
             else if (o != first + (size_t)48 * 512 * 4) return fail(SDFA_ESTATE, "internal: freq-lstm weights not contiguous");
-            for (int p = 0; p < 512; ++p) bias[d * 512 + p] = (*bih)[perm[p]] + (*bhh)[perm[p]];
+            for (int p = 0; p < 512; ++p) {
+#ifdef SDFA_OLD_CELL
+                bias[d * 512 + p] = (*bih)[perm[p]] + (*bhh)[perm[p]];
+#else
+                bias[d * 512 + p] = ((*bih)[perm[p]] + (*bhh)[perm[p]]) * ((perm[p] / 128 == 2) ? 2.8853900817779268f : 1.4426950408889634f);
+#endif
+            }
         }
         o_flw = first;
         o_flb = pk.add(1024);

@@ -62,7 +62,7 @@ __device__ __forceinline__ f32x2 tanh2(f32x2 x) {         // (1 - e) / (1 + e), 
 //       (1 - e) / (1 + e) form has ~3e-8 -- the size of sigmoid's own error, and g only enters through i * g.
 //     * sigmoid(o) * tanh(c') = (1 - e_c) / ((1 + e_o) (1 + e_c)), e_c = exp(-2c'), e_o = exp(-o): ONE reciprocal for both and no
 //       sign handling.  Needs a finite e_c: |c'| < step count = 32 here (|c_t| <= |f c_{t-1}| + |i g| < |c_{t-1}| + 1), so
-//       e_c <= 2^92.4; e_o may overflow -- the product is then inf, its reciprocal 0 and h = (1 - e_c) * 0 = 0 = sigmoid(-inf).
+//       e_c <= 2^92.4 (also with the cell state in units of 2 log2 e, below: the exponent is the same number); e_o may overflow -- the product is then inf, its reciprocal 0 and h = (1 - e_c) * 0 = 0 = sigmoid(-inf).
 //       (Not usable in the BiLSTM: 64 steps allow e_c = 2^185.)  Near c' = 0 it keeps the (1 - e) form's accuracy.
 //   The end-to-end error against the CPU port is unchanged (max |d dgrad| 7.5e-7 on the 10 s clip); all frequency-LSTM launch
 //   forms share this function and stay bit-identical to each other.
@@ -77,16 +77,37 @@ __device__ __forceinline__ void lstm_cell_quad(const f32x16 &ai, const f32x16 &a
 #ifdef SDFA_FAKE_CELL   /* timing experiment only: what does the cell math cost? */
         { const f32x2 cn = f32x2{af[r], af[r + 1]} * cp + f32x2{ai[r], ai[r + 1]} * f32x2{ag[r], ag[r + 1]}; c[r] = cn.x; c[r + 1] = cn.y; hv[p] = f32x2{ao[r], ao[r + 1]} * cn; continue; }
 #endif
-        const f32x2 ig = sigmoid2(f32x2{ai[r], ai[r + 1]});
-        const f32x2 fg = sigmoid2(f32x2{af[r], af[r + 1]});
-        const f32x2 fc = fg * cp;                                   // rounded product first, then one fused multiply-add
+#ifdef SDFA_OLD_CELL   /* A/B build only (make EXP=OLD_CELL): round 3's cell update on unscaled weights */
         if (FREQ) {
+            const f32x2 ig = sigmoid2(f32x2{ai[r], ai[r + 1]}), fg = sigmoid2(f32x2{af[r], af[r + 1]});
+            const f32x2 fc = fg * cp;
             const f32x2 gg = __builtin_elementwise_fma(rcp2(exp2n(f32x2{ag[r], ag[r + 1]} * 2.8853900817779268f) + 1.0f), f32x2{2.0f, 2.0f}, f32x2{-1.0f, -1.0f});
             const f32x2 cn = __builtin_elementwise_fma(ig, gg, fc);
             c[r] = cn.x; c[r + 1] = cn.y;
             const f32x2 eo = exp2n(f32x2{ao[r], ao[r + 1]} * 1.4426950408889634f), ec = exp2n(cn * 2.8853900817779268f);
             hv[p] = (1.0f - ec) * rcp2((1.0f + eo) * (1.0f + ec));
-        } else {
+            continue;
+        }
+#endif
+        if (FREQ) {
+            // Round 4: the accumulators arrive as exponents of two (the host folds log2 e / 2 log2 e into the weights and the bias:
+            // api.cpp), and the cell state is kept in the same units, c~ = 2 log2 e * c (it never leaves the kernel) -- so no gate and
+            // no tanh(c') argument needs a scaling multiply: 11 packed + 18 transcendental instructions per element pair (16 + 18).
+            constexpr float K2 = 2.8853900817779268f;      // 2 log2 e
+            const f32x2 ig = rcp2(exp2n(f32x2{ai[r], ai[r + 1]}) + 1.0f);
+            const f32x2 fg = rcp2(exp2n(f32x2{af[r], af[r + 1]}) + 1.0f);
+            const f32x2 fc = fg * cp;                               // rounded product first, then one fused multiply-add
+            const f32x2 gg = __builtin_elementwise_fma(rcp2(exp2n(f32x2{ag[r], ag[r + 1]}) + 1.0f), f32x2{2.0f * K2, 2.0f * K2}, f32x2{-K2, -K2});   // 2 log2 e * tanh(g)
+            const f32x2 cn = __builtin_elementwise_fma(ig, gg, fc);
+            c[r] = cn.x; c[r + 1] = cn.y;
+            const f32x2 eo = exp2n(f32x2{ao[r], ao[r + 1]}), ec = exp2n(cn);
+            hv[p] = (1.0f - ec) * rcp2((1.0f + eo) * (1.0f + ec));
+            continue;
+        }
+        const f32x2 ig = sigmoid2(f32x2{ai[r], ai[r + 1]});
+        const f32x2 fg = sigmoid2(f32x2{af[r], af[r + 1]});
+        const f32x2 fc = fg * cp;                                   // rounded product first, then one fused multiply-add
+        {
             const f32x2 gg = tanh2(f32x2{ag[r], ag[r + 1]});
             const f32x2 og = sigmoid2(f32x2{ao[r], ao[r + 1]});
             const f32x2 cn = __builtin_elementwise_fma(ig, gg, fc);
