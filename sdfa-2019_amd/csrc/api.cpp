@@ -419,7 +419,7 @@ int sdfa_mel_frontend_gather(const float *d_pcm, const int64_t *d_clip_off, cons
     ShareArgs sa{};
     sa.frame_clip = d_frame_clip; sa.frame_start = d_frame_start; sa.hop = c.hop;
     sa.t_lo = 1; sa.t_hi = 63;          // every window column but the first (raw first sample) is a function of (clip, position)
-    sa.frame_major = g_sdfa_frontend_t_major ? 0 : 1;      // distinct columns numbered clip by clip, hop by hop (share.hip: scan_pos)
+    sa.frame_major = g_sdfa_frontend_t_major ? 0 : 1;      // distinct columns numbered clip by clip, hop by hop, per-column arrays indexed [n][t] (share.hip: col_index)
     sa.N = n_frames; sa.Nc = w.Nc; sa.Mc = w.Mc;
     sa.counts = reinterpret_cast<int64_t *>(sh);
     sa.prev = sh + 16; sa.shift = sa.prev + w.Nc;
