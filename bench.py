@@ -267,17 +267,29 @@ def memory_plan(world, clips_per_gpu=32, seconds=10.0, sr=16000, head="dgrad", c
         "dgrad": rows + world * rows,                              # own rows + FrameGatherer.buf (all ranks' rows)
         "expand": world * rows + 2 * world * F * coef_dim * 4,     # ExpandGatherer.buf (own rows written in place) + the coefficient gather
         "direct": 2 * world * rows,                                # DirectGatherer: two alternating gathered buffers
+        "coef": rows + world * F * coef_dim * 4,                   # own rows + the gathered coefficients
+        "mesh": rows + (world + 1) * F * 5148 * 3 * 4,             # own rows + own and gathered vertices (bench.py's synthetic template: 5,148 vertices, one video frame per animation frame at 60 fps)
     }
     if world == 1:
         kinds = ["none"]
     else:
-        kinds = ["dgrad", "expand"] if gather == "auto" else [gather]
+        kinds = ["dgrad", "expand"] if gather == "auto" else [gather if gather in modes else "none"]
     fixed = sum(parts.values())
     plan = {k: round(v / 1e9, 3) for k, v in parts.items()}
     plan["output_and_gathered"] = {k: round(modes[k] / 1e9, 3) for k in kinds}
     plan["total_gb"] = round((fixed + max(modes[k] for k in kinds)) / 1e9, 2)
     plan["frames_per_gpu"] = F
     return plan
+
+
+def _plan_or_none(world, C, a, sr):
+    """memory_plan for the bench line: reporting only, so it can never cost the line."""
+    if a.ragged_seconds:
+        return None
+    try:
+        return memory_plan(world, C, a.seconds, sr, a.head, a.chunk, a.gather)
+    except Exception as e:
+        return {"error": repr(e)}
 
 
 def _sha1(name):
@@ -674,7 +686,7 @@ def main():
                        "gather": (Mode.kind if (Mode.gatherer is not None or Mode.direct is not None or (mesh is not None and mesh[3] is not None)) else "none") if dist_on else "none (1 GPU)",
                        "force_gather_world1": bool(a.force_gather and world == 1), "backend": a.backend if dist_on else None,
                        "reserved_cus": a.reserve_cus,
-                       "memory_plan_gb": memory_plan(world, C, a.seconds, sr, a.head, a.chunk, a.gather) if not a.ragged_seconds else None,   # planned; peak_device_memory_gb is measured
+                       "memory_plan_gb": _plan_or_none(world, C, a, sr),   # planned (memory_plan); peak_device_memory_gb is measured
                        "env": __import__("sdfa_amd").runtime_env(),      # set at import by bench.py / sdfa_amd unless the caller had set them
                        # does an asynchronous RCCL all-gather run UNDER the kernels of the stream the steps ran on?  (probe before the run)
                        "collective_overlap_probe": comm_probe,

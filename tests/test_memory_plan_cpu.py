@@ -35,3 +35,11 @@ def test_offsets_stream_plan():
     import bench
     p = bench.memory_plan(8, clips_per_gpu=80, seconds=6.0, sr=8000, head="offsets", chunk=8192)
     assert p["total_gb"] < 100
+
+
+def test_every_gather_mode_has_a_plan():
+    """bench.py --gather coef / mesh / none at N > 1 must not fail in the reporting code (found by the two-rank rehearsal in round 4)."""
+    import bench
+    for g in ("auto", "dgrad", "expand", "direct", "coef", "mesh", "none"):
+        p = bench.memory_plan(2, clips_per_gpu=4, gather=g)
+        assert p["total_gb"] > 0 and p["output_and_gathered"]
