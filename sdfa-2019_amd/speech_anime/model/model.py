@@ -192,7 +192,7 @@ class SaberSpeechDrivenAnimation:
         key = (sr, int(ensembling_ms) if ensemble else 0, eng.precision)
         c = getattr(self, "_signal_cache", None)
         if (len(signals) == 1 and c is not None and c["key"] == key and c["signal"].shape == signals[0].shape
-                and np.array_equal(c["signal"], signals[0])):
+                and (c["feat"] is not None or not want_inputs) and np.array_equal(c["signal"], signals[0])):
             n = len(c["tslist"])
             spk = torch.full((n,), int(speakers[0]), dtype=torch.int64, device=eng.device)
             inputs_host = eng.to_host_async(c["feat"][:n].permute(0, 3, 2, 1)) if want_inputs else None
@@ -215,7 +215,9 @@ class SaberSpeechDrivenAnimation:
             inputs_host = eng.to_host_async(feat[:n].permute(0, 3, 2, 1))
         rows = eng.forward_host(feat, spk, table=share, ops_key=self._model._key, wait=True, ensemble=ensemble)
         if len(signals) == 1 and eng.last_z() is not None:               # one clip, one piece: remember (signal -> z) for a speaker sweep
-            self._signal_cache = {"key": key, "signal": signals[0].copy(), "tslist": tslists[0], "z": eng.last_z(), "feat": feat}
+            # z is 2 KB per frame; the features (others["inputs"] of a later hit) are 98 KB per frame and are kept up to 256 MB only
+            keep_feat = feat if feat.numel() * 4 <= (256 << 20) else None
+            self._signal_cache = {"key": key, "signal": signals[0].copy(), "tslist": tslists[0], "z": eng.last_z(), "feat": keep_feat}
         return self._pack(rows.numpy(), inputs_host.numpy() if inputs_host is not None else None, tslists, counts)
 
     def _pack(self, rows_np, inputs_np, tslists, counts):
