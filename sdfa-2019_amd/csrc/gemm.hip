@@ -617,6 +617,109 @@ hipError_t launch_bf16_big(const GemmArgs &a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Six-product split on the 256 x 256 tile (P and Q multiples of 256): the 128 x 128 six-product kernel above is bound by its operand
+// stream like the other 128-tile bf16 kernels (its frequency projection took what the exact fp32 gemm_fat_kernel takes); this tile
+// stages half the bytes per FLOP.  Three planes per operand leave room for 16-deep stages only: [2 buffers][P | Q][3 planes]
+// [2 octets][256] = 96 KiB.  8 waves (2 x 4, each 128 x 64), one workgroup per CU.
+// ------------------------------------------------------------------------------------------------
+template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
+__global__ __launch_bounds__(512, 2) void gemm_bf16x6_big_kernel(GemmArgs a) {
+    constexpr int BT = 256, KQS = 4;                       // tile edge; k-quads per stage (16 k)
+    extern __shared__ bf16x8 s6b[];
+    auto S6B = [&](int buf, int pq, int plane) { return s6b + ((size_t)((buf * 2 + pq) * 3 + plane) * 2) * BT; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave >> 2, wq = wave & 3, l31 = lane & 31, h = lane >> 5;
+    const int64_t ntp = a.Ppad / BT, bid = blockIdx.x;
+    const int64_t p0 = (bid % ntp) * BT, q0 = (bid / ntp) * BT;
+    if (a.q_limit && q0 >= *a.q_limit) return;
+
+    const float4 *__restrict__ P = reinterpret_cast<const float4 *>(a.P);
+    const float4 *__restrict__ Q = reinterpret_cast<const float4 *>(a.Q);
+    const int seg_kq = a.seg_k / 4, nstage = a.K / 16;
+    // staging: a thread's item of a stage is (octet g0 = tid >> 8, column c = tid & 255): K4 quads 2 g0 and 2 g0 + 1 of the stage
+    const int c = tid & 255, g0 = tid >> 8;
+    const int64_t qrow = a.q_tile_major ? 128 : a.ldq;
+    const float4 *Pn = P + p0;
+    const float4 *Qn = a.q_tile_major ? Q + (q0 >> 7) * (int64_t)a.q_slab_rows * 128 : Q + q0;
+    int kin_n = 0;
+    const unsigned boffP = (unsigned)((2 * g0 * a.ldp + c) * 16);
+    const unsigned boffQ = a.q_tile_major ? (unsigned)((((int64_t)(c >> 7) * a.q_slab_rows + 2 * g0) * 128 + (c & 127)) * 16)
+                                          : (unsigned)((2 * g0 * qrow + c) * 16);
+    float4 rp[2], rq[2];
+#define B6B_GLOAD()                                                                                             \
+    {                                                                                                           \
+        _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                         \
+            rp[e] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Pn + e * a.ldp) + boffP);   \
+            rq[e] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Qn + e * qrow) + boffQ);    \
+        }                                                                                                       \
+        Pn += KQS * a.ldp;                                                                                      \
+        kin_n += KQS;                                                                                           \
+        if (kin_n == seg_kq) { kin_n = 0; Qn += a.seg_col - (int64_t)(seg_kq - KQS) * qrow; }                   \
+        else Qn += KQS * qrow;                                                                                  \
+    }
+#define B6B_LSTORE(buf)                                                                                         \
+    {                                                                                                           \
+        bf16x8 hi, mid, lo;                                                                                     \
+        split8x3(rp[0], rp[1], hi, mid, lo); S6B(buf, 0, 0)[g0 * BT + c] = hi; S6B(buf, 0, 1)[g0 * BT + c] = mid; S6B(buf, 0, 2)[g0 * BT + c] = lo; \
+        split8x3(rq[0], rq[1], hi, mid, lo); S6B(buf, 1, 0)[g0 * BT + c] = hi; S6B(buf, 1, 1)[g0 * BT + c] = mid; S6B(buf, 1, 2)[g0 * BT + c] = lo; \
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    B6B_GLOAD()
+    B6B_LSTORE(0)
+    __syncthreads();
+    for (int st = 0; st < nstage; ++st) {
+        const int buf = st & 1;
+        const bool reload = st + 1 < nstage;
+        if (reload) { B6B_GLOAD() }
+        bf16x8 ap[3][4], bq[3][2];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ap[pl][i] = S6B(buf, 0, pl)[h * BT + wp * 128 + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bq[pl][j] = S6B(buf, 1, pl)[h * BT + wq * 64 + j * 32 + l31];
+        }
+        constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};      // smallest partial products first
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[PA[t]][i], bq[PB[t]][j], acc[i][j], 0, 0, 0);
+        if (reload) { B6B_LSTORE(buf ^ 1) }
+        __syncthreads();
+    }
+#undef B6B_GLOAD
+#undef B6B_LSTORE
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            store_tile<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, acc[i][j], p0 + wp * 128 + i * 32, q0 + wq * 64 + j * 32 + l31, h);
+}
+
+template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
+hipError_t launch_bf16x6_big(const GemmArgs &a, hipStream_t s) {
+    const size_t lds = (size_t)2 * 2 * 3 * 2 * 256 * sizeof(bf16x8);   // 96 KiB
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16x6_big_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int64_t nblk = (a.Ppad / 256) * (a.Qpad / 256);
+    hipLaunchKernelGGL((gemm_bf16x6_big_kernel<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>), dim3((unsigned)nblk), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // 256 x 256 tile, 8 waves (2 x 4, each 128 x 64 = 4 x 2 MFMA tiles), 128 KiB LDS, one workgroup per CU.
 // Half the staged bytes per FLOP of the 128 x 128 tile: the 128-tile kernel's time did not move when its MFMA work
 // was cut 5x (split-bf16 experiment) -- it is bound by the global->LDS staging stream -- so the big GEMMs
@@ -1015,7 +1118,9 @@ thread_local int g_sdfa_gemm_variant = 0;
 template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
 hipError_t launch_any(const GemmArgs &a, hipStream_t s) {
     const int variant = (g_sdfa_gemm_variant == 2 || g_sdfa_gemm_variant == 6 || g_sdfa_gemm_variant == 10 || g_sdfa_gemm_variant == 11) ? 0 : g_sdfa_gemm_variant;   // 2 / 6 / 10 / 11 only steer the tile choice of the LDS-tiled kernel (launch)
-    if (a.terms == 6) return launch_bf16x6<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);   // six-product split: one tile shape
+    if (a.terms == 6)      // six-product split: the 256 x 256 tile wherever it divides the problem ("gemm_variant" 7 = never)
+        return (a.Ppad % 256 == 0 && a.Qpad % 256 == 0 && a.K % 16 == 0 && variant != 7) ? launch_bf16x6_big<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s)
+                                                                                         : launch_bf16x6<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
     if (a.terms) {   // mixed-precision modes
         const bool big = a.Ppad % 256 == 0 && a.Qpad % 256 == 0 && variant != 7;
         if (a.terms == 1) return big ? launch_bf16_big<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 1>(a, s) : launch_bf16<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 1>(a, s);
