@@ -601,15 +601,16 @@ constexpr int BF16_PLANES = 3;
 //   W_lo*b_hi, W_mid*b_mid, W_mid*b_hi, W_hi*b_lo, W_hi*b_mid, W_hi*b_hi        (dropped: the three below 2^-24 of the leading one)
 // -- fp32-equivalent products at 16 / 6 = 2.7x the fp32 MFMA rate.  The three weight planes of a k-step are streamed one after the
 // other (lo, mid, hi), each requested while the previous one multiplies, so only two planes are live; x_f and h are split into three
-// planes by the lanes that stage / produce them.  98 KiB of dynamic LDS, one workgroup per CU.
+// planes by the lanes that stage / produce them.  74 KiB of dynamic LDS, two workgroups per CU.
 template <bool SHARED>
-__global__ __launch_bounds__(256) void freq_lstm_bf16x6_kernel(FreqLstmArgs a) {
+__global__ __launch_bounds__(256, 2) void freq_lstm_bf16x6_kernel(FreqLstmArgs a) {
     extern __shared__ bf16x8 sF6[];
     bf16x8 *const sHp = sF6;                                   // [3 planes][16 octets][64 sequences]
-    bf16x8 *const sXp = sF6 + 3 * 16 * 64;                     // [2 buffers][3 planes][8 octets][64]
-    float *const sBias = reinterpret_cast<float *>(sF6 + 3 * 16 * 64 + 2 * 3 * 8 * 64);
+    bf16x8 *const sXp = sF6 + 3 * 16 * 64;                     // [3 planes][8 octets][64]: ONE buffer -- the next x tile waits in registers and is
+                                                               // written behind the barrier that ends the K loop; 74 KiB in all = two workgroups per CU
+    float *const sBias = reinterpret_cast<float *>(sF6 + 3 * 16 * 64 + 3 * 8 * 64);
 #define F6_H(pl, o) (sHp + ((pl) * 16 + (o)) * 64)
-#define F6_X(buf, pl, o) (sXp + (((buf) * 3 + (pl)) * 8 + (o)) * 64)
+#define F6_X(buf, pl, o) (sXp + ((pl) * 8 + (o)) * 64)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -653,7 +654,7 @@ __global__ __launch_bounds__(256) void freq_lstm_bf16x6_kernel(FreqLstmArgs a) {
 
     for (int s = 0; s < 32; ++s) {
         const int f = dir ? 31 - s : s;
-        const int cur = s & 1;
+        constexpr int cur = 0;      // one x buffer (the macros keep the two-buffer signature of freq_lstm_bf16_kernel)
 
         f32x16 acc[4][2];
 #pragma unroll
@@ -1662,7 +1663,7 @@ template <bool SHARED>
 static hipError_t launch_freq_bf16(const FreqLstmArgs &a, hipStream_t s) {
     if (!a.Wb) return hipErrorInvalidValue;
     if (a.terms == 6) {
-        const size_t lds = (size_t)(3 * 16 * 64 + 2 * 3 * 8 * 64) * sizeof(bf16x8) + 512 * sizeof(float);      // 98 KiB
+        const size_t lds = (size_t)(3 * 16 * 64 + 3 * 8 * 64) * sizeof(bf16x8) + 512 * sizeof(float);      // 74 KiB: two workgroups per CU
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(freq_lstm_bf16x6_kernel<SHARED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((freq_lstm_bf16x6_kernel<SHARED>), dim3((unsigned)(a.Mc / 64 * 2)), dim3(256), lds, s, a);
