@@ -655,6 +655,7 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_bf16x6_kernel(FreqLstmArgs a
     for (int s = 0; s < 32; ++s) {
         const int f = dir ? 31 - s : s;
         constexpr int cur = 0;      // one x buffer (the macros keep the two-buffer signature of freq_lstm_bf16_kernel)
+        (void)cur;
 
         f32x16 acc[4][2];
 #pragma unroll
