@@ -405,6 +405,9 @@ class Engine(FrontendOnly):
             # piece's kernels, so they keep the kernel-efficient max_frames-sized pieces
             big = max(1, self.max_frames // (2 if ensemble else 1))
             sizes = piece_schedule(n, big, many=3072 if self.out_dim * 4 > 150_000 else big)
+        elif isinstance(piece, (list, tuple)):      # an explicit schedule (frames per piece; tools/timeline_batch.py)
+            sizes = [int(x) for x in piece]
+            assert sum(sizes) == n and all(0 < x <= self.max_frames for x in sizes)
         else:
             p = max(1, int(piece) // (2 if ensemble else 1))
             sizes = [min(p, n - f0) for f0 in range(0, n, p)]

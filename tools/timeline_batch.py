@@ -18,13 +18,17 @@ n = feat.shape[0]
 spk = torch.full((n,), 2, dtype=torch.int64, device="cuda")
 out = torch.empty((n, eng.out_dim), dtype=torch.float32, pin_memory=True)
 from sdfa_amd.engine import piece_schedule
-for piece in [int(a) for a in sys.argv[1:]] or [8192, 4096, 2048, 0]:      # 0 = the default schedule (piece_schedule)
+def parse(a):      # "4096" = uniform pieces, "0" = the default schedule, "4736,4224,..." = an explicit schedule
+    return [int(x) for x in a.split(",")] if "," in a else int(a)
+
+
+for piece in [parse(a) for a in sys.argv[1:]] or [8192, 4096, 2048, 0]:
     for rep in range(3):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         eng.forward_host(feat, spk, out=out, table=table, piece=piece or None)
         dt = (time.perf_counter() - t0) * 1e3
-    sizes = piece_schedule(n, eng.max_frames) if not piece else [min(piece, n - f) for f in range(0, n, piece)]
+    sizes = piece if isinstance(piece, list) else (piece_schedule(n, eng.max_frames) if not piece else [min(piece, n - f) for f in range(0, n, piece)])
     # instrumented repeat: events after each piece's regress (compute stream) and after each copy
     host = eng._host
     marks = []
@@ -43,5 +47,5 @@ for piece in [int(a) for a in sys.argv[1:]] or [8192, 4096, 2048, 0]:      # 0 =
         evs.append((f1 - f0, ec, ed))
         f0 = f1
     eng.host_wait(); torch.cuda.synchronize()
-    print(f"piece {piece}: whole call {dt:.1f} ms = {n / dt:.1f} k frames/s; per piece (frames, compute end ms, copy end ms):")
+    print(f"piece {piece if not isinstance(piece, list) else 'schedule'}: whole call {dt:.1f} ms = {n / dt:.1f} k frames/s; per piece (frames, compute end ms, copy end ms):")
     print("   ", [(m, round(start.elapsed_time(ec), 1), round(start.elapsed_time(ed), 1)) for m, ec, ed in evs])
