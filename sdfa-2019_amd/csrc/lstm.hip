@@ -619,8 +619,15 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_bf16x6_kernel(FreqLstmArgs a
     if (SHARED && m0 >= *a.col_limit) return;
 
     const float4 *__restrict__ X3 = reinterpret_cast<const float4 *>(a.X3);
-    const bf16x8 *__restrict__ W0 = reinterpret_cast<const bf16x8 *>(a.Wb) + (size_t)dir * BF16_PLANES * 24 * 512 + wave * 128 + l31;
-#define F6_W(pl, ks, gt) W0[((size_t)(pl) * 24 + 2 * (ks) + h) * 512 + (gt) * 32]
+    // weights through a buffer descriptor: uniform base + ONE 32-bit lane offset + a scalar offset per (plane, k-step) -- no 64-bit
+    // address registers (with lane pointers the kernel spilled and its per-step weight prologue was serialised behind scratch reloads)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned long long wptr6 = (unsigned long long)(reinterpret_cast<const bf16x8 *>(a.Wb) + (size_t)dir * BF16_PLANES * 24 * 512);
+    const unsigned long long wuni6 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(wptr6 >> 32)) << 32) |
+                                     (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wptr6);
+    const __amdgpu_buffer_rsrc_t wrs6 = __builtin_amdgcn_make_buffer_rsrc((void *)wuni6, 0, BF16_PLANES * 24 * 512 * 16, 0x00020000);
+    const unsigned woff6 = (unsigned)((wave * 128 + l31 + h * 512) * 16);
+#define F6_W(pl, ks, gt) __builtin_bit_cast(bf16x8, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(wrs6, woff6 + (unsigned)(gt) * 512u, (unsigned)(((pl) * 24 + 2 * (ks)) * 512 * 16), 0))
     float4 *__restrict__ HF = reinterpret_cast<float4 *>(a.HF);
 
     sBias[tid] = a.bias[dir * 512 + tid];
@@ -670,46 +677,61 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_bf16x6_kernel(FreqLstmArgs a
                 }
             }
         const int nks = s > 0 ? 12 : 4;      // k-steps of 16: 0..3 = x_f, 4..11 = h_{s-1} (skipped on the first step)
-        bf16x8 wa[4], wb[4];
+        // Three register sets, one per weight plane, each refilled two planes ahead of its use, and the order PINNED with scheduling
+        // barriers: left to itself the compiler sank every plane's requests to just in front of the MFMAs that consume them (the first
+        // build: s_waitcnt right behind the loads, an L2 round trip exposed three times per k-step, 80 ms per step for 50 of MFMAs).
+#define F6_SB() __builtin_amdgcn_sched_barrier(0);
+        bf16x8 wl[4], wm[4], wh[4];
 #pragma unroll
-        for (int gt = 0; gt < 4; ++gt) wa[gt] = F6_W(2, 0, gt);                 // lo plane of k-step 0
+        for (int gt = 0; gt < 4; ++gt) { wl[gt] = F6_W(2, 0, gt); wm[gt] = F6_W(1, 0, gt); }
 #pragma unroll 1
         for (int ks = 0; ks < nks; ++ks) {
             bf16x8 b[3][2];
+            const int kn = ks + 1 < nks ? ks + 1 : 0;                           // branch-free: the last requests are dropped
+            F6_SB()
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt) wh[gt] = F6_W(0, ks, gt);            // hi plane of this k-step: needed 24 MFMAs from here
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     b[pl][j] = ks < 4 ? F6_X(cur, pl, 2 * ks + h)[j * 32 + l31] : F6_H(pl, 2 * (ks - 4) + h)[j * 32 + l31];
-#pragma unroll
-            for (int gt = 0; gt < 4; ++gt) wb[gt] = F6_W(1, ks, gt);            // mid plane, requested while lo multiplies
-#pragma unroll
-            for (int gt = 0; gt < 4; ++gt)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[gt][j] = MFMA_BF16(wa[gt], b[0][j], acc[gt][j]);      // lo * hi
-#pragma unroll
-            for (int gt = 0; gt < 4; ++gt) wa[gt] = F6_W(0, ks, gt);            // hi plane, requested while mid multiplies
+            F6_SB()
 #pragma unroll
             for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[gt][j] = MFMA_BF16(wb[gt], b[1][j], acc[gt][j]);                              // mid * mid
-                    acc[gt][j] = MFMA_BF16(wb[gt], b[0][j], acc[gt][j]);                              // mid * hi
-                }
-            const int kn = ks + 1 < nks ? ks + 1 : 0;                           // branch-free: the last request is dropped
+                for (int j = 0; j < 2; ++j) acc[gt][j] = MFMA_BF16(wl[gt], b[0][j], acc[gt][j]);      // lo * hi
+            F6_SB()
 #pragma unroll
-            for (int gt = 0; gt < 4; ++gt) wb[gt] = F6_W(2, kn, gt);            // next k-step's lo plane, requested while hi multiplies
+            for (int gt = 0; gt < 4; ++gt) wl[gt] = F6_W(2, kn, gt);            // next k-step's lo plane: 40 MFMAs ahead
+            F6_SB()
 #pragma unroll
             for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[gt][j] = MFMA_BF16(wa[gt], b[2][j], acc[gt][j]);                              // hi * lo
-                    acc[gt][j] = MFMA_BF16(wa[gt], b[1][j], acc[gt][j]);                              // hi * mid
-                    acc[gt][j] = MFMA_BF16(wa[gt], b[0][j], acc[gt][j]);                              // hi * hi
-                }
+                for (int j = 0; j < 2; ++j) acc[gt][j] = MFMA_BF16(wm[gt], b[1][j], acc[gt][j]);      // mid * mid
 #pragma unroll
-            for (int gt = 0; gt < 4; ++gt) wa[gt] = wb[gt];
+            for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[gt][j] = MFMA_BF16(wm[gt], b[0][j], acc[gt][j]);      // mid * hi
+            F6_SB()
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt) wm[gt] = F6_W(1, kn, gt);            // next k-step's mid plane: 32 MFMAs ahead
+            F6_SB()
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[gt][j] = MFMA_BF16(wh[gt], b[2][j], acc[gt][j]);      // hi * lo
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[gt][j] = MFMA_BF16(wh[gt], b[1][j], acc[gt][j]);      // hi * mid
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[gt][j] = MFMA_BF16(wh[gt], b[0][j], acc[gt][j]);      // hi * hi
         }
+        F6_SB()
+#undef F6_SB
         __syncthreads();   // every wave has finished reading sH / sX[cur]
         if (s + 1 < 32) { F6_XLOAD(dir ? 30 - s : s + 1) }   // lands while the cell update runs
 #pragma unroll
@@ -737,6 +759,218 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_bf16x6_kernel(FreqLstmArgs a
 #undef F6_W
 #undef F6_H
 #undef F6_X
+}
+
+// ------------------------------------------------------------------ frequency LSTM on split bf16, ONE workgroup per CU (round 4)
+// freq_lstm_bf16x6_kernel (PL = 3 operand planes, six products) and freq_lstm_bf16_kernel<3> (PL = 2, three products) rebuilt the way
+// freq_lstm_v3_kernel rebuilt the fp32 recurrence: one wave per SIMD that never waits.
+//   * x_f and h planes live in ONE LDS image per step parity, [PL planes][8 x octets | 16 h octets][64 columns] (PL 3: 72 KiB, both
+//     parities 144 KiB; PL 2: 96 KiB): k-step ks reads octet rows 2ks, 2ks+1 whatever they hold (no select between two arrays), and h
+//     being double buffered leaves ONE barrier per step;
+//   * tiles come from a queue (a.tile_counter), one persistent workgroup per CU;
+//   * a k-step is six (three) groups of eight MFMAs; the weight requests and LDS reads that feed the NEXT k-step sit between the
+//     groups, each at least two groups ahead of its use, pinned with scheduling barriers; the last k-step of a step requests
+//     k-step 0's planes for the next step.
+// Same products in the same order per accumulator as the two-per-CU kernels: bit-identical to them.
+template <bool SHARED, bool PERSIST, int PL>
+__global__ __launch_bounds__(256, 2) void freq_lstm_bf16p_v3_kernel(FreqLstmArgs a) {
+    static_assert(PL == 2 || PL == 3, "two planes (split-bf16, three products) or three (six products)");
+    constexpr int ROWS = 24, BT = 64;
+    extern __shared__ bf16x8 sP6[];                             // [2 parities][PL][24 octet rows][64]
+    float *const sBias = reinterpret_cast<float *>(sP6 + 2 * PL * ROWS * BT);
+    int *const sTile = reinterpret_cast<int *>(sBias + 512);
+#define P6_ROW(par, pl, r) (sP6 + (((par) * PL + (pl)) * ROWS + (r)) * BT)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const float4 *__restrict__ X3 = reinterpret_cast<const float4 *>(a.X3);
+    float4 *__restrict__ HF = reinterpret_cast<float4 *>(a.HF);
+    const int n_tiles = (int)(a.Mc / BT) * 2;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned woff = (unsigned)((wave * 128 + l31 + h * 512) * 16);
+    constexpr unsigned W_PLANE = 24u * 512u * 16u, W_KS = 2u * 512u * 16u;      // bytes: one plane, one k-step (two octet rows of 512 gate rows)
+#define P6_SB() __builtin_amdgcn_sched_barrier(0);
+#define P6_W(so, gt) __builtin_bit_cast(bf16x8, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(wrs, woff + (unsigned)(gt) * 512u, (so), 0))
+#define P6_WSET(dst, so) { dst[0] = P6_W(so, 0); dst[1] = P6_W(so, 1); dst[2] = P6_W(so, 2); dst[3] = P6_W(so, 3); }
+#define P6_G(wset, bset)                                                                          \
+    {                                                                                             \
+        acc[0][0] = MFMA_BF16(wset[0], bset[0], acc[0][0]); acc[0][1] = MFMA_BF16(wset[0], bset[1], acc[0][1]); \
+        acc[1][0] = MFMA_BF16(wset[1], bset[0], acc[1][0]); acc[1][1] = MFMA_BF16(wset[1], bset[1], acc[1][1]); \
+        acc[2][0] = MFMA_BF16(wset[2], bset[0], acc[2][0]); acc[2][1] = MFMA_BF16(wset[2], bset[1], acc[2][1]); \
+        acc[3][0] = MFMA_BF16(wset[3], bset[0], acc[3][0]); acc[3][1] = MFMA_BF16(wset[3], bset[1], acc[3][1]); \
+    }
+    // one k-step: weights of this k-step at byte offset `so`, of the next at `son`; next k-step's operand rows at `bn` (lane pointer
+    // into plane 0); B0C / B0N = this / the next k-step's hi operand plane (ping-pong), b1 / b2 = mid / lo planes (refilled in place)
+#define P6_KS(B0C, B0N, so, son, bn)                                                              \
+    {                                                                                             \
+        P6_SB() P6_WSET(wh, (so)) P6_SB()                                                         \
+        P6_G(wl, B0C)                                             /* lo  * hi  */                 \
+        P6_SB() P6_WSET(wl, 2u * W_PLANE + (son)) P6_SB()                                         \
+        P6_G(wm, b1)                                              /* mid * mid */                 \
+        P6_G(wm, B0C)                                             /* mid * hi  */                 \
+        P6_SB() P6_WSET(wm, W_PLANE + (son)) P6_SB()                                              \
+        P6_G(wh, b2)                                              /* hi  * lo  */                 \
+        P6_SB() b2[0] = (bn)[2 * ROWS * BT]; b2[1] = (bn)[2 * ROWS * BT + 32]; P6_SB()            \
+        P6_G(wh, b1)                                              /* hi  * mid */                 \
+        P6_SB() b1[0] = (bn)[ROWS * BT]; b1[1] = (bn)[ROWS * BT + 32]; B0N[0] = (bn)[0]; B0N[1] = (bn)[32]; P6_SB() \
+        P6_G(wh, B0C)                                             /* hi  * hi  */                 \
+    }
+    // PL 2: products hi*hi, hi*lo, lo*hi (the order of freq_lstm_bf16_kernel<3>); the hi weight plane ping-pongs (requested a whole
+    // k-step ahead), the lo plane is refilled behind its group (two groups ahead of its next use)
+#define P3_KS(WHC, WHN, B0C, B0N, so, son, bn)                                                    \
+    {                                                                                             \
+        P6_SB() P6_WSET(WHN, (son)) P6_SB()                                                       \
+        P6_G(WHC, B0C)                                            /* hi * hi */                   \
+        P6_SB() B0N[0] = (bn)[0]; B0N[1] = (bn)[32]; P6_SB()                                      \
+        P6_G(WHC, b1)                                             /* hi * lo */                   \
+        P6_SB() b1[0] = (bn)[ROWS * BT]; b1[1] = (bn)[ROWS * BT + 32]; P6_SB()                    \
+        P6_G(wl, B0C)                                             /* lo * hi */                   \
+        P6_SB() P6_WSET(wl, W_PLANE + (son)) P6_SB()                                              \
+    }
+  for (;;) {      // PERSIST: one pass per tile taken from the queue; otherwise a single pass
+    int dir;
+    int64_t m0;
+    if (PERSIST) {
+        if (tid == 0) *sTile = atomicAdd(a.tile_counter, 1);
+        __syncthreads();                       // (also: every wave has left the previous tile's last step)
+        const int t = __builtin_amdgcn_readfirstlane(*sTile);
+        if (t >= n_tiles) break;               // queue empty: every workgroup gets here
+        dir = t & 1;
+        m0 = (int64_t)(t >> 1) * BT;
+        if (SHARED && m0 >= *a.col_limit) break;
+    } else {
+        dir = (blockIdx.x >> 3) & 1;
+        m0 = (int64_t)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) * BT;
+        if (SHARED && m0 >= *a.col_limit) return;
+    }
+    const unsigned long long wptr = (unsigned long long)(reinterpret_cast<const bf16x8 *>(a.Wb) + (size_t)dir * BF16_PLANES * 24 * 512);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)wptr, 0, BF16_PLANES * 24 * 512 * 16, 0x00020000);
+    sBias[tid] = a.bias[dir * 512 + tid];
+    sBias[256 + tid] = a.bias[dir * 512 + 256 + tid];
+
+    // x_f tile of a step: 8 octets of 64 columns; thread (wave, lane) stages octets wave and 4 + wave of column lane
+    const float4 *__restrict__ xsrc = X3 + (int64_t)(2 * wave) * a.Mc + m0 + lane;
+    float4 xr0, xr1, xr2, xr3;
+#define P6_XLOAD(f)                                                                               \
+    {                                                                                             \
+        const float4 *xs = xsrc + (int64_t)((f) * 16) * a.Mc;                                     \
+        xr0 = xs[0]; xr1 = xs[a.Mc]; xr2 = xs[8 * a.Mc]; xr3 = xs[9 * a.Mc];                      \
+    }
+#define P6_SPLIT_STORE(par, row, col, q0, q1)                                                     \
+    {                                                                                             \
+        bf16x8 hi, mid, lo;                                                                       \
+        if constexpr (PL == 3) {                                                                  \
+            split_octet3(q0, q1, hi, mid, lo);                                                    \
+            P6_ROW(par, 0, row)[col] = hi; P6_ROW(par, 1, row)[col] = mid; P6_ROW(par, 2, row)[col] = lo; \
+        } else {                                                                                  \
+            split_octet(q0, q1, hi, lo);                                                          \
+            P6_ROW(par, 0, row)[col] = hi; P6_ROW(par, 1, row)[col] = lo;                         \
+        }                                                                                         \
+    }
+#define P6_XSTORE(par) { P6_SPLIT_STORE(par, wave, lane, xr0, xr1) P6_SPLIT_STORE(par, 4 + wave, lane, xr2, xr3) }
+    P6_XLOAD(dir ? 31 : 0)
+    bf16x8 wl[4], wm[4], wh[4];                             // PL 3: lo, mid, hi planes; PL 2: wl = lo plane, wh / wm = the hi plane's ping-pong pair
+    if constexpr (PL == 3) { P6_WSET(wl, 2u * W_PLANE) P6_WSET(wm, W_PLANE) }     // k-step 0, lo and mid planes
+    else { P6_WSET(wh, 0u) P6_WSET(wl, W_PLANE) }                                 // k-step 0, hi and lo planes
+    P6_XSTORE(0)
+
+    f32x16 c[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[j][r] = 0.f;
+    __syncthreads();   // bias and the first x tile are in LDS
+#ifdef SDFA_STAMPS
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, v_init = 0, v_k = 0, v_ep = 0, v_b2 = 0;
+#endif
+
+    for (int s = 0; s < 32; ++s) {
+        const int f = dir ? 31 - s : s;
+        const int cur = s & 1;
+        f32x16 acc[4][2];
+        LSTAMP(t0)
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 b = *reinterpret_cast<const float4 *>(&sBias[wave * 128 + gt * 32 + 8 * g + 4 * h]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[gt][j][4 * g + 0] = b.x; acc[gt][j][4 * g + 1] = b.y;
+                    acc[gt][j][4 * g + 2] = b.z; acc[gt][j][4 * g + 3] = b.w;
+                }
+            }
+        const int trips = s > 0 ? 3 : 1;       // h_{-1} = 0: the first step contracts x_f only (4 of the 12 k-steps)
+        const bf16x8 *brow = P6_ROW(cur, 0, h) + l31;            // operand rows of k-step ks: brow + ks * 2 * BT (+ plane * ROWS * BT, + 32 for the second column tile)
+        bf16x8 b0a[2], b0b[2], b1[2], b2[2];
+        b0a[0] = brow[0]; b0a[1] = brow[32];
+        b1[0] = brow[ROWS * BT]; b1[1] = brow[ROWS * BT + 32];
+        if constexpr (PL == 3) { b2[0] = brow[2 * ROWS * BT]; b2[1] = brow[2 * ROWS * BT + 32]; }
+        LSTAMP(t1)
+#pragma unroll 1
+        for (int t = 0; t < trips; ++t) {
+            const bf16x8 *bt = brow + t * 4 * 2 * BT;
+            const bf16x8 *bn = t + 1 < trips ? bt + 4 * 2 * BT : brow;       // behind the last trip: k-step 0 again (operands dropped)
+            const unsigned so = (unsigned)t * (4u * W_KS);
+            const unsigned son = t + 1 < trips ? so + 4u * W_KS : 0u;        // ... whose weights ARE k-step 0 of the next step
+            if constexpr (PL == 3) {
+                P6_KS(b0a, b0b, so, so + 1u * W_KS, bt + 1 * 2 * BT)
+                P6_KS(b0b, b0a, so + 1u * W_KS, so + 2u * W_KS, bt + 2 * 2 * BT)
+                P6_KS(b0a, b0b, so + 2u * W_KS, so + 3u * W_KS, bt + 3 * 2 * BT)
+                P6_KS(b0b, b0a, so + 3u * W_KS, son, bn)
+            } else {
+                P3_KS(wh, wm, b0a, b0b, so, so + 1u * W_KS, bt + 1 * 2 * BT)
+                P3_KS(wm, wh, b0b, b0a, so + 1u * W_KS, so + 2u * W_KS, bt + 2 * 2 * BT)
+                P3_KS(wh, wm, b0a, b0b, so + 2u * W_KS, so + 3u * W_KS, bt + 3 * 2 * BT)
+                P3_KS(wm, wh, b0b, b0a, so + 3u * W_KS, son, bn)
+            }
+        }
+        P6_SB()
+#ifdef SDFA_STAMPS
+        asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]), "v"(acc[0][1]), "v"(acc[1][1]), "v"(acc[2][1]), "v"(acc[3][1]));   // all MFMAs done
+#endif
+        LSTAMP(t2)
+        // the next x tile: requested BEHIND the step's last weight requests (loads return in issue order), split and written to the
+        // other parity after the cell update, which covers the round trip
+        P6_XLOAD(s + 1 < 32 ? (dir ? 30 - s : s + 1) : f)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float4 hq[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                lstm_cell_quad<true>(acc[0][j], acc[1][j], acc[2][j], acc[3][j], c[j], g, hq[g]);
+                HF[((m0 >> 7) * (int64_t)HF_SLAB_ROWS + (f * 64 + dir * 32 + 8 * wave + 2 * g + h)) * 128 + (m0 & 127) + j * 32 + l31] = hq[g];
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) P6_SPLIT_STORE(cur ^ 1, 8 + 4 * wave + 2 * q + h, j * 32 + l31, hq[2 * q], hq[2 * q + 1])
+        }
+        P6_XSTORE(cur ^ 1)
+        LSTAMP(t3)
+        // h_s and the next x tile must be in LDS before anyone starts step s+1 (the hidden-state stores need not be acknowledged)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef SDFA_STAMPS
+        LSTAMP(t4)
+        if (s > 0) { v_init += t1 - t0; v_k += t2 - t1; v_ep += t3 - t2; v_b2 += t4 - t3; }
+#endif
+    }
+#ifdef SDFA_STAMPS
+    if (lane == 0) {
+        atomicAdd(&g_lstamp[0], v_init); atomicAdd(&g_lstamp[1], v_k); atomicAdd(&g_lstamp[3], v_ep); atomicAdd(&g_lstamp[4], v_b2); atomicAdd(&g_lstamp[6], 31ull);
+    }
+#endif
+    if (!PERSIST) break;
+  }
+#undef P6_ROW
+#undef P6_SB
+#undef P6_W
+#undef P6_WSET
+#undef P6_G
+#undef P6_KS
+#undef P3_KS
+#undef P6_SPLIT_STORE
+#undef P6_XLOAD
+#undef P6_XSTORE
 }
 
 template <bool SHARED, int TERMS>
@@ -1663,7 +1897,32 @@ static hipError_t launch_freq(const FreqLstmArgs &a, hipStream_t s) {
 template <bool SHARED>
 static hipError_t launch_freq_bf16(const FreqLstmArgs &a, hipStream_t s) {
     if (!a.Wb) return hipErrorInvalidValue;
-    if (a.terms == 6) {
+    if ((a.terms == 6 || a.terms == 3) && a.shape != 3) {      // default: one persistent workgroup per CU (shape 8: one hardware-dispatched workgroup per tile)
+        const int pl = a.terms == 6 ? 3 : 2;
+        const size_t lds = (size_t)(2 * pl * 24 * 64) * sizeof(bf16x8) + 512 * sizeof(float) + 16;         // 146 KiB / 98 KiB
+        const unsigned n_tiles = (unsigned)(a.Mc / 64 * 2);
+        const bool persist = a.shape != 8;
+        const void *fn = pl == 3 ? (persist ? reinterpret_cast<const void *>(freq_lstm_bf16p_v3_kernel<SHARED, true, 3>) : reinterpret_cast<const void *>(freq_lstm_bf16p_v3_kernel<SHARED, false, 3>))
+                                 : (persist ? reinterpret_cast<const void *>(freq_lstm_bf16p_v3_kernel<SHARED, true, 2>) : reinterpret_cast<const void *>(freq_lstm_bf16p_v3_kernel<SHARED, false, 2>));
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        unsigned grid = n_tiles;
+        if (persist) {
+            const unsigned cus = (unsigned)std::max(1, sdfa_cu_count() - a.reserve_cus);
+            grid = n_tiles < cus ? n_tiles : cus;
+            e = hipMemsetAsync(a.tile_counter, 0, sizeof(int), s);
+            if (e != hipSuccess) return e;
+        }
+        if (pl == 3) {
+            if (persist) hipLaunchKernelGGL((freq_lstm_bf16p_v3_kernel<SHARED, true, 3>), dim3(grid), dim3(256), lds, s, a);
+            else hipLaunchKernelGGL((freq_lstm_bf16p_v3_kernel<SHARED, false, 3>), dim3(grid), dim3(256), lds, s, a);
+        } else {
+            if (persist) hipLaunchKernelGGL((freq_lstm_bf16p_v3_kernel<SHARED, true, 2>), dim3(grid), dim3(256), lds, s, a);
+            else hipLaunchKernelGGL((freq_lstm_bf16p_v3_kernel<SHARED, false, 2>), dim3(grid), dim3(256), lds, s, a);
+        }
+        return hipGetLastError();
+    }
+    if (a.terms == 6) {                      // shape 3: the two-per-CU form (shares a CU with other streams' kernels)
         const size_t lds = (size_t)(3 * 16 * 64 + 3 * 8 * 64) * sizeof(bf16x8) + 512 * sizeof(float);      // 74 KiB: two workgroups per CU
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(freq_lstm_bf16x6_kernel<SHARED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

@@ -112,6 +112,31 @@ def test_six_product_split_on_other_shapes(eng, synth_sd):
     assert float((o6 - o32).abs().max()) <= 5e-6
 
 
+@pytest.mark.parametrize("mode", ["bf16x6", "bf16x3"])
+def test_split_bf16_frequency_lstm_forms_agree_bitwise(eng, mode):
+    """freq_lstm_bf16p_v3_kernel (one persistent workgroup per CU: the default; freq_lstm_shape 8 = one workgroup per tile) makes the
+    products of freq_lstm_bf16x6_kernel / freq_lstm_bf16_kernel<3> (freq_lstm_shape 3, two workgroups per CU) in the same order: the
+    same bits, whatever the tile-to-workgroup assignment, for a batch that fills the queue several times over and for a single clip."""
+    from sdfa_amd import _lib
+    rs = np.random.RandomState(12)
+    try:
+        eng.set_precision(mode)
+        for n in (2304, 156):
+            x = torch.from_numpy(rs.uniform(0, 1, (n, 64, 128, 3)).astype(np.float32)).cuda()
+            got = {}
+            for shape in (0, 3, 8, 0):
+                _lib.set_option("freq_lstm_shape", shape)
+                z, al = eng.encoder(x)
+                got.setdefault(shape, []).append((z.clone(), al.clone()))
+            z0, a0 = got[0][0]
+            for shape, rows in got.items():
+                for z, al in rows:
+                    assert torch.equal(z, z0) and torch.equal(al, a0), (n, shape)
+    finally:
+        _lib.set_option("freq_lstm_shape", 0)
+        eng.set_precision("fp32")
+
+
 def test_column_sharing_is_exact_in_split_bf16(eng):
     """Column sharing evaluates each distinct column once; a column's arithmetic does not depend on its position in the
     launch, so the shared and unshared encoders agree bitwise in the bf16 modes too."""

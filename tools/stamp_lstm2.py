@@ -13,6 +13,8 @@ from sdfa_amd import _lib
 if os.environ.get("SDFA_FORM"):
     _lib.set_option("freq_lstm_shape", int(os.environ["SDFA_FORM"]))      # e.g. SDFA_FORM=8: freq_lstm_v3_kernel (no barrier-1 / sub-phase stamps there)
 eng = Engine(synth.make_state_dict("dgrad", 1234), max_frames=8192)
+if os.environ.get("SDFA_PREC"):
+    eng.set_precision(os.environ["SDFA_PREC"])       # e.g. SDFA_PREC=bf16x6: freq_lstm_bf16p_v3_kernel (48 MFMAs of 32 cycles per k-step, 12 k-steps = 18,432)
 x = torch.rand((8192, 64, 128, 3), device="cuda")
 out = (C.c_ulonglong * 8)()
 span = (C.c_ulonglong * 4)()
@@ -41,6 +43,10 @@ e0, e1, e2 = (int(x) / n for x in sub[:3])
 print(f"  inside the cell-update phase: x DMA issue {e0:.0f}, columns 0-31 (4 quads: math, LDS write, store) {e1:.0f}, columns 32-63 {e2:.0f}, final wait (DMA landed, LDS writes done) {v[3] / n - e0 - e1 - e2:.0f}")
 lib.sdfa_debug_read_lstm_span(span, 0)
 t0, t1, life_ticks, life_cyc = (int(x) for x in span)
+if t1 <= t0 or not life_ticks:      # kernels without lifetime stamps (freq_lstm_v3_kernel, freq_lstm_bf16p_v3_kernel): the clock from the launch time instead
+    tiles_per_cu = 8192 * 2 / 256
+    print(f"  shader clock over the launch ~ {tiles_per_cu * 32 * sum(v[:5]) / n / (ms * 1e-3) / 1e9:.2f} GHz ({tiles_per_cu:.0f} tiles per CU x 32 steps x the total above / launch time; tile prologues not counted)")
+    sys.exit(0)
 slots = 256 * (1 if os.environ.get("SDFA_LONE") else 2)
 n_wg = 8192 * 2
 print(f"  launch span (first workgroup start -> last end) {(t1 - t0) / 100e3:.2f} ms; sum of workgroup lifetimes / {slots} slots = {life_ticks / slots / 100e3:.2f} ms "
