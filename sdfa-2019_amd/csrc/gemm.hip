@@ -522,30 +522,58 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_big_kernel(GemmArgs a) {
     const unsigned boffP = (unsigned)((2 * g0 * a.ldp + c) * 16);
     const unsigned boffQ = a.q_tile_major ? (unsigned)((((int64_t)(c >> 7) * a.q_slab_rows + 2 * g0) * 128 + (c & 127)) * 16)
                                           : (unsigned)((2 * g0 * qrow + c) * 16);
+    // Software pipeline (round 4): the registers hold stage st+1 while stage st multiplies; each of a thread's four octets (two items x
+    // P, Q) is split and written to the OTHER LDS buffer between the MFMAs of stage st -- three pairs of elements, then the last pair,
+    // the LDS writes and the REFILL of the same registers with stage st+2 (consumed a whole stage later), one such piece behind every
+    // row of six MFMAs, pinned with scheduling barriers.  (Before: split + stores behind the stage's last MFMA, 200 vector
+    // instructions per wave in front of every barrier.)  Requests are unconditional -- one under a branch makes every later vmcnt
+    // wait a full drain -- so the running pointers stop at the last stage, which the requests behind it re-read (dropped).
     float4 rp[2][2], rq[2][2];   // [item][quad of the octet]
-#ifdef SDFA_GEMM_SAMEP   /* timing experiment only: every stage re-reads the first weight rows */
-#define BB_PSTEP
-#else
-#define BB_PSTEP Pn += KQ * a.ldp;
-#endif
-#define BB_GLOAD()                                                                                              \
-    {                                                                                                           \
-        _Pragma("unroll") for (int it = 0; it < 2; ++it)                                                        \
-            _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                     \
-                rp[it][e] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Pn + (4 * it + e) * a.ldp) + boffP); \
-                rq[it][e] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Qn + (4 * it + e) * qrow) + boffQ);  \
-            }                                                                                                   \
-        BB_PSTEP                                                                                                \
+    int next_k = 0;              // stage the running pointers address
+#define BB_SB() __builtin_amdgcn_sched_barrier(0);
+#define BB_LOADP(it) { _Pragma("unroll") for (int e = 0; e < 2; ++e) rp[it][e] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Pn + (4 * (it) + e) * a.ldp) + boffP); }
+#define BB_LOADQ(it) { _Pragma("unroll") for (int e = 0; e < 2; ++e) rq[it][e] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Qn + (4 * (it) + e) * qrow) + boffQ); }
+#define BB_ADVANCE()                                                                                            \
+    if (++next_k < nstage) {                                                                                    \
+        Pn += KQ * a.ldp;                                                                                       \
         kin_n += KQ;                                                                                            \
         if (kin_n == seg_kq) { kin_n = 0; Qn += a.seg_col - (int64_t)(seg_kq - KQ) * qrow; }                    \
         else Qn += KQ * qrow;                                                                                   \
     }
-#define BB_LSTORE(buf)                                                                                          \
-    _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                                          \
-        const int g = 2 * it + g0;                                                                              \
-        bf16x8 hi, lo;                                                                                          \
-        split8(rp[it][0], rp[it][1], hi, lo); SPL(buf, 0, 0)[g * BT + c] = hi; if (LO) SPL(buf, 0, NPL - 1)[g * BT + c] = lo; \
-        split8(rq[it][0], rq[it][1], hi, lo); SPL(buf, 1, 0)[g * BT + c] = hi; if (LO) SPL(buf, 1, NPL - 1)[g * BT + c] = lo; \
+    // elements 2e, 2e+1 of an octet held as two float4 -> the planes
+#define BB_PAIR(R, e)                                                                                           \
+    {                                                                                                           \
+        const float x0 = f4c(R[(e) >> 1], (2 * (e)) & 3), x1 = f4c(R[(e) >> 1], (2 * (e) + 1) & 3);             \
+        const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;                                                          \
+        shi[2 * (e)] = h0; shi[2 * (e) + 1] = h1;                                                               \
+        if (LO) { slo[2 * (e)] = (__bf16)(x0 - (float)h0); slo[2 * (e) + 1] = (__bf16)(x1 - (float)h1); }       \
+    }
+#define BB_WRITE(buf, pq, it) { SPL(buf, pq, 0)[(2 * (it) + g0) * BT + c] = shi; if (LO) SPL(buf, pq, NPL - 1)[(2 * (it) + g0) * BT + c] = slo; }
+    // the two pieces of octet o (0, 1 = P items; 2, 3 = Q items) of the stage in registers
+#define BB_PIECE_A(o) { if ((o) < 2) { BB_PAIR(rp[(o) & 1], 0) BB_PAIR(rp[(o) & 1], 1) BB_PAIR(rp[(o) & 1], 2) } else { BB_PAIR(rq[(o) & 1], 0) BB_PAIR(rq[(o) & 1], 1) BB_PAIR(rq[(o) & 1], 2) } }
+#define BB_PIECE_B(buf, o)                                                                                      \
+    {                                                                                                           \
+        if ((o) < 2) { BB_PAIR(rp[(o) & 1], 3) BB_WRITE((buf) ^ 1, 0, (o) & 1) BB_LOADP((o) & 1) }              \
+        else { BB_PAIR(rq[(o) & 1], 3) BB_WRITE((buf) ^ 1, 1, (o) & 1) BB_LOADQ((o) & 1) }                      \
+    }
+#define BB_ROW(i)                                                                                               \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                             \
+        if (LO) {                                                                                               \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);              \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);              \
+        }                                                                                                       \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);                  \
+    }
+#define BB_READS(buf, m)                                                                                        \
+    {                                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
+            ah[i] = SPL(buf, 0, 0)[(2 * (m) + h) * BT + wp * 128 + i * 32 + l31];                               \
+            if (LO) al[i] = SPL(buf, 0, NPL - 1)[(2 * (m) + h) * BT + wp * 128 + i * 32 + l31];                 \
+        }                                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                         \
+            bh[j] = SPL(buf, 1, 0)[(2 * (m) + h) * BT + wq * 64 + j * 32 + l31];                                \
+            if (LO) bl[j] = SPL(buf, 1, NPL - 1)[(2 * (m) + h) * BT + wq * 64 + j * 32 + l31];                  \
+        }                                                                                                       \
     }
 
     f32x16 acc[4][2];
@@ -556,46 +584,48 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_big_kernel(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    BB_GLOAD()
-    BB_LSTORE(0)
+    BB_LOADP(0) BB_LOADQ(0) BB_LOADP(1) BB_LOADQ(1) BB_ADVANCE()
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int g = 2 * it + g0;
+        bf16x8 hi, lo;
+        split8(rp[it][0], rp[it][1], hi, lo); SPL(0, 0, 0)[g * BT + c] = hi; if (LO) SPL(0, 0, NPL - 1)[g * BT + c] = lo;
+        split8(rq[it][0], rq[it][1], hi, lo); SPL(0, 1, 0)[g * BT + c] = hi; if (LO) SPL(0, 1, NPL - 1)[g * BT + c] = lo;
+    }
+    BB_LOADP(0) BB_LOADQ(0) BB_LOADP(1) BB_LOADQ(1) BB_ADVANCE()
     __syncthreads();
+#ifdef SDFA_GEMM_LOADONLY   /* timing experiment only: the operand stream without LDS staging and matrix work */
+    for (int st = 0; st + 2 < nstage; ++st) {
+        acc[0][0][0] += rp[0][0].x + rp[0][1].y + rp[1][0].z + rp[1][1].w + rq[0][0].x + rq[0][1].y + rq[1][0].z + rq[1][1].w;
+        BB_LOADP(0) BB_LOADQ(0) BB_LOADP(1) BB_LOADQ(1) BB_ADVANCE()
+    }
+#else
+    // (behind the last stage the registers hold stale operands: they are split and written to the buffer nobody reads any more)
     for (int st = 0; st < nstage; ++st) {
         const int buf = st & 1;
-        const bool reload = st + 1 < nstage;
-        if (reload) { BB_GLOAD() }
-#ifdef SDFA_GEMM_LOADONLY   /* timing experiment only: the operand stream without LDS staging and matrix work */
-        acc[0][0][0] += rp[0][0].x + rp[0][1].y + rp[1][0].z + rp[1][1].w + rq[0][0].x + rq[0][1].y + rq[1][0].z + rq[1][1].w;
-        continue;
-#endif
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {   // two k-steps of 16
-            bf16x8 ah[4], al[4], bh[2], bl[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ah[i] = SPL(buf, 0, 0)[(2 * m + h) * BT + wp * 128 + i * 32 + l31];
-                if (LO) al[i] = SPL(buf, 0, NPL - 1)[(2 * m + h) * BT + wp * 128 + i * 32 + l31];
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                bh[j] = SPL(buf, 1, 0)[(2 * m + h) * BT + wq * 64 + j * 32 + l31];
-                if (LO) bl[j] = SPL(buf, 1, NPL - 1)[(2 * m + h) * BT + wq * 64 + j * 32 + l31];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (LO) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
-        }
-        if (reload) { BB_LSTORE(buf ^ 1) }
+        bf16x8 ah[4], al[4], bh[2], bl[2], shi, slo;
+        BB_SB() BB_READS(buf, 0) BB_SB()
+        BB_ROW(0) BB_SB() BB_PIECE_A(0) BB_SB()
+        BB_ROW(1) BB_SB() BB_PIECE_B(buf, 0) BB_SB()
+        BB_ROW(2) BB_SB() BB_PIECE_A(2) BB_SB()
+        BB_ROW(3) BB_SB() BB_PIECE_B(buf, 2) BB_READS(buf, 1) BB_SB()
+        BB_ROW(0) BB_SB() BB_PIECE_A(1) BB_SB()
+        BB_ROW(1) BB_SB() BB_PIECE_B(buf, 1) BB_SB()
+        BB_ROW(2) BB_SB() BB_PIECE_A(3) BB_SB()
+        BB_ROW(3) BB_SB() BB_PIECE_B(buf, 3) BB_ADVANCE() BB_SB()
         __syncthreads();
     }
-#undef BB_GLOAD
-#undef BB_LSTORE
+#endif
+#undef BB_SB
+#undef BB_LOADP
+#undef BB_LOADQ
+#undef BB_ADVANCE
+#undef BB_PAIR
+#undef BB_WRITE
+#undef BB_PIECE_A
+#undef BB_PIECE_B
+#undef BB_ROW
+#undef BB_READS
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -646,23 +676,67 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x6_big_kernel(GemmArgs a) {
     const unsigned boffP = (unsigned)((2 * g0 * a.ldp + c) * 16);
     const unsigned boffQ = a.q_tile_major ? (unsigned)((((int64_t)(c >> 7) * a.q_slab_rows + 2 * g0) * 128 + (c & 127)) * 16)
                                           : (unsigned)((2 * g0 * qrow + c) * 16);
-    float4 rp[2], rq[2];
-#define B6B_GLOAD()                                                                                             \
+    // Software pipeline, two stages deep: the operands of stage st+2 are requested at the top of stage st; those of stage st+1 -- in
+    // registers since the previous stage -- are split into planes and written to the other LDS buffer BETWEEN the MFMAs of stage st,
+    // a pair of elements (or three ds_write_b128) behind every fourth MFMA pair, pinned with scheduling barriers.  (The first build split
+    // and stored behind the stage's last MFMA: ~110 vector instructions + 6 LDS writes per wave in front of every barrier, with both
+    // waves of a SIMD arriving there together; a timing build without staging ran the frequency projection in 18.7 ms instead of 25.8.)
+    float4 rpA[2], rqA[2], rpB[2], rqB[2];
+    int next_k = 0;                 // stage the running pointers address
+#define B6B_GLOAD(RP, RQ)                                                                                       \
     {                                                                                                           \
         _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                         \
-            rp[e] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Pn + e * a.ldp) + boffP);   \
-            rq[e] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Qn + e * qrow) + boffQ);    \
+            RP[e] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Pn + e * a.ldp) + boffP);   \
+            RQ[e] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Qn + e * qrow) + boffQ);    \
         }                                                                                                       \
-        Pn += KQS * a.ldp;                                                                                      \
-        kin_n += KQS;                                                                                           \
-        if (kin_n == seg_kq) { kin_n = 0; Qn += a.seg_col - (int64_t)(seg_kq - KQS) * qrow; }                   \
-        else Qn += KQS * qrow;                                                                                  \
+        if (++next_k < nstage) {      /* the pointers never pass the last stage: the requests behind it re-read it (dropped) */ \
+            Pn += KQS * a.ldp;                                                                                  \
+            kin_n += KQS;                                                                                       \
+            if (kin_n == seg_kq) { kin_n = 0; Qn += a.seg_col - (int64_t)(seg_kq - KQS) * qrow; }               \
+            else Qn += KQS * qrow;                                                                              \
+        }                                                                                                       \
     }
-#define B6B_LSTORE(buf)                                                                                         \
+#define B6B_SB() __builtin_amdgcn_sched_barrier(0);
+    // elements 2e, 2e+1 of an octet held as two float4 -> the three planes
+#define B6B_PAIR(R, e, HI, MID, LO)                                                                             \
     {                                                                                                           \
-        bf16x8 hi, mid, lo;                                                                                     \
-        split8x3(rp[0], rp[1], hi, mid, lo); S6B(buf, 0, 0)[g0 * BT + c] = hi; S6B(buf, 0, 1)[g0 * BT + c] = mid; S6B(buf, 0, 2)[g0 * BT + c] = lo; \
-        split8x3(rq[0], rq[1], hi, mid, lo); S6B(buf, 1, 0)[g0 * BT + c] = hi; S6B(buf, 1, 1)[g0 * BT + c] = mid; S6B(buf, 1, 2)[g0 * BT + c] = lo; \
+        const float x0 = f4c(R[(e) >> 1], (2 * (e)) & 3), x1 = f4c(R[(e) >> 1], (2 * (e) + 1) & 3);             \
+        const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;                                                          \
+        const float r0 = x0 - (float)h0, r1 = x1 - (float)h1;                                                   \
+        const __bf16 m0 = (__bf16)r0, m1 = (__bf16)r1;                                                          \
+        HI[2 * (e)] = h0; HI[2 * (e) + 1] = h1; MID[2 * (e)] = m0; MID[2 * (e) + 1] = m1;                       \
+        LO[2 * (e)] = (__bf16)(r0 - (float)m0); LO[2 * (e) + 1] = (__bf16)(r1 - (float)m1);                     \
+    }
+#define B6B_WRITE(buf, pq, HI, MID, LO) { S6B(buf, pq, 0)[g0 * BT + c] = HI; S6B(buf, pq, 1)[g0 * BT + c] = MID; S6B(buf, pq, 2)[g0 * BT + c] = LO; }
+#define B6B_MF(t, i)                                                                                            \
+    {                                                                                                           \
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[PA[t]][i], bq[PB[t]][0], acc[i][0], 0, 0, 0);    \
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[PA[t]][i], bq[PB[t]][1], acc[i][1], 0, 0, 0);    \
+    }
+#define B6B_GROUP(t) { B6B_MF(t, 0) B6B_MF(t, 1) B6B_MF(t, 2) B6B_MF(t, 3) }
+#define B6B_APLANE(buf, pl) { _Pragma("unroll") for (int i = 0; i < 4; ++i) ap[pl][i] = S6B(buf, 0, pl)[h * BT + wp * 128 + i * 32 + l31]; }
+#define B6B_BPLANE(buf, pl) { _Pragma("unroll") for (int j = 0; j < 2; ++j) bq[pl][j] = S6B(buf, 1, pl)[h * BT + wq * 64 + j * 32 + l31]; }
+    // one stage on LDS buffer `buf`: RC* hold stage st+1 (split and written to buf ^ 1 here), RN* receive stage st+2; product groups
+    // 0..5 = hi*lo, mid*mid, lo*hi, hi*mid, mid*hi, hi*hi (PA / PB), each 4 x 2 MFMAs
+#define B6B_STAGE(st, buf, RCP, RCQ, RNP, RNQ)                                                                  \
+    {                                                                                                           \
+        bf16x8 ap[3][4], bq[3][2], shi, smid, slo;                                                              \
+        B6B_SB()                                                                                                \
+        B6B_GLOAD(RNP, RNQ)       /* UNconditional: a request under a branch makes every later vmcnt wait a full drain */ \
+        B6B_APLANE(buf, 0) B6B_BPLANE(buf, 2) B6B_APLANE(buf, 1) B6B_BPLANE(buf, 1)                             \
+        B6B_SB() B6B_GROUP(0) B6B_SB()                                                                          \
+        B6B_APLANE(buf, 2) B6B_BPLANE(buf, 0) B6B_PAIR(RCP, 0, shi, smid, slo)                                  \
+        B6B_SB() B6B_MF(1, 0) B6B_MF(1, 1) B6B_SB() B6B_PAIR(RCP, 1, shi, smid, slo)                            \
+        B6B_SB() B6B_MF(1, 2) B6B_MF(1, 3) B6B_SB() B6B_PAIR(RCP, 2, shi, smid, slo)                            \
+        B6B_SB() B6B_MF(2, 0) B6B_MF(2, 1) B6B_SB() B6B_PAIR(RCP, 3, shi, smid, slo)                            \
+        B6B_SB() B6B_MF(2, 2) B6B_MF(2, 3) B6B_SB() B6B_WRITE((buf) ^ 1, 0, shi, smid, slo)                     \
+        B6B_SB() B6B_MF(3, 0) B6B_MF(3, 1) B6B_SB() B6B_PAIR(RCQ, 0, shi, smid, slo)                            \
+        B6B_SB() B6B_MF(3, 2) B6B_MF(3, 3) B6B_SB() B6B_PAIR(RCQ, 1, shi, smid, slo)                            \
+        B6B_SB() B6B_MF(4, 0) B6B_MF(4, 1) B6B_SB() B6B_PAIR(RCQ, 2, shi, smid, slo)                            \
+        B6B_SB() B6B_MF(4, 2) B6B_MF(4, 3) B6B_SB() B6B_PAIR(RCQ, 3, shi, smid, slo)                            \
+        B6B_SB() B6B_MF(5, 0) B6B_MF(5, 1) B6B_SB() B6B_WRITE((buf) ^ 1, 1, shi, smid, slo)                     \
+        B6B_SB() B6B_MF(5, 2) B6B_MF(5, 3) B6B_SB()                                                             \
+        __syncthreads();                                                                                        \
     }
 
     f32x16 acc[4][2];
@@ -673,34 +747,37 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x6_big_kernel(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    B6B_GLOAD()
-    B6B_LSTORE(0)
+    constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};      // smallest partial products first
+    B6B_GLOAD(rpA, rqA)
+    {
+        bf16x8 hi, mid, lo;
+        split8x3(rpA[0], rpA[1], hi, mid, lo); B6B_WRITE(0, 0, hi, mid, lo)
+        split8x3(rqA[0], rqA[1], hi, mid, lo); B6B_WRITE(0, 1, hi, mid, lo)
+    }
+    B6B_GLOAD(rpA, rqA)
     __syncthreads();
-    for (int st = 0; st < nstage; ++st) {
-        const int buf = st & 1;
-        const bool reload = st + 1 < nstage;
-        if (reload) { B6B_GLOAD() }
-        bf16x8 ap[3][4], bq[3][2];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ap[pl][i] = S6B(buf, 0, pl)[h * BT + wp * 128 + i * 32 + l31];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bq[pl][j] = S6B(buf, 1, pl)[h * BT + wq * 64 + j * 32 + l31];
-        }
-        constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};      // smallest partial products first
-#pragma unroll
-        for (int t = 0; t < 6; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[PA[t]][i], bq[PB[t]][j], acc[i][j], 0, 0, 0);
-        if (reload) { B6B_LSTORE(buf ^ 1) }
-        __syncthreads();
+#ifdef SDFA_GEMM6_NOSTAGE   /* timing experiment only: the MFMA + LDS-read loop without the operand stream (wrong results) */
+#undef B6B_GLOAD
+#undef B6B_PAIR
+#undef B6B_WRITE
+#define B6B_GLOAD(RP, RQ)
+#define B6B_PAIR(R, e, HI, MID, LO)
+#define B6B_WRITE(buf, pq, HI, MID, LO)
+#endif
+    // (behind the last stage the registers hold stale operands: they are split and written to the buffer nobody reads any more)
+    for (int st = 0; st < nstage; st += 2) {
+        B6B_STAGE(st, 0, rpA, rqA, rpB, rqB)
+        if (st + 1 < nstage) B6B_STAGE(st + 1, 1, rpB, rqB, rpA, rqA)
     }
 #undef B6B_GLOAD
-#undef B6B_LSTORE
+#undef B6B_SB
+#undef B6B_PAIR
+#undef B6B_WRITE
+#undef B6B_MF
+#undef B6B_GROUP
+#undef B6B_APLANE
+#undef B6B_BPLANE
+#undef B6B_STAGE
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
