@@ -1134,8 +1134,11 @@ __global__ __launch_bounds__(256, 1) void gemm_fat_kernel(GemmArgs a) {
                         }
                         *reinterpret_cast<float4 *>(dbase + ((int64_t)(i * 8 + 2 * g) * a.ldd + j * 32) * 16 + dlane) = make_float4(v[0], v[1], v[2], v[3]);
                     }
+#ifndef SDFA_FAT_NOZERO   /* timing experiment: what zero-start accumulators could save at most -- the 256 register
+                             writes per tile simply left out (wrong results from the second tile of a workgroup on) */
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#endif
                 }
             }
         }

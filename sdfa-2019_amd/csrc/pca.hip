@@ -294,6 +294,20 @@ __global__ __launch_bounds__(256, 1) void pca_dgrad_res_kernel(PcaArgs a, int *q
             }
             float4 rv0, rv1, rv2;      // (named: an array indexed inside the destination loop ends up in scratch memory)
             const bool plain = frame0 + 32 <= a.N && orow_valid >= 288 && a.n_extra == 0;      // uniform
+#ifdef SDFA_PCA_DIRECT   /* experiment: no LDS transposition -- every lane stores its own 4-byte values (144 dword stores
+                            per lane and tile instead of 48 x 16 bytes); correct results for whole tiles with one destination */
+            if (plain) {
+#pragma unroll
+                for (int p = 0; p < 16; ++p) {
+                    float *orow = a.out + (frame0 + 8 * (p >> 2) + (p & 3) + 4 * h) * a.out_dim + ocol0;
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) orow[opos[t]] = accs[0][t][p] + mean[t];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) orow[opos[6 + t]] = accr[0][t][p] + mean[6 + t];
+                }
+                continue;
+            }
+#endif
             PR_WRITE(0)
             WAVE_LDS_FENCE()
             PR_READ(0)
