@@ -747,9 +747,9 @@ def main():
         if mixed is not None:
             dt_m, st_m, dt_ms, dt_a, st_a, dt_6, st_6 = mixed
             res["mixed_precision"] = {
-                "note": "BASELINE configs[3]: same workload with the frequency LSTM and every GEMM on split-bf16 MFMA (operands as "
-                        "hi+lo bf16, three v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate/state/activations; front end, conv "
-                        "stack, BiLSTM recurrences, softmax fp32); NOT the headline, which stays exact fp32",
+                "note": "BASELINE configs[3]: same workload with the conv stack, the frequency LSTM, the BiLSTM recurrences and every GEMM "
+                        "on split-bf16 MFMA (operands as hi+lo bf16, three v_mfma_f32_32x32x16_bf16 per product, fp32 "
+                        "accumulate/state/activations; front end, softmax / context, dgrad PCA expansion fp32); NOT the headline, which stays exact fp32",
                 "mode": "bf16x3", "value": round(F_all * a.steps / dt_m, 1), "unit": "frames/s",
                 "ms_per_step": round(dt_m / a.steps * 1e3, 3),
                 "with_column_sharing": None if dt_ms is None else round(F_all * a.steps / dt_ms, 1),

@@ -130,7 +130,7 @@ int64_t     sdfa_model_coef_dim(const sdfa_model *m);         /* 265 (85 scale |
  * accumulation, LSTM cell state, bias and activation stay fp32 in all modes.  May be changed between calls.
  *   SDFA_PREC_FP32            v_mfma_f32_32x32x2_f32 everywhere (exact fp32 products)
  *   SDFA_PREC_BF16_ATTENTION  attention stage (key / query projections, query conv) on bf16 MFMA, rest fp32
- *   SDFA_PREC_BF16X3          frequency LSTM, BiLSTM recurrences + every GEMM (not the fused dgrad PCA expansion) on
+ *   SDFA_PREC_BF16X3          conv stack, frequency LSTM, BiLSTM recurrences + every GEMM (not the fused dgrad PCA expansion) on
  *                             split-bf16: operands as hi + lo bf16 (16 significand bits), three
  *                             v_mfma_f32_32x32x16_bf16 per product
  *   SDFA_PREC_BF16            the same kernels on plain bf16 operands (8 bits) -- outside the 1e-4 budget,

@@ -142,6 +142,7 @@ struct sdfa_model {
     const float *w1, *b1, *s1, *t1, *w2, *b2, *s2, *t2, *w3, *b3, *s3, *t3;
     const float *fl_w, *fl_b, *fp_w, *fp_b;
     const void *fl_wb = nullptr;   // frequency-LSTM weights as bf16 hi/lo planes (mixed-precision modes)
+    const void *cv_wb = nullptr;   // conv stack weights as bf16 planes in the K order of conv123_bf16_kernel (mixed-precision modes)
     int precision = SDFA_PREC_FP32;
     const float *gx_w[2], *tl_w[2];
     const void *tl_wb[2] = {nullptr, nullptr};   // BiLSTM recurrent weights as bf16 hi/lo planes (mixed-precision modes)
@@ -217,6 +218,42 @@ float bf16_bits_to_float(uint16_t b) {
     float x;
     memcpy(&x, &u, 4);
     return x;
+}
+
+// Conv stack weights for conv123_bf16_kernel (conv.hip): three planes (hi | mid | lo) of 1344 octets of 8 bf16 each,
+//   w1 [2 halves][32 co]            k = 8 hh + e: tap df = k / 3, channel c = k % 3 (k >= 9: zero)
+//   w2 [6 k-steps][2 halves][64 co] tap df = ks / 2, input channel 8 (2 (ks % 2) + e / 4) + 4 hh + e % 4
+//   w3 [4 k-steps][2 halves][64 co] input channel 32 (ks / 2) + 8 (2 (ks % 2) + e / 4) + 4 hh + e % 4
+// -- the order in which an accumulator lane of the kernel owns its channels.  Torch layout of w: [co][ci][kf].
+void pack_conv_bf16(uint16_t *dst, const float *w1, const float *w2, const float *w3) {
+    constexpr size_t PLANE = (size_t)1344 * 8;
+    auto put = [&](size_t octet, int e, float x) {
+        const uint16_t hi = bf16_rne_bits(x);
+        const float r1 = x - bf16_bits_to_float(hi);
+        const uint16_t mid = bf16_rne_bits(r1);
+        const uint16_t lo = bf16_rne_bits(r1 - bf16_bits_to_float(mid));
+        dst[octet * 8 + e] = hi; dst[PLANE + octet * 8 + e] = mid; dst[2 * PLANE + octet * 8 + e] = lo;
+    };
+    for (int hh = 0; hh < 2; ++hh)
+        for (int co = 0; co < 32; ++co)
+            for (int e = 0; e < 8; ++e) {
+                const int k = 8 * hh + e;
+                put((size_t)hh * 32 + co, e, k < 9 ? w1[((size_t)co * 3 + k % 3) * 3 + k / 3] : 0.f);
+            }
+    for (int ks = 0; ks < 6; ++ks)
+        for (int hh = 0; hh < 2; ++hh)
+            for (int co = 0; co < 64; ++co)
+                for (int e = 0; e < 8; ++e) {
+                    const int df = ks >> 1, ci = 8 * (2 * (ks & 1) + (e >> 2)) + 4 * hh + (e & 3);
+                    put(64 + ((size_t)ks * 2 + hh) * 64 + co, e, w2[((size_t)co * 32 + ci) * 3 + df]);
+                }
+    for (int ks = 0; ks < 4; ++ks)
+        for (int hh = 0; hh < 2; ++hh)
+            for (int co = 0; co < 64; ++co)
+                for (int e = 0; e < 8; ++e) {
+                    const int ci = 32 * (ks >> 1) + 8 * (2 * (ks & 1) + (e >> 2)) + 4 * hh + (e & 3);
+                    put(64 + 768 + ((size_t)ks * 2 + hh) * 64 + co, e, w3[(size_t)co * 64 + ci]);
+                }
 }
 
 // Frequency-LSTM weights for freq_lstm_bf16_kernel / freq_lstm_bf16x6_kernel: per direction [plane hi | mid | lo][24 octets][512 gate rows][8] bf16.
@@ -467,6 +504,7 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
     const std::string enc = "_audio_encoder._layers.";
     // ---- conv stack: fold eval BatchNorm (eps 1e-3) into scale/shift applied AFTER LeakyReLU (extend.py:94-101)
     size_t o_conv[3][4];
+    const std::vector<float> *conv_w[3] = {nullptr, nullptr, nullptr};
     const int cshape[3][3] = {{32, 3, 3}, {64, 32, 3}, {64, 64, 1}};   // co, ci, kf
     const int cidx[3] = {1, 3, 5};
     for (int l = 0; l < 3; ++l) {
@@ -477,6 +515,7 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
         auto *g = get(m, k + "._ext_post_bn.weight", co), *be = get(m, k + "._ext_post_bn.bias", co);
         auto *mu = get(m, k + "._ext_post_bn.running_mean", co), *var = get(m, k + "._ext_post_bn.running_var", co);
         if (!w || !b || !g || !be || !mu || !var) return SDFA_ESTATE;
+        conv_w[l] = w;
         if (l == 0) {   // A operand [5 k-steps][2 halves][32 co], k = df*3 + c, k = 9 -> 0
             o_conv[0][0] = pk.add(5 * 2 * 32);
             for (int s = 0; s < 5; ++s)
@@ -503,6 +542,8 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
             pk.buf[o_conv[l][3] + o] = (float)((double)(*be)[o] - (double)(*mu)[o] * sc);
         }
     }
+    const size_t o_cvwb = pk.add((size_t)3 * 1344 * 8 / 2);      // three bf16 planes of 1344 octets, two bf16 per float slot
+    pack_conv_bf16(reinterpret_cast<uint16_t *>(&pk.buf[o_cvwb]), conv_w[0]->data(), conv_w[1]->data(), conv_w[2]->data());
     // ---- frequency LSTM: [W_ih | W_hh] concatenated along K, gate rows packed per wave; bias = b_ih + b_hh
     size_t o_flw = pk.add(0), o_flb, o_flwb;
     {
@@ -655,6 +696,7 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
     m->w2 = d + o_conv[1][0]; m->b2 = d + o_conv[1][1]; m->s2 = d + o_conv[1][2]; m->t2 = d + o_conv[1][3];
     m->w3 = d + o_conv[2][0]; m->b3 = d + o_conv[2][1]; m->s3 = d + o_conv[2][2]; m->t3 = d + o_conv[2][3];
     m->fl_wb = d + o_flwb;
+    m->cv_wb = d + o_cvwb;
     m->fl_w = d + o_flw; m->fl_b = d + o_flb; m->fp_w = d + o_fpw; m->fp_b = d + o_fpb;
     for (int l = 0; l < 2; ++l) { m->gx_w[l] = d + o_gx[l]; m->tl_w[l] = d + o_tl[l]; m->tl_wb[l] = d + o_tlb[l]; m->tl_w16[l] = d + o_tl16[l]; }
     m->kp_w = d + o_kp; m->qc_w = d + o_qc; m->qp_w = d + o_qp; m->at_v = d + o_v; m->at_b = d + o_b;
@@ -765,6 +807,7 @@ thread_local int g_sdfa_freq_lstm_shape = 0;
 thread_local int g_sdfa_pca_unfused = 0;
 thread_local int g_sdfa_conv_unfused = 0;
 thread_local int g_sdfa_pca_lds = 0;
+thread_local int g_sdfa_conv_fp32 = 0;    // "conv_fp32": 1 = the conv stack stays on the fp32 kernel in the mixed-precision modes (A/B)
 thread_local int g_sdfa_time_lstm_split = 0;
 thread_local int g_sdfa_time_lstm_handoff = 0;
 thread_local int g_sdfa_time_lstm_timeout_us = 0;
@@ -782,6 +825,7 @@ int sdfa_debug_set_option(const char *name, int value) {
     if (name && !strcmp(name, "pca_unfused")) { g_sdfa_pca_unfused = value; return SDFA_OK; }
     if (name && !strcmp(name, "conv_unfused")) { g_sdfa_conv_unfused = value; return SDFA_OK; }
     if (name && !strcmp(name, "pca_lds")) { g_sdfa_pca_lds = value; return SDFA_OK; }
+    if (name && !strcmp(name, "conv_fp32")) { g_sdfa_conv_fp32 = value; return SDFA_OK; }
     return fail(SDFA_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }
 
@@ -948,6 +992,7 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
             pf.begin("conv1"); HIP_TRY(sdfa_launch_conv1(ca, s)); pf.end();
             pf.begin("conv23"); HIP_TRY(sdfa_launch_conv23(ca, s)); pf.end();
         } else {
+            ca.wb = m->cv_wb; ca.terms = g_sdfa_conv_fp32 ? 0 : stage_terms(m, STAGE_BODY);      // the mixed-precision modes run the stack on bf16 MFMA too
             pf.begin("conv23"); HIP_TRY(sdfa_launch_conv123(ca, s)); pf.end();
         }
 

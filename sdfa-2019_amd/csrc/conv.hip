@@ -343,6 +343,218 @@ __global__ __launch_bounds__(256, 2) void conv123_kernel(ConvArgs a) {
         }
 }
 
+// ------------------------------------------------- the fused conv stack on bf16 MFMA (mixed-precision modes, round 4)
+// conv123_kernel with every contraction on v_mfma_f32_32x32x16_bf16 (fp32 accumulation, fp32 epilogues): TERMS 1 = operands rounded
+// to bf16, 3 = split-bf16 (hi + lo, three products), 6 = three bf16 terms, six products -- the modes of the other body kernels.
+// An MFMA contracts 16 k: conv1 (K = 9) is ONE instruction per output row and product, conv2 (K = 96) six, conv3 (K = 64) four --
+// 37 + 24 + 4 per wave instead of 281 fp32 MFMAs of twice the cycles.  The K axes are ordered so that every lane builds its B
+// operand from values it already owns (the scheme of the LSTM kernels): an accumulator lane holds channels 8g + 4h + e (g, e = 0..3),
+// so k-step "octet pair q" of lane half h is channels {8(2q) + 4h + e} u {8(2q+1) + 4h + e} -- pool1 goes to LDS as such octets,
+// plane by plane, and pool2 never leaves the registers.  The host packs the weights in the same order (api.cpp: pack_conv_bf16).
+typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
+#define CMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+template <int NPL>
+__device__ __forceinline__ void conv_split8(const float (&x)[8], cbf16x8 (&pl)[3]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 hb = (__bf16)x[e];
+        pl[0][e] = hb;
+        if (NPL > 1) {
+            const float r1 = x[e] - (float)hb;
+            const __bf16 mb = (__bf16)r1;
+            pl[1][e] = mb;
+            if (NPL > 2) pl[2][e] = (__bf16)(r1 - (float)mb);
+        }
+    }
+}
+
+// acc += W * x over the partial products of the mode, smallest first (plane 0 = hi, 1 = mid / lo, 2 = lo)
+template <int TERMS>
+__device__ __forceinline__ void conv_products(f32x16 &acc, const cbf16x8 (&w)[3], const cbf16x8 (&x)[3]) {
+    if (TERMS == 6) {
+        acc = CMFMA(w[0], x[2], acc); acc = CMFMA(w[1], x[1], acc); acc = CMFMA(w[2], x[0], acc);
+        acc = CMFMA(w[0], x[1], acc); acc = CMFMA(w[1], x[0], acc);
+    } else if (TERMS == 3) {
+        acc = CMFMA(w[1], x[0], acc); acc = CMFMA(w[0], x[1], acc);
+    }
+    acc = CMFMA(w[0], x[0], acc);
+}
+
+template <int TERMS>
+__global__ __launch_bounds__(256, 2) void conv123_bf16_kernel(ConvArgs a) {
+    constexpr int NPL = TERMS == 6 ? 3 : (TERMS == 3 ? 2 : 1);
+    __shared__ cbf16x8 sP1b[NPL][10][4][32];   // pool1: [plane][row j][octet 2q + h][column]
+    __shared__ float sIn[68][33];
+    __shared__ float sPar[6][64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int fc = blockIdx.x & 7;
+    const int64_t m0 = (int64_t)(blockIdx.x >> 3) * 32;
+    if (a.col_limit && m0 >= *a.col_limit) return;
+    const int64_t t = m0 / a.Nc, n0 = m0 % a.Nc;
+
+    // ---- input slice, exactly as conv123_kernel
+    const int k_lo = (16 * fc - 3) * 3;
+    {
+        const int col = tid >> 3, kb0 = (tid & 7) * 9;
+        const int64_t n = n0 + col;
+        int64_t row = n < a.N ? n * 64 + t : -1;
+        if (a.col_src) row = a.col_src[m0 + col];
+        const float *src = a.audio_feat + (row >= 0 ? row : 0) * 384;
+        float v[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int gk = k_lo + kb0 + i;
+            v[i] = src[gk < 0 ? 0 : (gk > 383 ? 383 : gk)];
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int k = kb0 + i, gk = k_lo + k;
+            if (k < 68) sIn[k][col] = (row >= 0 && k < 66 && gk >= 0 && gk < 384) ? v[i] : 0.f;
+        }
+    }
+    if (tid < 64) {
+        sPar[0][tid] = a.b2[tid]; sPar[1][tid] = a.s2[tid]; sPar[2][tid] = a.t2[tid];
+        sPar[3][tid] = a.b3[tid]; sPar[4][tid] = a.s3[tid]; sPar[5][tid] = a.t3[tid];
+    }
+    // weights: planes of [w1: 2 halves x 32 co | w2: 6 k-steps x 2 halves x 64 co | w3: 4 k-steps x 2 halves x 64 co] octets
+    constexpr int W_PLANE = 2 * 32 + 6 * 2 * 64 + 4 * 2 * 64;       // 1344 octets per plane
+    const cbf16x8 *__restrict__ Wb = reinterpret_cast<const cbf16x8 *>(a.wb);
+    const cbf16x8 *__restrict__ W1b = Wb + h * 32 + l31;
+    const cbf16x8 *__restrict__ W2b = Wb + 64 + h * 64 + l31;
+    const cbf16x8 *__restrict__ W3b = Wb + 64 + 768 + h * 64 + l31;
+    cbf16x8 wa[2][3], wn[2][3];
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) { wa[0][pl] = W2b[pl * W_PLANE]; wa[1][pl] = W2b[pl * W_PLANE + 32]; }      // conv2 k-step 0: lands during conv1
+    __syncthreads();
+
+    // ---- conv1 + LeakyReLU + BN + pool -> pool1 rows j = wave, wave + 4, wave + 8 of the slice, as octets
+    {
+        cbf16x8 w1[3];
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) w1[pl] = W1b[pl * W_PLANE];
+        for (int j = wave; j < 10; j += 4) {
+            const int f1 = 8 * fc - 1 + j;
+            float x0[8], x1[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {       // k = 8h + e: nine taps, the rest of the 16 are zeros (h = 1 reads one value)
+                const bool on = h == 0 || e == 0;
+                const int k0 = 6 * j + (on ? 8 * h + e : 0);
+                x0[e] = on ? sIn[k0][l31] : 0.f;
+                x1[e] = on ? sIn[k0 + 3][l31] : 0.f;
+            }
+            cbf16x8 b0[3], b1[3];
+            conv_split8<NPL>(x0, b0);
+            conv_split8<NPL>(x1, b1);
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+            conv_products<TERMS>(acc0, w1, b0);
+            conv_products<TERMS>(acc1, w1, b1);
+            const bool valid = f1 >= 0 && f1 < 64;       // rows -1 and 64 are conv2's zero padding
+            float o[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 b = ld4(a.b1 + 8 * g + 4 * h), sc = ld4(a.s1 + 8 * g + 4 * h), sh = ld4(a.t1 + 8 * g + 4 * h);
+                const float bq[4] = {b.x, b.y, b.z, b.w}, sq[4] = {sc.x, sc.y, sc.z, sc.w}, tq[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v0 = lrelu02(acc0[4 * g + e] + bq[e]) * sq[e] + tq[e];
+                    const float v1 = lrelu02(acc1[4 * g + e] + bq[e]) * sq[e] + tq[e];
+                    o[4 * g + e] = valid ? fmaxf(v0, v1) : 0.f;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float xo[8] = {o[8 * q], o[8 * q + 1], o[8 * q + 2], o[8 * q + 3], o[8 * q + 4], o[8 * q + 5], o[8 * q + 6], o[8 * q + 7]};
+                cbf16x8 pp[3];
+                conv_split8<NPL>(xo, pp);
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) sP1b[pl][j][2 * q + h][l31] = pp[pl];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- conv2 (six k-steps: tap df = ks / 2, octet pair ks % 2) + pool + conv3 (four k-steps, B operand from registers)
+    const int fo = fc * 4 + wave;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+        if (ks + 1 < 6) {
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) { wn[0][pl] = W2b[pl * W_PLANE + (ks + 1) * 128]; wn[1][pl] = W2b[pl * W_PLANE + (ks + 1) * 128 + 32]; }
+        }
+        cbf16x8 x[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) x[i][pl] = sP1b[pl][2 * wave + i + (ks >> 1)][2 * (ks & 1) + h][l31];
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) conv_products<TERMS>(acc[ot][i], wa[ot], x[i]);
+        if (ks + 1 < 6) {
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) { wa[0][pl] = wn[0][pl]; wa[1][pl] = wn[1][pl]; }
+        }
+    }
+    float p2[2][16];
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ch = ot * 32 + 8 * g + 4 * h;
+            float4 b = ld4(&sPar[0][ch]), sc = ld4(&sPar[1][ch]), sh = ld4(&sPar[2][ch]);
+            const float bq[4] = {b.x, b.y, b.z, b.w}, sq[4] = {sc.x, sc.y, sc.z, sc.w}, tq[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v0 = lrelu02(acc[ot][0][4 * g + e] + bq[e]) * sq[e] + tq[e];
+                float v1 = lrelu02(acc[ot][1][4 * g + e] + bq[e]) * sq[e] + tq[e];
+                p2[ot][4 * g + e] = fmaxf(v0, v1);
+            }
+        }
+    f32x16 acc3[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc3[j][r] = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float xo[8] = {p2[ct][8 * q], p2[ct][8 * q + 1], p2[ct][8 * q + 2], p2[ct][8 * q + 3], p2[ct][8 * q + 4], p2[ct][8 * q + 5], p2[ct][8 * q + 6], p2[ct][8 * q + 7]};
+            cbf16x8 xb[3], w3[2][3];
+            conv_split8<NPL>(xo, xb);
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) { w3[0][pl] = W3b[pl * W_PLANE + (2 * ct + q) * 128]; w3[1][pl] = W3b[pl * W_PLANE + (2 * ct + q) * 128 + 32]; }
+            conv_products<TERMS>(acc3[0], w3[0], xb);
+            conv_products<TERMS>(acc3[1], w3[1], xb);
+        }
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ch = ot * 32 + 8 * g + 4 * h;
+            float4 b = ld4(&sPar[3][ch]), sc = ld4(&sPar[4][ch]), sh = ld4(&sPar[5][ch]);
+            float4 o;
+            o.x = lrelu02(acc3[ot][4 * g + 0] + b.x) * sc.x + sh.x;
+            o.y = lrelu02(acc3[ot][4 * g + 1] + b.y) * sc.y + sh.y;
+            o.z = lrelu02(acc3[ot][4 * g + 2] + b.z) * sc.z + sh.z;
+            o.w = lrelu02(acc3[ot][4 * g + 3] + b.w) * sc.w + sh.w;
+            st4(a.X3 + ((int64_t)(fo * 16 + ot * 8 + 2 * g + h) * a.Mc + m0 + l31) * 4, o);
+        }
+}
+#undef CMFMA
+
 }  // namespace
 
 hipError_t sdfa_launch_conv1(const ConvArgs &a, hipStream_t s) {
@@ -351,6 +563,14 @@ hipError_t sdfa_launch_conv1(const ConvArgs &a, hipStream_t s) {
 }
 
 hipError_t sdfa_launch_conv123(const ConvArgs &a, hipStream_t s) {
+    if (a.terms) {      // mixed-precision modes: the same stack on bf16 MFMA
+        if (!a.wb) return hipErrorInvalidValue;
+        const dim3 grid((unsigned)(a.Mc / 32 * 8));
+        if (a.terms == 6) hipLaunchKernelGGL(conv123_bf16_kernel<6>, grid, dim3(256), 0, s, a);
+        else if (a.terms == 3) hipLaunchKernelGGL(conv123_bf16_kernel<3>, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(conv123_bf16_kernel<1>, grid, dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(conv123_kernel, dim3((unsigned)(a.Mc / 32 * 8)), dim3(256), 0, s, a);
     return hipGetLastError();
 }

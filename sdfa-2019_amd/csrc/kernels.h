@@ -92,6 +92,10 @@ struct ConvArgs {
     // workgroups whose first column is >= *col_limit exit at once.  Both null = every column of every frame.
     const int32_t *col_src;
     const int64_t *col_limit;
+    // mixed-precision modes (sdfa_launch_conv123 only): bf16 planes [hi | mid | lo] of the three layers' weights in the K order of
+    // conv123_bf16_kernel (api.cpp: pack_conv_bf16); terms 0 = fp32 MFMA, 1 / 3 / 6 as in FreqLstmArgs
+    const void *wb;
+    int terms;
 };
 hipError_t sdfa_launch_conv1(const ConvArgs &a, hipStream_t s);
 hipError_t sdfa_launch_conv23(const ConvArgs &a, hipStream_t s);

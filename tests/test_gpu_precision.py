@@ -137,6 +137,27 @@ def test_split_bf16_frequency_lstm_forms_agree_bitwise(eng, mode):
         eng.set_precision("fp32")
 
 
+@pytest.mark.parametrize("mode,tol", [("bf16x6", 2e-5), ("bf16x3", 3e-4), ("bf16", 0.2)])
+def test_conv_stack_on_bf16_mfma_against_the_fp32_stack(eng, mode, tol):
+    """The mixed-precision modes run the fused conv stack on bf16 MFMA (conv123_bf16_kernel: K axes in the accumulator lanes' channel
+    order, pool2 chained in registers); option conv_fp32 = 1 keeps it on the fp32 kernel.  Same mode otherwise: the encoder outputs
+    differ by the stack's operand rounding only -- not zero (the bf16 stack did run), and small."""
+    from sdfa_amd import _lib
+    rs = np.random.RandomState(3)
+    x = torch.from_numpy(rs.uniform(0, 1, (300, 64, 128, 3)).astype(np.float32)).cuda()
+    try:
+        eng.set_precision(mode)
+        _lib.set_option("conv_fp32", 1)
+        z0 = eng.encoder(x)[0].clone()
+        _lib.set_option("conv_fp32", 0)
+        z1 = eng.encoder(x)[0].clone()
+    finally:
+        _lib.set_option("conv_fp32", 0)
+        eng.set_precision("fp32")
+    d = float((z0 - z1).abs().max())
+    assert 0.0 < d <= tol, (mode, d)
+
+
 def test_column_sharing_is_exact_in_split_bf16(eng):
     """Column sharing evaluates each distinct column once; a column's arithmetic does not depend on its position in the
     launch, so the shared and unshared encoders agree bitwise in the bf16 modes too."""
