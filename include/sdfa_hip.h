@@ -264,6 +264,8 @@ int sdfa_ensemble_mean(const float *d_a, const float *d_b, int64_t n, float *d_o
  *   "freq_lstm_shape"  0 = the model's form (9 unless sdfa_model_autotune picked another); 9 = freq_lstm_v3_kernel persistent, one
  *                      workgroup per CU; 8 = the same kernel, one hardware-dispatched workgroup per tile; 5 = freq_lstm_v2_kernel
  *                      persistent, two workgroups per CU; 3 = freq_lstm_v2_kernel hardware-dispatched (the fallback that shares a CU)
+ *                      (split-bf16 / six-product modes: freq_lstm_bf16p_v3_kernel persistent, one workgroup per CU; 8 = the same kernel, one
+ *                      workgroup per tile; 3 = freq_lstm_bf16_kernel<3> / freq_lstm_bf16x6_kernel, two workgroups per CU -- the same bits)
  *   "gemm_variant"     0 = per-shape default (gemm_fat_kernel where 256 x 256 tiles fill the chip twice, else the 128 x 128 LDS-tiled
  *                      kernel; 256 x 256 gemm_big_kernel for the 8192-deep projection at mid sizes); 9 = never the persistent fat
  *                      kernel (two-workgroups-per-CU fallback); 8 = fat wherever it fits; 5 = 256 x 256 tile wherever it fits;
@@ -290,7 +292,9 @@ int sdfa_ensemble_mean(const float *d_a, const float *d_b, int64_t n, float *d_o
  *   "share_gx0_off"    1 = sdfa_encoder_forward_shared expands the frequency projection to all columns before the layer-0 BiLSTM input
  *                      projection (rounds 2-3) instead of projecting the distinct columns and letting the recurrence read them through the map
  *   "pca_unfused"      1 = the dgrad PCA expansion as two generic GEMM launches with the scatter epilogue (round-1 form)
- *   "conv_unfused"     1 = conv1_pool_kernel + conv23_kernel instead of the fused conv123_kernel (what the debug taps use)   */
+ *   "conv_unfused"     1 = conv1_pool_kernel + conv23_kernel instead of the fused conv123_kernel (what the debug taps use)
+ *   "conv_fp32"        1 = the body precision modes (bf16, bf16x3, bf16x6) keep the conv stack on the fp32 kernel instead of
+ *                      conv123_bf16_kernel (NOT bit-identical: that stack's operand rounding)   */
 int sdfa_debug_set_option(const char *name, int value);
 int sdfa_debug_keep_intermediates(sdfa_model *m, int on);   /* un-aliased workspace: call before sizing it */
 /* Number of distinct columns the LAST sdfa_encoder_forward_shared call evaluated for a chunk of n_frames frames
