@@ -1180,12 +1180,21 @@ __device__ __forceinline__ void time_lstm_body(const TimeLstmArgs &a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) ucol[j] = cmap[(int64_t)(dir ? 62 : 1) * a.Nc + j * 32];
     }
+#if defined(SDFA_STAMPS) && defined(__HIP_DEVICE_COMPILE__)   /* (the host pass of a __device__ template rejects the asm constraints) */
+#define TSTAMP(t) LSTAMP(t)
+#else
+#define TSTAMP(t)
+#endif
+#if defined(SDFA_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long tt0 = 0, tt1 = 0, tt2 = 0, tt3 = 0, tv_k = 0, tv_cell = 0, tv_bar = 0;
+#endif
     for (int s = 0; s < 64; ++s) {
         const int t = dir ? 63 - s : s;
         const int tn = dir ? t - 1 : t + 1;
         const int64_t tcol = (int64_t)t * a.Nc;
         const float4 *sHc = sHt + (size_t)(s & 1) * 64 * BT;
         float4 *sHn = sHt + (size_t)((s & 1) ^ 1) * 64 * BT;
+        TSTAMP(tt0)
 
         if (s > 0) {
             float4 wa0 = wn0, wa1 = wn1, wa2 = wn2, wa3 = wn3, wb0, wb1, wb2, wb3, ba[NT], bb[NT];
@@ -1232,6 +1241,10 @@ __device__ __forceinline__ void time_lstm_body(const TimeLstmArgs &a) {
 #undef TL_SB
             wn0 = wa0; wn1 = wa1; wn2 = wa2; wn3 = wa3;      // k-block 0 again: the next step's first operands
         }
+#if defined(SDFA_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+        if (NT == 2) asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]), "v"(acc[0][NT - 1]), "v"(acc[1][NT - 1]), "v"(acc[2][NT - 1]), "v"(acc[3][NT - 1]));   // all MFMAs done
+#endif
+        TSTAMP(tt1)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -1254,9 +1267,18 @@ __device__ __forceinline__ void time_lstm_body(const TimeLstmArgs &a) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) ucol[j] = cmap[(int64_t)t2 * a.Nc + j * 32];
         }
+        TSTAMP(tt2)
         __syncthreads();   // h_s complete in sHn before anyone reads it; sHc free for step s+1's writes
+#if defined(SDFA_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+        TSTAMP(tt3)
+        if (s > 0) { tv_k += tt1 - tt0; tv_cell += tt2 - tt1; tv_bar += tt3 - tt2; }
+#endif
     }
+#if defined(SDFA_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+    if (NT == 2 && lane == 0) { atomicAdd(&g_lsub[0], tv_k); atomicAdd(&g_lsub[1], tv_cell); atomicAdd(&g_lsub[2], tv_bar); atomicAdd(&g_lsub[3], 63ull); }
+#endif
 #undef TL_GX
+#undef TSTAMP
 #undef TL_LOAD
 #undef TL_W1
 }
