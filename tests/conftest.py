@@ -11,6 +11,22 @@ for p in (os.path.join(ROOT, "sdfa-2019_amd"), os.path.join(ROOT, "oracle"), ROO
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _ensure_library():
+    """A fresh checkout has no libsdfa_hip.so (built artefacts stay out of history): build it once, in-tree, before any test module
+    imports sdfa_amd -- hipcc cross-compiles gfx950 without a GPU.  (Building the product is not a CPU fallback: the library still only
+    runs on an MI355X; the CPU tests check that it loads and exports what include/sdfa_hip.h declares.)"""
+    so = os.environ.get("SDFA_HIP_LIB") or os.path.join(ROOT, "sdfa-2019_amd", "sdfa_amd", "libsdfa_hip.so")
+    if os.path.exists(so):
+        return
+    import subprocess
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "sdfa-2019_amd", "csrc")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0 or not os.path.exists(so):
+        raise RuntimeError("building libsdfa_hip.so failed:\n" + r.stdout[-2000:])
+
+
+_ensure_library()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
