@@ -38,6 +38,9 @@ def evaluate_model(args):
     if args.get("template_mesh"):                                       # tools/config.py:75-85
         from . import viewer
         viewer.set_template_mesh(args["template_mesh"], args.get("mesh_constraints"), args.get("mesh_tricorres"))
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and torch.cuda.device_count() > 0:
+        # one process per GPU (torch.distributed.run sets LOCAL_RANK): model.evaluate() takes this rank's shard of the sources
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     ckpt = _load_checkpoint(os.path.expanduser(hparams.load_from))
     model = build_model(hparams, ckpt["state"])
     model.current_epoch = ckpt.get("epoch", 0)

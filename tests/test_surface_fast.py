@@ -268,6 +268,38 @@ def test_evaluate_in_launch_groups_is_the_clip_by_clip_loop(tmp_path, synth_sd):
             assert not mismatch and not errors, (i, mismatch, errors)
 
 
+def test_evaluate_shards_sources_across_ranks(tmp_path, synth_sd, monkeypatch):
+    """north_star / SURVEY 8(e) on the surface: under torch.distributed.run every rank's evaluate() takes a contiguous block of the
+    flat source list (RANK / WORLD_SIZE, or shard=(rank, world)) and writes its own sources' files; together the ranks write exactly
+    the files of the single-process run, and no source twice."""
+    import filecmp
+    import os
+    from scipy.io import wavfile
+    sr = 16000
+    hp, model = _model(synth_sd["dgrad"], sr)
+    recs = {"a": [], "b": []}
+    for i, s in enumerate((1.0, 1.4, 0.9, 2.1, 1.2)):
+        w = tmp_path / f"clip{i}.wav"
+        wavfile.write(str(w), sr, (synth.make_pcm(80 + i, int(s * sr), "speechlike") * 20000).astype(np.int16))
+        recs["a" if i < 2 else "b"].append([str(w), f"speaker={('m1', 'f0')[i & 1]}"])
+    whole = model.evaluate(recs, output_dir=str(tmp_path / "whole"), export_mesh_frames=True)
+    assert [os.path.basename(r[0]) for r in whole] == [f"clip{i}.wav" for i in range(5)]
+    part0 = model.evaluate(recs, output_dir=str(tmp_path / "sharded"), export_mesh_frames=True, shard=(0, 2))      # clips 0..2
+    monkeypatch.setenv("RANK", "1"); monkeypatch.setenv("WORLD_SIZE", "2")                                             # clips 3..4, from the environment
+    part1 = model.evaluate(recs, output_dir=str(tmp_path / "sharded"), export_mesh_frames=True)
+    monkeypatch.delenv("RANK"); monkeypatch.delenv("WORLD_SIZE")
+    assert [r[0] for r in part0] + [r[0] for r in part1] == [r[0] for r in whole] and len(part0) == 3
+    for (pa, ta, ra), (pb, tb, rb) in zip(part0 + part1, whole):
+        assert list(ta) == list(tb) and np.array_equal(ra, rb)
+    for i in range(5):
+        da, db = tmp_path / "sharded" / f"clip{i}", tmp_path / "whole" / f"clip{i}"
+        names = sorted(os.listdir(da))
+        assert names == sorted(os.listdir(db))
+        match, mismatch, errors = filecmp.cmpfiles(str(da), str(db), names, shallow=False)
+        assert not mismatch and not errors, (i, mismatch, errors)
+    assert model.evaluate(recs, output_dir=str(tmp_path / "none"), shard=(7, 8)) == []          # more ranks than sources: an empty shard is fine
+
+
 def test_default_piece_schedule_is_bitwise(eng):
     """Calls larger than max_frames take Engine.forward_host's default schedule (sdfa_amd/engine.py piece_schedule: uniform pieces of
     3072 frames, the measured optimum of the kernels-then-copy pipeline); the rows do not depend on it."""

@@ -183,3 +183,55 @@ def test_evaluate_sh_command_line_as_a_process(tmp_path, synth_sd):
     res = evaluate_model(dict(mode="evaluate", load_from=str(ck), custom_hparams=str(hpj), output_dir=str(tmp_path / "inproc"),
                               eval_input=str(wav), eval_spk_cond="m1", overwrite_video=True))
     assert list(res[0][1]) == list(ts) and np.array_equal(res[0][2], track)
+
+
+def test_evaluate_under_torch_distributed_run_shards_the_sources(tmp_path, synth_sd):
+    """Two ranks started by `python -m torch.distributed.run --nproc-per-node 2` (both on this box's one GPU) run the same script: each
+    rank's model.evaluate() takes its block of the five sources (RANK / WORLD_SIZE from the launcher, no process group, no exchange:
+    frames are independent) and writes those sources' files; together they write what one process writes, bit for bit."""
+    import filecmp
+    import socket
+    import subprocess
+    import sys
+    from scipy.io import wavfile
+    sr = 16000
+    recs = []
+    for i, s in enumerate((1.0, 1.4, 0.9, 2.1, 1.2)):
+        w = tmp_path / f"clip{i}.wav"
+        wavfile.write(str(w), sr, (synth.make_pcm(90 + i, int(s * sr), "speechlike") * 20000).astype(np.int16))
+        recs.append([str(w), f"speaker={('m1', 'f0')[i & 1]}"])
+    ck = tmp_path / "epoch0050-step086751.ckpt"
+    torch.save({"epoch": 50, "global_step": 86751, "state": {k: torch.from_numpy(np.array(v)) for k, v in synth_sd["dgrad"].items()}}, str(ck))
+    hpj = tmp_path / "hparams.json"
+    hpj.write_text('{"audio": {"sample_rate": 16000}}')
+    script = tmp_path / "run_eval.py"
+    script.write_text(
+        "import json, os, sys, torch\n"
+        "from speech_anime.hparams import configure\n"
+        "from speech_anime.api import build_model, _load_checkpoint\n"
+        "ck, hpj, out, recs = sys.argv[1], sys.argv[2], sys.argv[3], json.loads(sys.argv[4])\n"
+        "torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())\n"
+        "hp = configure(dict(mode='evaluate', custom_hparams=hpj, load_from=ck))\n"
+        "model = build_model(hp, _load_checkpoint(ck)['state'])\n"
+        "res = model.evaluate({'test': recs}, output_dir=out, export_mesh_frames=True)\n"
+        "print('rank', os.environ.get('RANK'), 'wrote', [os.path.basename(r[0]) for r in res], flush=True)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=os.path.join(root, "sdfa-2019_amd") + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    import json
+    r1 = subprocess.run([sys.executable, str(script), str(ck), str(hpj), str(tmp_path / "one"), json.dumps(recs)], env=env, cwd=str(tmp_path),
+                        capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(port), str(script), str(ck), str(hpj), str(tmp_path / "two"), json.dumps(recs)],
+                        env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert "rank 0 wrote ['clip0.wav', 'clip1.wav', 'clip2.wav']" in r2.stdout and "rank 1 wrote ['clip3.wav', 'clip4.wav']" in r2.stdout, r2.stdout[-1000:]
+    for i in range(5):
+        da, db = tmp_path / "two" / f"clip{i}", tmp_path / "one" / f"clip{i}"
+        names = sorted(os.listdir(da))
+        assert names == sorted(os.listdir(db)) and "dgrad_3d.npy" in names
+        match, mismatch, errors = filecmp.cmpfiles(str(da), str(db), names, shallow=False)
+        assert not mismatch and not errors, (i, mismatch, errors)
