@@ -295,9 +295,10 @@ class SaberSpeechDrivenAnimation:
         # Utterance-level shards (north_star): under `python -m torch.distributed.run --nproc-per-node N -m speech_anime
         # evaluate ...` (or kwargs["shard"] = (rank, world)) rank r takes a contiguous block of the flat source list -- sizes differ by
         # at most one -- and writes its own sources' files; frames are independent, so no exchange is needed and every file is what the
-        # single-process run writes.  One process (the default) takes everything.
+        # single-process run writes.  One process (the default) takes everything; so does a call from inside a trainer (in_trainer=True:
+        # the reference evaluates there on one rank) unless it passes `shard` itself.
         flat = [rec for _, records in dict(sources).items() for rec in records]
-        rank, world = kwargs.get("shard") or (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
+        rank, world = kwargs.get("shard") or ((0, 1) if in_trainer else (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))))
         if world > 1:
             from sdfa_amd.dist import shard_range
             lo, hi = shard_range(len(flat), rank, world)
