@@ -94,9 +94,14 @@ def _load():
 lib = _load()
 
 
+option_epoch = 0      # bumped by every set_option: caches of results that a switch may change key on it (speech_anime signal -> z cache)
+
+
 def set_option(name, value):
     """Library tuning switch (A/B runs); also settable as SDFA_OPTS="name=value,name=value" in the environment."""
+    global option_epoch
     check(lib.sdfa_debug_set_option(name.encode(), int(value)))
+    option_epoch += 1
 
 
 def check(rc):

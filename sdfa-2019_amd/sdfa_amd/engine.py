@@ -42,10 +42,13 @@ def _ptr(t):
 class FrontendOnly:
     """The spectral-gather front end alone (needs no weights)."""
 
-    def __init__(self, device="cuda:0"):
+    def __init__(self, device=None):
         if not torch.cuda.is_available():
             raise RuntimeError("sdfa_amd needs a ROCm GPU: the hot path has no CPU implementation")
-        self.device = torch.device(device)
+        # None = the process's current device (one process per GPU sets it once; a hard-wired cuda:0 would pull every rank onto GPU 0)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         torch.cuda.set_device(self.device)
 
     def _staging(self, nbytes):

@@ -16,6 +16,20 @@ def _load_checkpoint(path):
     return ckpt
 
 
+def shard_from_env(env=None):
+    """(rank, world) of a torch.distributed.run launch, (0, 1) outside one."""
+    env = os.environ if env is None else env
+    return int(env.get("RANK", "0")), int(env.get("WORLD_SIZE", "1"))
+
+
+def rank_device(env, device_count):
+    """The device string of this rank's GPU under one process per GPU: cuda:<LOCAL_RANK mod devices> (several ranks share a card
+    only when a node is rehearsed on fewer GPUs than ranks); None without a GPU."""
+    if device_count <= 0:
+        return None
+    return f"cuda:{int(env.get('LOCAL_RANK', env.get('RANK', '0'))) % device_count}"
+
+
 def build_model(hparams, state_dict=None):
     from .model import SaberSpeechDrivenAnimation
     model = SaberSpeechDrivenAnimation(hparams, trainset=None, validset=None, load_pca=False)
@@ -38,13 +52,19 @@ def evaluate_model(args):
     if args.get("template_mesh"):                                       # tools/config.py:75-85
         from . import viewer
         viewer.set_template_mesh(args["template_mesh"], args.get("mesh_constraints"), args.get("mesh_tricorres"))
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and torch.cuda.device_count() > 0:
-        # one process per GPU (torch.distributed.run sets LOCAL_RANK): model.evaluate() takes this rank's shard of the sources
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+    # one process per GPU (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE): THIS entry point -- the CLI / torchrun one --
+    # derives the rank's device and its utterance shard from the environment and hands both down explicitly; the library call
+    # model.evaluate() never reads the environment
+    shard = shard_from_env()
+    if shard[1] > 1:
+        dev = rank_device(os.environ, torch.cuda.device_count())
+        if dev is not None:
+            hparams.set_key("device", dev)                             # Engine + front end of this rank live on its own GPU
+            torch.cuda.set_device(torch.device(dev))
     ckpt = _load_checkpoint(os.path.expanduser(hparams.load_from))
     model = build_model(hparams, ckpt["state"])
     model.current_epoch = ckpt.get("epoch", 0)
-    return model.evaluate(hparams.trainer.evaluate, experiment=None, in_trainer=False,
+    return model.evaluate(hparams.trainer.evaluate, experiment=None, in_trainer=False, shard=shard if shard[1] > 1 else None,
                           overwrite_video=args.get("overwrite_video", False),
                           export_mesh_frames=args.get("export_mesh_frames", False), keep_results=not from_cli,
                           output_dir=args.get("output_dir") or os.path.join(hparams.get("log_dir") or ".", "evaluate_videos"))

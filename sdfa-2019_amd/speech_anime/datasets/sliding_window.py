@@ -71,8 +71,10 @@ class DatasetSlidingWindow:
         eng = cls._engine_ref() if cls._engine_ref is not None else None
         if eng is not None:
             return eng
-        if cls._engine is None:
-            cls._engine = _engine.FrontendOnly()
+        # a bare front end lives on the configured device (hparams.device; api.evaluate_model sets it per rank), else the CURRENT one
+        want = (cls.hparams.get("device") if cls.hparams is not None else None) or None
+        if cls._engine is None or (want is not None and str(cls._engine.device) != str(torch.device(want))):
+            cls._engine = _engine.FrontendOnly(device=want)
         return cls._engine
 
     @staticmethod

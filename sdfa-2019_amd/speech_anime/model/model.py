@@ -88,6 +88,10 @@ class SaberSpeechDrivenAnimation:
     def eval(self):
         return self
 
+    def clear_signal_cache(self):
+        """Drop the one-entry signal -> z cache of generate_animation (frees z and the kept features on the device)."""
+        self._signal_cache = None
+
     def __call__(self, batch):
         return self.forward(batch)
 
@@ -189,15 +193,20 @@ class SaberSpeechDrivenAnimation:
         # The reference keeps the features of the LAST signal (model.py:364-367,409-416): the same audio with another speaker does
         # not recompute the front end.  Here everything up to the encoder output z is speaker-independent, so the one-entry cache
         # holds z: a speaker sweep over one clip re-runs only the regressor (bitwise the full call: same z, same kernels after it).
-        key = (sr, int(ensembling_ms) if ensemble else 0, eng.precision)
-        c = getattr(self, "_signal_cache", None)
+        # The key carries everything that changes z for a given signal: rate, ensembling delay, precision mode and the library's
+        # option epoch (sdfa_amd._lib.set_option; a switch set through the raw C call needs clear_signal_cache()).
+        # hparams.signal_cache = False turns the cache off (it pins z and up to 256 MB of features on the device).
+        from sdfa_amd import _lib as _sdfa_lib
+        use_cache = bool(self.hp.get("signal_cache", True))
+        key = (sr, int(ensembling_ms) if ensemble else 0, eng.precision, _sdfa_lib.option_epoch)
+        c = getattr(self, "_signal_cache", None) if use_cache else None
         if (len(signals) == 1 and c is not None and c["key"] == key and c["signal"].shape == signals[0].shape
                 and (c["feat"] is not None or not want_inputs) and np.array_equal(c["signal"], signals[0])):
             n = len(c["tslist"])
             spk = torch.full((n,), int(speakers[0]), dtype=torch.int64, device=eng.device)
             inputs_host = eng.to_host_async(c["feat"][:n].permute(0, 3, 2, 1)) if want_inputs else None
             rows = eng.forward_host(None, spk, z=c["z"], ops_key=self._model._key, wait=True, ensemble=ensemble)
-            return [self._pack(rows.numpy(), None if inputs_host is None else inputs_host.numpy(), [c["tslist"]], [n])[0]]
+            return [self._pack(rows.numpy(), None if inputs_host is None else inputs_host.numpy(), [list(c["tslist"])], [n])[0]]
         self._signal_cache = None
         tables = [frame_index(len(s), sr) for s in signals]             # ONE enumeration per clip (starts, tslist)
         clips = list(signals)
@@ -214,10 +223,10 @@ class SaberSpeechDrivenAnimation:
         if want_inputs:                                                 # others["inputs"] = audio_feat.permute(0, 3, 2, 1), model.py:463-466
             inputs_host = eng.to_host_async(feat[:n].permute(0, 3, 2, 1))
         rows = eng.forward_host(feat, spk, table=share, ops_key=self._model._key, wait=True, ensemble=ensemble)
-        if len(signals) == 1 and eng.last_z() is not None:               # one clip, one piece: remember (signal -> z) for a speaker sweep
+        if use_cache and len(signals) == 1 and eng.last_z() is not None:   # one clip, one piece: remember (signal -> z) for a speaker sweep
             # z is 2 KB per frame; the features (others["inputs"] of a later hit) are 98 KB per frame and are kept up to 256 MB only
             keep_feat = feat if feat.numel() * 4 <= (256 << 20) else None
-            self._signal_cache = {"key": key, "signal": signals[0].copy(), "tslist": tslists[0], "z": eng.last_z(), "feat": keep_feat}
+            self._signal_cache = {"key": key, "signal": signals[0].copy(), "tslist": list(tslists[0]), "z": eng.last_z(), "feat": keep_feat}
         return self._pack(rows.numpy(), inputs_host.numpy() if inputs_host is not None else None, tslists, counts)
 
     def _pack(self, rows_np, inputs_np, tslists, counts):
@@ -292,16 +301,17 @@ class SaberSpeechDrivenAnimation:
                     results.append((g["path"], tslist, animes))
             group, group_frames = [], 0
 
-        # Utterance-level shards (north_star): under `python -m torch.distributed.run --nproc-per-node N -m speech_anime
-        # evaluate ...` (or kwargs["shard"] = (rank, world)) rank r takes a contiguous block of the flat source list -- sizes differ by
-        # at most one -- and writes its own sources' files; frames are independent, so no exchange is needed and every file is what the
-        # single-process run writes.  One process (the default) takes everything; so does a call from inside a trainer (in_trainer=True:
-        # the reference evaluates there on one rank) unless it passes `shard` itself.
+        # Utterance-level shards (north_star): with kwargs["shard"] = (rank, world) rank r takes a contiguous block of the
+        # flat source list -- sizes differ by at most one -- and writes its own sources' files; frames are independent, so no exchange
+        # is needed and every file is what the single-process run writes.  WITHOUT `shard` every source is processed, as the reference's
+        # evaluate does (model.py:152-212), whatever RANK / WORLD_SIZE say: only the process entry point (`speech_anime.api.evaluate_model`,
+        # i.e. `python -m torch.distributed.run ... -m speech_anime evaluate`) derives the shard from the environment and passes it down.
         flat = [rec for _, records in dict(sources).items() for rec in records]
-        rank, world = kwargs.get("shard") or ((0, 1) if in_trainer else (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))))
+        rank, world = kwargs.get("shard") or (0, 1)
         if world > 1:
             from sdfa_amd.dist import shard_range
             lo, hi = shard_range(len(flat), rank, world)
+            print(f"[speech_anime] evaluate: shard {rank} of {world} takes sources [{lo}, {hi}) of {len(flat)} ({len(flat) - (hi - lo)} left to the other ranks)")
             flat = flat[lo:hi]
         for records in (flat,):
             for rec in records:

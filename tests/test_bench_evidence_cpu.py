@@ -65,3 +65,39 @@ def test_attention_stage_is_picked_by_dispatch_position(tmp_path):
     assert ns == 300 + 100 + 100 + 100 + 100                                   # the MLP GEMMs behind attn_kernel are not the attention stage
     assert abs(util - (80 * 300 + 60 * 100 + 70 * 100) / 700) < 1e-9
     assert {e["kernel"]: e["calls"] for e in per} == {"gemm_k4_kernel<0>": 3, "attn_kernel": 2}
+
+
+def test_launcher_argv_and_self_launch_relay(tmp_path, monkeypatch, capfd):
+    """`python3 bench.py --gpus N` with no launcher starts its own ranks as a CHILD under torch.distributed.run (127.0.0.1 rendezvous, same
+    arguments), passes rank 0's line through and exits with the child's code; a child that fails, or ends without the line, is a
+    non-zero exit -- never a silent N = 1."""
+    import pytest
+    bench = _load("bench_for_test3", "bench.py")
+    argv = ["--gpus", "8", "--steps", "20", "--warmup", "3"]
+    cmd = bench.launcher_argv(8, argv, 29555, python="py")
+    assert cmd[:4] == ["py", "-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29555"
+    assert cmd[-len(argv) - 1] == os.path.join(ROOT, "bench.py") and cmd[-len(argv):] == argv
+    a = bench.parse(argv)
+    assert a.gpus == 8 and a.all_legs is False and a.inject_failure is None
+
+    def fake(code, line):
+        script = tmp_path / f"child{code}{len(line)}.py"
+        script.write_text(f"import os, sys\nassert os.environ['SDFA_BENCH_LAUNCHER'] == 'self'\nprint('noise')\n"
+                          f"print({line!r}) if {bool(line)!r} else None\nsys.exit({code})\n")
+        monkeypatch.setattr(bench, "launcher_argv", lambda n, av, port, python=None: [sys.executable, str(script)])
+
+    fake(0, '{"metric": "m", "value": 1.0, "n_gpus": 8}')
+    with pytest.raises(SystemExit) as e:
+        bench.self_launch(a, argv)
+    assert e.value.code == 0
+    out = capfd.readouterr().out.splitlines()
+    assert out[-1] == '{"metric": "m", "value": 1.0, "n_gpus": 8}' and json.loads(out[-1])["n_gpus"] == 8
+    fake(3, '')
+    with pytest.raises(SystemExit) as e:
+        bench.self_launch(a, argv)
+    assert e.value.code == 3                                                   # the child's code, not a fall-back
+    fake(0, '')
+    with pytest.raises(SystemExit) as e:
+        bench.self_launch(a, argv)
+    assert e.value.code == 1                                                   # ended "fine" without the line: still an error

@@ -98,3 +98,39 @@ def test_librosa_restatement_reproduces_published_docstring_examples():
     hz_per_bin = 22050 / 2048
     area = fb.sum(1) * hz_per_bin
     assert np.all(np.abs(area[5:-1] - 1.0) < 0.05)
+
+
+def test_evaluate_model_hands_rank_device_and_shard_down(tmp_path, monkeypatch):
+    """under `torch.distributed.run --nproc-per-node N -m speech_anime evaluate` the process entry point -- and only it --
+    turns LOCAL_RANK into the device the Engine is built on and RANK / WORLD_SIZE into the explicit utterance shard; without a
+    launcher nothing is sharded and the configured device stands."""
+    import torch
+    from speech_anime import api
+    assert api.rank_device({"LOCAL_RANK": "5"}, 8) == "cuda:5" and api.rank_device({"LOCAL_RANK": "5"}, 4) == "cuda:1"
+    assert api.rank_device({"LOCAL_RANK": "1"}, 1) == "cuda:0" and api.rank_device({}, 0) is None
+    assert api.shard_from_env({}) == (0, 1) and api.shard_from_env({"RANK": "3", "WORLD_SIZE": "8"}) == (3, 8)
+    seen = {}
+
+    class FakeModel:
+        current_epoch = 0
+
+        def evaluate(self, sources, **kw):
+            seen["shard"], seen["sources"] = kw.get("shard"), sources
+            return []
+
+    def fake_build(hparams, state_dict=None):
+        seen["device"] = hparams.device
+        return FakeModel()
+
+    monkeypatch.setattr(api, "_load_checkpoint", lambda path: {"state": {}, "epoch": 1})
+    monkeypatch.setattr(api, "build_model", fake_build)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: seen.__setitem__("set_device", str(d)))
+    args = dict(mode="evaluate", load_from="x.ckpt", custom_hparams="dgrad", eval_input="a.wav", output_dir=str(tmp_path))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    api.evaluate_model(dict(args))
+    assert seen["device"] == "cuda:0" and seen["shard"] is None and "set_device" not in seen
+    monkeypatch.setenv("RANK", "5"); monkeypatch.setenv("LOCAL_RANK", "5"); monkeypatch.setenv("WORLD_SIZE", "8")
+    api.evaluate_model(dict(args))
+    assert seen["device"] == "cuda:5" and seen["set_device"] == "cuda:5" and seen["shard"] == (5, 8)

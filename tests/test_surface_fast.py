@@ -234,6 +234,24 @@ def test_speaker_sweep_reuses_the_encoder_output(synth_sd):
     fresh._signal_cache = None
     tsf, af, _ = fresh.generate_animation(other, "m1", 0, 0, ensembling_ms=0, want_inputs=False)
     assert np.array_equal(a4, af)
+    # a hit hands out its own timestamp list (a caller may mutate it), a library switch set through sdfa_amd._lib.set_option
+    # retires the entry, clear_signal_cache() / hparams.signal_cache = False drop or disable it
+    from sdfa_amd import _lib
+    ts5, _, _ = model.generate_animation(other, "f1", 0, 0, ensembling_ms=0, want_inputs=False)
+    ts5.append(-1)
+    ts6, _, _ = model.generate_animation(other, "f2", 0, 0, ensembling_ms=0, want_inputs=False)
+    assert ts6 == ts4 and ts6 is not model._signal_cache["tslist"]
+    _lib.set_option("gemm_variant", 0)                                    # any switch: the epoch moves, the entry no longer matches
+    eng.profile(True)
+    model.generate_animation(other, "f3", 0, 0, ensembling_ms=0, want_inputs=False)
+    torch.cuda.synchronize()
+    assert eng.profile_ms("freq_lstm") > 0                                # recomputed
+    eng.profile(False)
+    model.clear_signal_cache()
+    assert model._signal_cache is None
+    hp.set_key("signal_cache", False)
+    model.generate_animation(other, "m1", 0, 0, ensembling_ms=0, want_inputs=False)
+    assert model._signal_cache is None
 
 
 def test_evaluate_in_launch_groups_is_the_clip_by_clip_loop(tmp_path, synth_sd):
@@ -270,8 +288,9 @@ def test_evaluate_in_launch_groups_is_the_clip_by_clip_loop(tmp_path, synth_sd):
 
 def test_evaluate_shards_sources_across_ranks(tmp_path, synth_sd, monkeypatch):
     """north_star / SURVEY 8(e) on the surface: under torch.distributed.run every rank's evaluate() takes a contiguous block of the
-    flat source list (RANK / WORLD_SIZE, or shard=(rank, world)) and writes its own sources' files; together the ranks write exactly
-    the files of the single-process run, and no source twice."""
+    flat source list (shard=(rank, world), which the process entry point speech_anime.api.evaluate_model derives from RANK / WORLD_SIZE)
+    and writes its own sources' files; together the ranks write exactly the files of the single-process run, and no source twice.  The
+    LIBRARY call never reads the environment: without `shard` it processes every source, like the reference's evaluate."""
     import filecmp
     import os
     from scipy.io import wavfile
@@ -285,9 +304,11 @@ def test_evaluate_shards_sources_across_ranks(tmp_path, synth_sd, monkeypatch):
     whole = model.evaluate(recs, output_dir=str(tmp_path / "whole"), export_mesh_frames=True)
     assert [os.path.basename(r[0]) for r in whole] == [f"clip{i}.wav" for i in range(5)]
     part0 = model.evaluate(recs, output_dir=str(tmp_path / "sharded"), export_mesh_frames=True, shard=(0, 2))      # clips 0..2
-    monkeypatch.setenv("RANK", "1"); monkeypatch.setenv("WORLD_SIZE", "2")                                             # clips 3..4, from the environment
-    part1 = model.evaluate(recs, output_dir=str(tmp_path / "sharded"), export_mesh_frames=True)
+    part1 = model.evaluate(recs, output_dir=str(tmp_path / "sharded"), export_mesh_frames=True, shard=(1, 2))      # clips 3..4
+    monkeypatch.setenv("RANK", "1"); monkeypatch.setenv("WORLD_SIZE", "2")                  # inside somebody's torchrun job: still every source
+    envd = model.evaluate(recs, output_dir=str(tmp_path / "env"), export_mesh_frames=False)
     monkeypatch.delenv("RANK"); monkeypatch.delenv("WORLD_SIZE")
+    assert [r[0] for r in envd] == [r[0] for r in whole]
     assert [r[0] for r in part0] + [r[0] for r in part1] == [r[0] for r in whole] and len(part0) == 3
     for (pa, ta, ra), (pb, tb, rb) in zip(part0 + part1, whole):
         assert list(ta) == list(tb) and np.array_equal(ra, rb)

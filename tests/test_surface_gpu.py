@@ -187,8 +187,9 @@ def test_evaluate_sh_command_line_as_a_process(tmp_path, synth_sd):
 
 def test_evaluate_under_torch_distributed_run_shards_the_sources(tmp_path, synth_sd):
     """Two ranks started by `python -m torch.distributed.run --nproc-per-node 2` (both on this box's one GPU) run the same script: each
-    rank's model.evaluate() takes its block of the five sources (RANK / WORLD_SIZE from the launcher, no process group, no exchange:
-    frames are independent) and writes those sources' files; together they write what one process writes, bit for bit."""
+    rank's model.evaluate() takes its block of the five sources (shard = speech_anime.api.shard_from_env(): RANK / WORLD_SIZE from the
+    launcher, handed down explicitly as evaluate_model does; no process group, no exchange: frames are independent) on the device
+    speech_anime.api.rank_device() names, and writes those sources' files; together they write what one process writes, bit for bit."""
     import filecmp
     import socket
     import subprocess
@@ -208,12 +209,14 @@ def test_evaluate_under_torch_distributed_run_shards_the_sources(tmp_path, synth
     script.write_text(
         "import json, os, sys, torch\n"
         "from speech_anime.hparams import configure\n"
-        "from speech_anime.api import build_model, _load_checkpoint\n"
+        "from speech_anime.api import build_model, _load_checkpoint, shard_from_env, rank_device\n"
         "ck, hpj, out, recs = sys.argv[1], sys.argv[2], sys.argv[3], json.loads(sys.argv[4])\n"
-        "torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())\n"
         "hp = configure(dict(mode='evaluate', custom_hparams=hpj, load_from=ck))\n"
+        "shard = shard_from_env()\n"
+        "hp.set_key('device', rank_device(os.environ, torch.cuda.device_count()))\n"
         "model = build_model(hp, _load_checkpoint(ck)['state'])\n"
-        "res = model.evaluate({'test': recs}, output_dir=out, export_mesh_frames=True)\n"
+        "assert str(model._model._engine.device) == hp.device\n"
+        "res = model.evaluate({'test': recs}, output_dir=out, export_mesh_frames=True, shard=shard if shard[1] > 1 else None)\n"
         "print('rank', os.environ.get('RANK'), 'wrote', [os.path.basename(r[0]) for r in res], flush=True)\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYTHONPATH=os.path.join(root, "sdfa-2019_amd") + os.pathsep + os.environ.get("PYTHONPATH", ""))
