@@ -378,6 +378,22 @@ def frontend_counter_bytes():
         return None, None
 
 
+def precision_worst_case():
+    """Worst max|dgrad - reference| per precision mode over the committed wide sweep (profiles/r*_precision_modes.json, written by
+    tests/test_gpu_precision.py: other seeds, hotter recurrences, BatchNorm scales of both signs, the reference's 10 s fixture, full size) --
+    what `mixed_precision.max_abs_dgrad_err_vs_cpu_ref` reports, together with this run's own 10 s clip, instead of the one fixture case."""
+    import glob
+    try:
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_precision_modes.json")))[::-1]:
+            with open(path) as f:
+                t = json.load(f)
+            if "worst_case_dgrad" in t:
+                return {k: float(v) for k, v in t["worst_case_dgrad"].items()}, os.path.relpath(path, ROOT)
+    except Exception:
+        pass
+    return {}, None
+
+
 def attention_counter_util():
     """Time-weighted rocprofv3 MfmaUtil of the attention stage (profiles/r*_pmc/attention_mfma.json, written by profiles/pmc_summary.py
     from the committed --pmc pass), or None when absent or csrc/attn.hip / csrc/gemm.hip have changed since."""
@@ -880,12 +896,17 @@ def main():
                 res["cpu_baseline"] = cb
                 res["max_abs_dgrad_err_vs_cpu_ref"], res["tslist_bit_exact"] = gpu_err(a.precision)
                 if mixed is not None and not fatal:
+                    worst, worst_src = precision_worst_case()
                     for mode, block in (("bf16x3", res["mixed_precision"]), ("bf16x3_attention", res["mixed_precision"]["bf16x3_attention"]),
                                         ("bf16x6", res["mixed_precision"]["bf16x6"])):
                         try:
-                            block["max_abs_dgrad_err_vs_cpu_ref_10s_clip"] = gpu_err(mode)[0]
+                            live = gpu_err(mode)[0]
+                            block["max_abs_dgrad_err_vs_cpu_ref_10s_clip"] = live
+                            # the WORST case on record, not the fixture case: this run's clip and the committed wide sweep
+                            block["max_abs_dgrad_err_vs_cpu_ref"] = max(live, worst.get(mode, 0.0))
+                            block["max_abs_dgrad_err_source"] = f"max(this run's 10 s clip, worst case of {worst_src})" if mode in worst else "this run's 10 s clip only"
                         except Exception as e:
-                            block["max_abs_dgrad_err_vs_cpu_ref_10s_clip"] = {"error": repr(e)}
+                            block["max_abs_dgrad_err_vs_cpu_ref"] = {"error": repr(e)}
             except Exception as e:      # the GPU measurement above stands on its own; say what went wrong with the CPU leg
                 res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": None, "nproc": int(os.cpu_count() or 0), "kind": "port",
                                        "sample": f"failed: {e!r}"}

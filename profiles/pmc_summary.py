@@ -117,17 +117,25 @@ def main():
         # the spectrogram stage (north_star: "rocprof counters reporting achieved HBM GB/s on the spectrogram stage"): counter bytes
         # of its two kernels per frame; bench.py divides by its live stage time
         frames = int(sys.argv[sys.argv.index("--frames") + 1])
+        # round 5: the stage is share_prev_kernel + mel_stream_kernel (no mel table); with option frontend_two_kernel = 1 it is the share
+        # map + mel_columns_kernel + gather_features_kernel of rounds 2-4.  Whichever form ran is summarised.
         fe = {}
         for k in M:
-            for stem in ("mel_columns", "gather_features"):          # mel_columns_kernel<WIN> / mel_columns_r8_kernel, gather_features_kernel
+            for stem in ("mel_stream", "share_prev", "mel_columns", "gather_features"):
                 if k[0].startswith(stem) and F.get(k) and W.get(k):
                     fe[stem] = {"read_bytes": F[k][-1] * 1024 * FETCH_CORRECTION, "write_bytes": W[k][-1] * 1024, "grid": k[1]}
-        if len(fe) == 2:
+        form = "stream" if "mel_stream" in fe else ("two_kernel" if len([s_ for s_ in ("mel_columns", "gather_features") if s_ in fe]) == 2 else None)
+        if form == "stream":
+            fe = {k: v for k, v in fe.items() if k in ("mel_stream", "share_prev")}
+        elif form == "two_kernel":
+            fe = {k: v for k, v in fe.items() if k in ("mel_columns", "gather_features")}
+        if form:
             tot = sum(v["read_bytes"] + v["write_bytes"] for v in fe.values())
-            json.dump({"frames": frames, "kernels": fe, "bytes_per_frame": tot / frames, "fetch_correction": FETCH_CORRECTION,
-                       "frontend_hip_sha1": file_sha1("frontend.hip"),
+            names = "share_prev_kernel + mel_stream_kernel" if form == "stream" else "mel_columns_kernel + gather_features_kernel"
+            json.dump({"frames": frames, "form": form, "kernels": fe, "bytes_per_frame": tot / frames, "algorithmic_bytes_per_frame": 4 * 16000 / 60 + 98304,
+                       "fetch_correction": FETCH_CORRECTION, "frontend_hip_sha1": file_sha1("frontend.hip"),
                        "source": f"separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes ({os.path.basename(os.path.normpath(d))}), last launch of "
-                                 "mel_columns_kernel + gather_features_kernel (the full batch); FETCH_SIZE doubled per MI355X_MICROARCH.md"},
+                                 f"{names} (the full batch); FETCH_SIZE doubled per MI355X_MICROARCH.md"},
                       open(sys.argv[sys.argv.index("--frontend-json") + 1], "w"), indent=1)
     if "--attention-json" in sys.argv:
         util, ns, per = attention_stage(os.path.join(d, "MfmaUtil_counter_collection.csv"))

@@ -18,6 +18,9 @@
 
 thread_local int g_sdfa_mel_fft_radix4 = 0;     // "mel_fft_radix4" option (read by frontend.hip)
 thread_local int g_sdfa_gather_plain_order = 0; // "gather_plain_order" option (read by frontend.hip)
+thread_local int g_sdfa_frontend_two_kernel = 0;    // "frontend_two_kernel": 1 = share map + mel_columns + gather_features (rounds 2-4) instead of the spectral stream
+thread_local int g_sdfa_frontend_stream_block = 0; // "frontend_stream_block" / "frontend_stream_slots": segment geometry of the spectral stream (0 = default)
+thread_local int g_sdfa_frontend_stream_slots = 0;
 thread_local int g_sdfa_frontend_t_major = 0;   // "frontend_t_major" option: the front end's distinct columns numbered time-step-major (rounds 2-3)
 
 namespace {
@@ -154,6 +157,7 @@ struct sdfa_model {
     // offsets = one basis (K 64)
     int pca_n = 0;
     const float *pca_q[2], *pca_bias[2];
+    const void *pca_qb = nullptr;              // dgrad head: both bases as bf16 octets (hi | lo planes) for the split-bf16 PCA kernel (pack_pca_bf16)
     int pca_K[2], pca_k0[2], pca_group[2], pca_off[2];
     std::atomic<int> freq_shape{9};   // launch form of the fp32 frequency LSTM (kernels.h FreqLstmArgs::shape); sdfa_model_autotune measures and sets it
                                       // (atomic: forwards on other threads may read it while an autotune call stores the winner)
@@ -254,6 +258,35 @@ void pack_conv_bf16(uint16_t *dst, const float *w1, const float *w2, const float
                     const int ci = 32 * (ks >> 1) + 8 * (2 * (ks & 1) + (e >> 2)) + 4 * hh + (e & 3);
                     put(64 + 768 + ((size_t)ks * 2 + hh) * 64 + co, e, w3[(size_t)co * 64 + ci]);
                 }
+}
+
+// PCA bases of the dgrad head for pca_dgrad_res_kernel<true> (pca.hip): per triangle block tb (32 triangles: 192 scale + 96 rotat columns)
+//   [plane hi | lo] x ( scale: 12 rows r = 2 ks + h of 192 octets | rotat: 24 rows of 96 octets ),  octet e = basis[k = 16 ks + 8 h + e][column]
+// -- the B operand of v_mfma_f32_32x32x16_bf16 as a lane reads it.  comp: torch layout [column][k]; k >= kreal and columns past the end are 0.
+void pack_pca_bf16(uint16_t *dst, const float *comp_s, const float *comp_r, int64_t cols_s, int64_t cols_r, int64_t ntb) {
+    constexpr size_t PLANE = (size_t)(12 * 192 + 24 * 96) * 8;       // bf16 values per plane and triangle block
+    for (int64_t tb = 0; tb < ntb; ++tb) {
+        uint16_t *blk = dst + (size_t)tb * 2 * PLANE;
+        auto put = [&](size_t octet, int e, float x) {
+            const uint16_t hi = bf16_rne_bits(x);
+            blk[octet * 8 + e] = hi;
+            blk[PLANE + octet * 8 + e] = bf16_rne_bits(x - bf16_bits_to_float(hi));
+        };
+        for (int r = 0; r < 12; ++r)
+            for (int c = 0; c < 192; ++c)
+                for (int e = 0; e < 8; ++e) {
+                    const int k = 8 * r + e;                         // 16 ks + 8 h + e with r = 2 ks + h
+                    const int64_t q = tb * 192 + c;
+                    put((size_t)r * 192 + c, e, (k < 85 && q < cols_s) ? comp_s[(size_t)q * 85 + k] : 0.f);
+                }
+        for (int r = 0; r < 24; ++r)
+            for (int c = 0; c < 96; ++c)
+                for (int e = 0; e < 8; ++e) {
+                    const int k = 8 * r + e;
+                    const int64_t q = tb * 96 + c;
+                    put((size_t)12 * 192 + (size_t)r * 96 + c, e, (k < 180 && q < cols_r) ? comp_r[(size_t)q * 180 + k] : 0.f);
+                }
+    }
 }
 
 // Frequency-LSTM weights for freq_lstm_bf16_kernel / freq_lstm_bf16x6_kernel: per direction [plane hi | mid | lo][24 octets][512 gate rows][8] bf16.
@@ -462,6 +495,13 @@ int sdfa_mel_frontend_gather(const float *d_pcm, const int64_t *d_clip_off, cons
     sa.prev = sh + 16; sa.shift = sa.prev + w.Nc;
     sa.owner = sa.shift + w.Nc; sa.flag = sa.owner + w.Mc; sa.uid = sa.flag + w.Mc;
     sa.col_src = sa.uid + w.Mc; sa.col_to_u = sa.col_src + w.Mc; sa.tile_sum = sa.col_to_u + w.Mc;
+    if (!g_sdfa_frontend_two_kernel && !g_sdfa_mel_fft_radix4 && !g_sdfa_frontend_t_major) {
+        // spectral stream (frontend.hip): the chains are read from prev / shift, the mel rows live in an LDS ring, no table
+        HIP_TRY(sdfa_launch_share_prev(sa, s));
+        HIP_TRY(sdfa_launch_mel_stream(c, d_pcm, d_clip_off, d_clip_len, d_frame_clip, d_frame_start, sa.prev, sa.shift, n_frames,
+                                       g_sdfa_frontend_stream_block, g_sdfa_frontend_stream_slots, d_audio_feat, s));
+        return SDFA_OK;
+    }
     HIP_TRY(sdfa_launch_share_map(sa, s));
     float *table = reinterpret_cast<float *>(reinterpret_cast<char *>(d_workspace) + w.table_off);
     HIP_TRY(sdfa_launch_mel_columns(c, d_pcm, d_clip_off, d_clip_len, d_frame_clip, d_frame_start, sa.col_src, sa.counts, table, s));
@@ -642,7 +682,8 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
     // ---- output module
     const std::string om = "_output_module.";
     size_t o_fc[7][3];
-    size_t o_pq[2] = {0, 0}, o_pb[2] = {0, 0};
+    size_t o_pq[2] = {0, 0}, o_pb[2] = {0, 0}, o_pqb = 0;
+    bool have_pqb = false;
     if (m->head == SDFA_HEAD_DGRAD) {
         if (pack_fc(m, pk, om + "_layers.0", 512, 512, true, ACT_LRELU, o_fc[0], m->trunk)) return SDFA_ESTATE;
         const char *brn[2] = {"_scale_layers.", "_rotat_layers."};
@@ -670,6 +711,12 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
                 for (int k = 0; k < kreal[b]; ++k) pk.buf[o_pq[b] + ((size_t)(k / 4) * m->pca_ld[b] + o) * 4 + (k % 4)] = row[k];
                 pk.buf[o_pb[b] + o] = (*mean[b])[o];
             }
+        }
+        {   // the same bases as bf16 octets for the split-bf16 form of the fused kernel
+            const int64_t ntb = (m->pca_cols[1] + 95) / 96;
+            o_pqb = pk.add((size_t)ntb * 2 * (12 * 192 + 24 * 96) * 8 / 2);      // two bf16 per float slot
+            pack_pca_bf16(reinterpret_cast<uint16_t *>(&pk.buf[o_pqb]), cs->data(), cr->data(), m->pca_cols[0], m->pca_cols[1], ntb);
+            have_pqb = true;
         }
     } else {
         if (pack_fc(m, pk, om + "_layers.0", 512, 512, true, ACT_LRELU, o_fc[0], m->off[0])) return SDFA_ESTATE;
@@ -711,6 +758,7 @@ int sdfa_model_finalize(sdfa_model *m, void *stream) {
         for (int i = 0; i < 3; ++i) bind(m->off[i], o_fc[i]);
     }
     for (int b = 0; b < m->pca_n; ++b) { m->pca_q[b] = d + o_pq[b]; m->pca_bias[b] = d + o_pb[b]; }
+    if (have_pqb) m->pca_qb = d + o_pqb;
     m->host.clear();
     m->finalized = true;
     return SDFA_OK;
@@ -807,6 +855,7 @@ thread_local int g_sdfa_freq_lstm_shape = 0;
 thread_local int g_sdfa_pca_unfused = 0;
 thread_local int g_sdfa_conv_unfused = 0;
 thread_local int g_sdfa_pca_lds = 0;
+thread_local int g_sdfa_pca_fp32 = 0;     // "pca_fp32": 1 = the dgrad PCA expansion stays on the fp32 kernel in SDFA_PREC_BF16X3 (A/B)
 thread_local int g_sdfa_conv_fp32 = 0;    // "conv_fp32": 1 = the conv stack stays on the fp32 kernel in the mixed-precision modes (A/B)
 thread_local int g_sdfa_time_lstm_split = 0;
 thread_local int g_sdfa_time_lstm_handoff = 0;
@@ -814,6 +863,15 @@ thread_local int g_sdfa_time_lstm_timeout_us = 0;
 thread_local int g_sdfa_share_gx0_off = 0;
 int sdfa_debug_set_option(const char *name, int value) {
     if (name && !strcmp(name, "share_gx0_off")) { g_sdfa_share_gx0_off = value; return SDFA_OK; }
+    if (name && !strcmp(name, "frontend_two_kernel")) { g_sdfa_frontend_two_kernel = value; return SDFA_OK; }
+    if (name && !strcmp(name, "frontend_stream_block")) {
+        if (value < 0 || value > 256) return fail(SDFA_EINVAL, "frontend_stream_block: 0 (default) or 1..256 frames");
+        g_sdfa_frontend_stream_block = value; return SDFA_OK;
+    }
+    if (name && !strcmp(name, "frontend_stream_slots")) {
+        if (value < 0 || value > 256) return fail(SDFA_EINVAL, "frontend_stream_slots: 0 (default) or 1..256 workgroups per block");
+        g_sdfa_frontend_stream_slots = value; return SDFA_OK;
+    }
     if (name && !strcmp(name, "gather_plain_order")) { g_sdfa_gather_plain_order = value; return SDFA_OK; }
     if (name && !strcmp(name, "mel_fft_radix4")) { g_sdfa_mel_fft_radix4 = value; return SDFA_OK; }
     if (name && !strcmp(name, "frontend_t_major")) { g_sdfa_frontend_t_major = value; return SDFA_OK; }
@@ -826,6 +884,7 @@ int sdfa_debug_set_option(const char *name, int value) {
     if (name && !strcmp(name, "conv_unfused")) { g_sdfa_conv_unfused = value; return SDFA_OK; }
     if (name && !strcmp(name, "pca_lds")) { g_sdfa_pca_lds = value; return SDFA_OK; }
     if (name && !strcmp(name, "conv_fp32")) { g_sdfa_conv_fp32 = value; return SDFA_OK; }
+    if (name && !strcmp(name, "pca_fp32")) { g_sdfa_pca_fp32 = value; return SDFA_OK; }
     return fail(SDFA_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }
 
@@ -988,11 +1047,18 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
             d_ulimit = sa.counts + 1; col_to_u = sa.col_to_u;
             ca.col_src = sa.col_src; ca.col_limit = d_ulimit;
         }
-        if (m->keep || g_sdfa_conv_unfused) {   // the debug taps read pool1
+        const int conv_terms = g_sdfa_conv_fp32 ? 0 : stage_terms(m, STAGE_BODY);
+        if (m->keep && conv_terms && !g_sdfa_conv_unfused) {
+            // debug taps in a body precision mode: the X3 tap must be the arithmetic that ships -- conv123_bf16_kernel -- so a
+            // packing or K-order bug in pack_conv_bf16 can be localised; the pool1 tap (which the fused kernel never writes) stays fp32
+            pf.begin("conv1"); HIP_TRY(sdfa_launch_conv1(ca, s)); pf.end();
+            ca.wb = m->cv_wb; ca.terms = conv_terms;
+            pf.begin("conv23"); HIP_TRY(sdfa_launch_conv123(ca, s)); pf.end();
+        } else if (m->keep || g_sdfa_conv_unfused) {   // the debug taps read pool1
             pf.begin("conv1"); HIP_TRY(sdfa_launch_conv1(ca, s)); pf.end();
             pf.begin("conv23"); HIP_TRY(sdfa_launch_conv23(ca, s)); pf.end();
         } else {
-            ca.wb = m->cv_wb; ca.terms = g_sdfa_conv_fp32 ? 0 : stage_terms(m, STAGE_BODY);      // the mixed-precision modes run the stack on bf16 MFMA too
+            ca.wb = m->cv_wb; ca.terms = conv_terms;      // the mixed-precision modes run the stack on bf16 MFMA too
             pf.begin("conv23"); HIP_TRY(sdfa_launch_conv123(ca, s)); pf.end();
         }
 
@@ -1080,6 +1146,8 @@ static hipError_t expand_rows(const sdfa_model *m, const float *coef, int64_t N,
         pa.out = d_out + f0 * m->out_dim; pa.N = N; pa.Nc = Nc; pa.out_dim = m->out_dim;
         pa.n_extra = n_outs - 1;
         pa.reserve_cus = m->reserved_cus.load();
+        // SDFA_PREC_BF16X3: the expansion on split-bf16 MFMA too (round 5; "pca_fp32" = 1 keeps it exact); every other mode: fp32
+        pa.basis_b = m->pca_qb; pa.terms = (g_sdfa_pca_fp32 || m->precision != SDFA_PREC_BF16X3) ? 0 : 3;
         for (int x = 1; x < n_outs; ++x) pa.out_extra[x - 1] = h_d_outs[x] + f0 * m->out_dim;
         pa.ld_s = m->pca_ld[0]; pa.ld_r = m->pca_ld[1]; pa.cols_s = m->pca_cols[0]; pa.cols_r = m->pca_cols[1];
         // default: basis slab resident in LDS, persistent work units (pca_dgrad_res_kernel); "pca_lds" option 4 = the register-

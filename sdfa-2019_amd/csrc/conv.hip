@@ -14,6 +14,25 @@
 
 namespace {
 
+// Epilogue of a POOLED conv layer: LeakyReLU(0.2) -> eval BatchNorm -> max over the row pair (extend.py:94-101, conv2d.py:64-97).
+// v -> lrelu(v + b) * s + t is monotone in v (each step is, roundings included): non-decreasing for a BN scale s >= 0, non-increasing
+// for s < 0, so max(f(v0), f(v1)) = f(max(v0, v1)) resp. f(min(v0, v1)) BITWISE, and the activation can run once on the selected
+// accumulator.  The select is ONE instruction: v_med3(v0, v1, c) with c = +inf picks the max, c = -inf the min; c = copysign(inf, s)
+// is one v_bfi per channel value.  Six vector instructions per pooled element instead of nine.
+// -DSDFA_CONV_POOL_LATE=1 (make EXP=CONV_POOL_LATE) keeps the activation-on-both-rows order for same-box A/B timing: same bits.
+__device__ __forceinline__ float pool_act(float a0, float a1, float b, float s, float t) {
+#if SDFA_CONV_NOEPI          /* timing experiment only (wrong results): no activation at all -- what is the whole epilogue worth? */
+    return __builtin_amdgcn_fmed3f(a0, a1, __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, s) & 0x80000000u) | 0x7f800000u));
+#elif SDFA_CONV_POOL_LATE
+    const float v0 = lrelu02(a0 + b) * s + t;
+    const float v1 = lrelu02(a1 + b) * s + t;
+    return fmaxf(v0, v1);
+#else
+    const float c = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, s) & 0x80000000u) | 0x7f800000u);
+    return lrelu02(__builtin_amdgcn_fmed3f(a0, a1, c) + b) * s + t;
+#endif
+}
+
 // ---------------------------------------------------------------------------------- conv1 + pool
 constexpr int C1_ROWS = 391;   // input rows f*3+c = -3 .. 387 (zero rows either side)
 
@@ -75,9 +94,7 @@ __global__ __launch_bounds__(256, 2) void conv1_pool_kernel(ConvArgs a) {
             float o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float v0 = lrelu02(acc0[4 * g + e] + bq[e]) * sq[e] + tq[e];
-                float v1 = lrelu02(acc1[4 * g + e] + bq[e]) * sq[e] + tq[e];
-                o[e] = fmaxf(v0, v1);
+                o[e] = pool_act(acc0[4 * g + e], acc1[4 * g + e], bq[e], sq[e], tq[e]);
             }
             st4(a.P1 + (((int64_t)(p * 8 + 2 * g + h)) * a.Mc + m0 + l31) * 4, make_float4(o[0], o[1], o[2], o[3]));
         }
@@ -146,6 +163,8 @@ __global__ __launch_bounds__(256, 2) void conv23_kernel(ConvArgs a) {
         }
     }
     // LeakyReLU -> BN -> max over the row pair: pooled tile, rows = channels
+    float4 wc[2] = {W3[h * 64 + l31], W3[h * 64 + 32 + l31]};      // conv3's first weight quads: requested before the pooling epilogue, land during it
+    __builtin_amdgcn_sched_barrier(0);
     f32x16 p2[2];
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
@@ -156,9 +175,7 @@ __global__ __launch_bounds__(256, 2) void conv23_kernel(ConvArgs a) {
             const float bq[4] = {b.x, b.y, b.z, b.w}, sq[4] = {s.x, s.y, s.z, s.w}, tq[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float v0 = lrelu02(acc[ot][0][4 * g + e] + bq[e]) * sq[e] + tq[e];
-                float v1 = lrelu02(acc[ot][1][4 * g + e] + bq[e]) * sq[e] + tq[e];
-                p2[ot][4 * g + e] = fmaxf(v0, v1);
+                p2[ot][4 * g + e] = pool_act(acc[ot][0][4 * g + e], acc[ot][1][4 * g + e], bq[e], sq[e], tq[e]);
             }
         }
     // conv3 (1x1): contract over the pooled tile's ROW index straight from registers
@@ -167,14 +184,20 @@ __global__ __launch_bounds__(256, 2) void conv23_kernel(ConvArgs a) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc3[j][0][r] = 0.f;
+    {   // conv3's weight quads one step ahead of the MFMAs (round 5: requested right in front of them, each of the eight steps began
+        // with an exposed L2 round trip)
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int st = 0; st < 8; ++st) {
+            const int ct = st >> 2, g = st & 3;
+            float4 wn[2] = {wc[0], wc[1]};
+            if (st + 1 < 8) { wn[0] = W3[(2 * (st + 1) + h) * 64 + l31]; wn[1] = W3[(2 * (st + 1) + h) * 64 + 32 + l31]; }
+            __builtin_amdgcn_sched_barrier(0);
             const float4 xb[1] = {make_float4(p2[ct][4 * g], p2[ct][4 * g + 1], p2[ct][4 * g + 2], p2[ct][4 * g + 3])};
-            const float4 w[2] = {W3[(8 * ct + 2 * g + h) * 64 + l31], W3[(8 * ct + 2 * g + h) * 64 + 32 + l31]};
-            mfma_block<2, 1>(acc3, w, xb);
+            mfma_block<2, 1>(acc3, wc, xb);
+            __builtin_amdgcn_sched_barrier(0);
+            wc[0] = wn[0]; wc[1] = wn[1];
         }
+    }
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -238,13 +261,18 @@ __global__ __launch_bounds__(256, 2) void conv123_kernel(ConvArgs a) {
     const float4 *__restrict__ W2 = reinterpret_cast<const float4 *>(a.w2) + h * 64 + l31;
     const float4 *__restrict__ W3 = reinterpret_cast<const float4 *>(a.w3);
     float4 wa[2] = {W2[0], W2[32]}, wb[2];
+    // conv1's operands and epilogue constants are requested BEFORE the barrier too (round 5): behind it, every workgroup paid an
+    // exposed L2 round trip in front of its first MFMA
+    float w1[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) w1[s] = a.w1[(s * 2 + h) * 32 + l31];
+    float4 e1b[4], e1s[4], e1t[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { e1b[g] = ld4(a.b1 + 8 * g + 4 * h); e1s[g] = ld4(a.s1 + 8 * g + 4 * h); e1t[g] = ld4(a.t1 + 8 * g + 4 * h); }
     __syncthreads();
 
     // ---- conv1 + LeakyReLU + BN + pool: pool1 row j of the slice (global row 8 fc - 1 + j), rows j = wave, wave+4, wave+8
     {
-        float w1[5];
-#pragma unroll
-        for (int s = 0; s < 5; ++s) w1[s] = a.w1[(s * 2 + h) * 32 + l31];
         for (int j = wave; j < 10; j += 4) {
             const int f1 = 8 * fc - 1 + j;
             f32x16 acc0, acc1;
@@ -260,14 +288,13 @@ __global__ __launch_bounds__(256, 2) void conv123_kernel(ConvArgs a) {
             const bool valid = f1 >= 0 && f1 < 64;       // rows -1 and 64 are conv2's zero padding
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 b = ld4(a.b1 + 8 * g + 4 * h), sc = ld4(a.s1 + 8 * g + 4 * h), sh = ld4(a.t1 + 8 * g + 4 * h);
+                const float4 b = e1b[g], sc = e1s[g], sh = e1t[g];
                 const float bq[4] = {b.x, b.y, b.z, b.w}, sq[4] = {sc.x, sc.y, sc.z, sc.w}, tq[4] = {sh.x, sh.y, sh.z, sh.w};
                 float o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float v0 = lrelu02(acc0[4 * g + e] + bq[e]) * sq[e] + tq[e];
-                    const float v1 = lrelu02(acc1[4 * g + e] + bq[e]) * sq[e] + tq[e];
-                    o[e] = valid ? fmaxf(v0, v1) : 0.f;
+                    const float v = pool_act(acc0[4 * g + e], acc1[4 * g + e], bq[e], sq[e], tq[e]);
+                    o[e] = valid ? v : 0.f;
                 }
                 sP1[j * 8 + 2 * g + h][l31] = make_float4(o[0], o[1], o[2], o[3]);
             }
@@ -300,6 +327,8 @@ __global__ __launch_bounds__(256, 2) void conv123_kernel(ConvArgs a) {
             mfma_block<2, 2>(acc, wb, x);
         }
     }
+    float4 wc[2] = {W3[h * 64 + l31], W3[h * 64 + 32 + l31]};      // conv3's first weight quads: requested before the pooling epilogue, land during it
+    __builtin_amdgcn_sched_barrier(0);
     f32x16 p2[2];
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
@@ -310,9 +339,7 @@ __global__ __launch_bounds__(256, 2) void conv123_kernel(ConvArgs a) {
             const float bq[4] = {b.x, b.y, b.z, b.w}, sq[4] = {sc.x, sc.y, sc.z, sc.w}, tq[4] = {sh.x, sh.y, sh.z, sh.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float v0 = lrelu02(acc[ot][0][4 * g + e] + bq[e]) * sq[e] + tq[e];
-                float v1 = lrelu02(acc[ot][1][4 * g + e] + bq[e]) * sq[e] + tq[e];
-                p2[ot][4 * g + e] = fmaxf(v0, v1);
+                p2[ot][4 * g + e] = pool_act(acc[ot][0][4 * g + e], acc[ot][1][4 * g + e], bq[e], sq[e], tq[e]);
             }
         }
     f32x16 acc3[2][1];
@@ -320,14 +347,20 @@ __global__ __launch_bounds__(256, 2) void conv123_kernel(ConvArgs a) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc3[j][0][r] = 0.f;
+    {   // conv3's weight quads one step ahead of the MFMAs (round 5: requested right in front of them, each of the eight steps began
+        // with an exposed L2 round trip)
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int st = 0; st < 8; ++st) {
+            const int ct = st >> 2, g = st & 3;
+            float4 wn[2] = {wc[0], wc[1]};
+            if (st + 1 < 8) { wn[0] = W3[(2 * (st + 1) + h) * 64 + l31]; wn[1] = W3[(2 * (st + 1) + h) * 64 + 32 + l31]; }
+            __builtin_amdgcn_sched_barrier(0);
             const float4 xb[1] = {make_float4(p2[ct][4 * g], p2[ct][4 * g + 1], p2[ct][4 * g + 2], p2[ct][4 * g + 3])};
-            const float4 w[2] = {W3[(8 * ct + 2 * g + h) * 64 + l31], W3[(8 * ct + 2 * g + h) * 64 + 32 + l31]};
-            mfma_block<2, 1>(acc3, w, xb);
+            mfma_block<2, 1>(acc3, wc, xb);
+            __builtin_amdgcn_sched_barrier(0);
+            wc[0] = wn[0]; wc[1] = wn[1];
         }
+    }
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -428,13 +461,17 @@ __global__ __launch_bounds__(256, 2) void conv123_bf16_kernel(ConvArgs a) {
     cbf16x8 wa[2][3], wn[2][3];
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl) { wa[0][pl] = W2b[pl * W_PLANE]; wa[1][pl] = W2b[pl * W_PLANE + 32]; }      // conv2 k-step 0: lands during conv1
+    // conv1's operands and epilogue constants before the barrier too (round 5, as in conv123_kernel)
+    cbf16x8 w1[3];
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) w1[pl] = W1b[pl * W_PLANE];
+    float4 e1b[4], e1s[4], e1t[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { e1b[g] = ld4(a.b1 + 8 * g + 4 * h); e1s[g] = ld4(a.s1 + 8 * g + 4 * h); e1t[g] = ld4(a.t1 + 8 * g + 4 * h); }
     __syncthreads();
 
     // ---- conv1 + LeakyReLU + BN + pool -> pool1 rows j = wave, wave + 4, wave + 8 of the slice, as octets
     {
-        cbf16x8 w1[3];
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) w1[pl] = W1b[pl * W_PLANE];
         for (int j = wave; j < 10; j += 4) {
             const int f1 = 8 * fc - 1 + j;
             float x0[8], x1[8];
@@ -457,13 +494,12 @@ __global__ __launch_bounds__(256, 2) void conv123_bf16_kernel(ConvArgs a) {
             float o[16];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 b = ld4(a.b1 + 8 * g + 4 * h), sc = ld4(a.s1 + 8 * g + 4 * h), sh = ld4(a.t1 + 8 * g + 4 * h);
+                const float4 b = e1b[g], sc = e1s[g], sh = e1t[g];
                 const float bq[4] = {b.x, b.y, b.z, b.w}, sq[4] = {sc.x, sc.y, sc.z, sc.w}, tq[4] = {sh.x, sh.y, sh.z, sh.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float v0 = lrelu02(acc0[4 * g + e] + bq[e]) * sq[e] + tq[e];
-                    const float v1 = lrelu02(acc1[4 * g + e] + bq[e]) * sq[e] + tq[e];
-                    o[4 * g + e] = valid ? fmaxf(v0, v1) : 0.f;
+                    const float v = pool_act(acc0[4 * g + e], acc1[4 * g + e], bq[e], sq[e], tq[e]);
+                    o[4 * g + e] = valid ? v : 0.f;
                 }
             }
 #pragma unroll
@@ -517,9 +553,7 @@ __global__ __launch_bounds__(256, 2) void conv123_bf16_kernel(ConvArgs a) {
             const float bq[4] = {b.x, b.y, b.z, b.w}, sq[4] = {sc.x, sc.y, sc.z, sc.w}, tq[4] = {sh.x, sh.y, sh.z, sh.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float v0 = lrelu02(acc[ot][0][4 * g + e] + bq[e]) * sq[e] + tq[e];
-                float v1 = lrelu02(acc[ot][1][4 * g + e] + bq[e]) * sq[e] + tq[e];
-                p2[ot][4 * g + e] = fmaxf(v0, v1);
+                p2[ot][4 * g + e] = pool_act(acc[ot][0][4 * g + e], acc[ot][1][4 * g + e], bq[e], sq[e], tq[e]);
             }
         }
     f32x16 acc3[2];
@@ -527,18 +561,30 @@ __global__ __launch_bounds__(256, 2) void conv123_bf16_kernel(ConvArgs a) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc3[j][r] = 0.f;
+    {   // conv3's weights one k-step ahead (round 5: requested in front of their products, every k-step began with an L2 round trip)
+        cbf16x8 w3c[2][3], w3n[2][3];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+        for (int pl = 0; pl < NPL; ++pl) { w3c[0][pl] = W3b[pl * W_PLANE]; w3c[1][pl] = W3b[pl * W_PLANE + 32]; }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int st = 0; st < 4; ++st) {
+            const int ct = st >> 1, q = st & 1;
+            if (st + 1 < 4) {
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) { w3n[0][pl] = W3b[pl * W_PLANE + (st + 1) * 128]; w3n[1][pl] = W3b[pl * W_PLANE + (st + 1) * 128 + 32]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
             const float xo[8] = {p2[ct][8 * q], p2[ct][8 * q + 1], p2[ct][8 * q + 2], p2[ct][8 * q + 3], p2[ct][8 * q + 4], p2[ct][8 * q + 5], p2[ct][8 * q + 6], p2[ct][8 * q + 7]};
-            cbf16x8 xb[3], w3[2][3];
+            cbf16x8 xb[3];
             conv_split8<NPL>(xo, xb);
+            conv_products<TERMS>(acc3[0], w3c[0], xb);
+            conv_products<TERMS>(acc3[1], w3c[1], xb);
+            __builtin_amdgcn_sched_barrier(0);
+            if (st + 1 < 4) {
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) { w3[0][pl] = W3b[pl * W_PLANE + (2 * ct + q) * 128]; w3[1][pl] = W3b[pl * W_PLANE + (2 * ct + q) * 128 + 32]; }
-            conv_products<TERMS>(acc3[0], w3[0], xb);
-            conv_products<TERMS>(acc3[1], w3[1], xb);
+                for (int pl = 0; pl < NPL; ++pl) { w3c[0][pl] = w3n[0][pl]; w3c[1][pl] = w3n[1][pl]; }
+            }
         }
+    }
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
 #pragma unroll

@@ -324,13 +324,57 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(FrontendConsts c, 
 //                           32 KB read (mostly L2) + 98 KB written per frame: the HBM-bound scan SURVEY 8(d) describes.
 constexpr int MC_WAVES = 8;
 
+// The clip as a BUFFER: descriptor in scalar registers (a wave transforms one column, so the clip is wave-uniform) and the
+// sample index as a 32-bit byte offset -- no 64-bit address arithmetic per request.  The zero padding on both sides of the
+// clip stays explicit (index clamped for the request, value selected afterwards, all in 32-bit arithmetic: |index| < 2^29):
+// the hardware's range check cannot do it -- an index in front of the clip wraps to a huge offset that is NOT refused,
+// and the compiler merges neighbouring requests into 8-byte ones that are judged as a whole at the clip's end.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t clip_buffer(const float *base, int len) {
+    const unsigned long long xb = (unsigned long long)base;
+    const unsigned long long xuni = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(xb >> 32)) << 32) |
+                                    (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xb);
+    return __builtin_amdgcn_make_buffer_rsrc((void *)xuni, 0, __builtin_amdgcn_readfirstlane(len * 4), 0x00020000);
+}
+
+// One wave, one STFT column at sample position p of a clip (radix-4 / LDS-staged FFT): samples with the pre-emphasis applied on
+// the fly -> mel[bb] for band lane + 64 bb.  raw0: the column is a window's column 0, whose very first sample is not pre-emphasised
+// (misc.py:17).  A function of (clip samples, p, raw0) alone: whichever kernel, batch or neighbour computes it, the bits are the same.
+template <int WIN>
+__device__ __forceinline__ void column_mel_r4(const __amdgpu_buffer_rsrc_t xrs, int len, int64_t p, bool raw0, float2 *buf, const float2 *sTw,
+                                              const float *sHamm, const int *sBin0, const float (*sW8)[128], int lane, float (&mel)[2]) {
+    constexpr int M = WIN / 2, NR4 = M / 256;
+    float2 v[NR4][4];
+#pragma unroll
+    for (int b = 0; b < NR4; ++b) {
+        const int j = lane + 64 * b;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 2 * (j + r * (M / 4));                       // even sample of z[j + r M/4]
+            // samples g-1, g, g+1 (indices relative to the clip); pre-emphasis with one rounding per op (misc.py:8-17).  All
+            // requests are unconditional, at clamped indices: a load behind a divergent condition compiles to branch + load +
+            // wait, which serialised the requests of a column into ~10 memory round trips
+            const int g0 = (int)(p + i), last = len - 1;
+#define MC_REQ(idx) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (unsigned)((idx) < 0 ? 0 : ((idx) > last ? last : (idx))) * 4u, 0, 0))
+            const float rm = MC_REQ(g0 - 1), r0 = MC_REQ(g0), r1 = MC_REQ(g0 + 1);
+#undef MC_REQ
+            const float xm = (unsigned)(g0 - 1) < (unsigned)len ? rm : 0.f;
+            const float x0 = (unsigned)g0 < (unsigned)len ? r0 : 0.f;
+            const float x1 = (unsigned)(g0 + 1) < (unsigned)len ? r1 : 0.f;
+            const float y0 = (raw0 && i == 0) ? x0 : __fsub_rn(x0, __fmul_rn(0.65f, xm));
+            const float y1 = __fsub_rn(x1, __fmul_rn(0.65f, x0));
+            v[b][r] = make_float2(sHamm[i] * y0, sHamm[i + 1] * y1);
+        }
+    }
+    fft_real_to_mel<WIN>(v, buf, sTw, sBin0, sW8, lane, mel);
+}
+
 template <int WIN>
 __global__ __launch_bounds__(64 * MC_WAVES) void mel_columns_kernel(FrontendConsts c, const float *__restrict__ pcm,
                                                                     const int64_t *__restrict__ clip_off, const int64_t *__restrict__ clip_len,
                                                                     const int32_t *__restrict__ frame_clip, const int64_t *__restrict__ frame_start,
                                                                     const int32_t *__restrict__ col_src, const int64_t *__restrict__ n_distinct,
                                                                     float *__restrict__ mel_table) {
-    constexpr int HOP = WIN / 8, M = WIN / 2, NR4 = M / 256;
+    constexpr int HOP = WIN / 8, M = WIN / 2;
     __shared__ float2 sFft[MC_WAVES][M];
     __shared__ float2 sTw[WIN];
     __shared__ float sHamm[WIN];
@@ -347,42 +391,11 @@ __global__ __launch_bounds__(64 * MC_WAVES) void mel_columns_kernel(FrontendCons
     for (int64_t u = (int64_t)blockIdx.x * MC_WAVES + wave; u < nd; u += (int64_t)gridDim.x * MC_WAVES) {
         // (frame, window column) of this distinct column -> clip and absolute sample position
         const int row = col_src[u], n = row >> 6, t = row & 63, clip = frame_clip[n];
-        // The clip as a BUFFER: descriptor in scalar registers (a wave transforms one column, so the clip is wave-uniform) and the
-        // sample index as a 32-bit byte offset -- no 64-bit address arithmetic per request.  The zero padding on both sides of the
-        // clip stays explicit (index clamped for the request, value selected afterwards, all in 32-bit arithmetic: |index| < 2^29):
-        // the hardware's range check cannot do it -- an index in front of the clip wraps to a huge offset that is NOT refused,
-        // and the compiler merges neighbouring requests into 8-byte ones that are judged as a whole at the clip's end.
         const int64_t len64 = clip_len[clip], p = frame_start[n] + (int64_t)t * HOP;
         const int len = (int)(len64 > 0x1fffffff ? 0x1fffffff : len64);
-        const unsigned long long xb = (unsigned long long)(pcm + clip_off[clip]);
-        const unsigned long long xuni = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(xb >> 32)) << 32) |
-                                        (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xb);
-        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)xuni, 0, __builtin_amdgcn_readfirstlane(len * 4), 0x00020000);
-        const bool raw0 = t == 0;                 // a window's very first sample is not pre-emphasised (misc.py:17)
-        float2 v[NR4][4];
-#pragma unroll
-        for (int b = 0; b < NR4; ++b) {
-            const int j = lane + 64 * b;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 2 * (j + r * (M / 4));                       // even sample of z[j + r M/4]
-                // samples g-1, g, g+1 (indices relative to the clip); pre-emphasis with one rounding per op (misc.py:8-17).  All
-                // requests are unconditional, at clamped indices: a load behind a divergent condition compiles to branch + load +
-                // wait, which serialised the requests of a column into ~10 memory round trips
-                const int g0 = (int)(p + i), last = len - 1;
-#define MC_REQ(idx) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (unsigned)((idx) < 0 ? 0 : ((idx) > last ? last : (idx))) * 4u, 0, 0))
-                const float rm = MC_REQ(g0 - 1), r0 = MC_REQ(g0), r1 = MC_REQ(g0 + 1);
-#undef MC_REQ
-                const float xm = (unsigned)(g0 - 1) < (unsigned)len ? rm : 0.f;
-                const float x0 = (unsigned)g0 < (unsigned)len ? r0 : 0.f;
-                const float x1 = (unsigned)(g0 + 1) < (unsigned)len ? r1 : 0.f;
-                const float y0 = (raw0 && i == 0) ? x0 : __fsub_rn(x0, __fmul_rn(0.65f, xm));
-                const float y1 = __fsub_rn(x1, __fmul_rn(0.65f, x0));
-                v[b][r] = make_float2(sHamm[i] * y0, sHamm[i + 1] * y1);
-            }
-        }
+        const __amdgpu_buffer_rsrc_t xrs = clip_buffer(pcm + clip_off[clip], len);
         float mel[2];
-        fft_real_to_mel<WIN>(v, buf, sTw, sBin0, sW8, lane, mel);
+        column_mel_r4<WIN>(xrs, len, p, t == 0, buf, sTw, sHamm, sBin0, sW8, lane, mel);
         mel_table[u * 128 + lane] = mel[0];
         mel_table[u * 128 + 64 + lane] = mel[1];
     }
@@ -483,6 +496,48 @@ __device__ __forceinline__ void fft512_r8_to_mel(f32x2 (&v)[8], f32x2 *buf, cons
     WAVE_SYNC()
 }
 
+// One wave, one STFT column of the 16 kHz geometry (WIN = 1024) at sample position p of a clip: see column_mel_r4.
+__device__ __forceinline__ void column_mel_r8(const __amdgpu_buffer_rsrc_t xrs, int len, int64_t p, bool raw0, f32x2 *buf, const float2 *sTw,
+                                              const float *sHamm, const int *sBin0, const float (*sW8)[128], int lane, float (&mel)[2]) {
+    constexpr int WIN = 1024;
+    f32x2 v[8];
+    // A column that lies inside its clip with one sample to spare in front (all but the first / last few of a clip: a wave-uniform
+    // test) needs no clamping and no zero fill: its three samples per element come as ONE request of four dwords (g0 - 1 .. g0 + 2,
+    // dword-aligned; the compiler keeps the three that are used: buffer_load_dwordx3).  NB the whole vector is bit-cast to float4:
+    // __builtin_bit_cast(float, q.y) on an ELEMENT of the integer vector compiles to element 0 with this clang (ROCm 7.2) -- the
+    // first build loaded one dword per element and returned garbage; found by reading the ISA.
+    const bool inside = __builtin_amdgcn_readfirstlane((int)(p >= 1 && p + WIN < (int64_t)len)) != 0;
+    if (inside) {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const unsigned voff = (unsigned)((int)p - 1 + 2 * lane) * 4u;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i = 2 * (lane + 64 * r);
+            const float4 q = __builtin_bit_cast(float4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(xrs, voff + 512u * r, 0, 0));
+            const float xm = q.x, x0 = q.y, x1 = q.z;
+            const float y0 = (raw0 && i == 0) ? x0 : __fsub_rn(x0, __fmul_rn(0.65f, xm));
+            const float y1 = __fsub_rn(x1, __fmul_rn(0.65f, x0));
+            const float2 hw = *reinterpret_cast<const float2 *>(&sHamm[i]);
+            v[r] = f32x2{hw.x * y0, hw.y * y1};
+        }
+    } else
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int i = 2 * (lane + 64 * r);                             // even sample of z[lane + 64 r]
+        const int g0 = (int)(p + i), last = len - 1;
+#define MC_REQ(idx) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (unsigned)((idx) < 0 ? 0 : ((idx) > last ? last : (idx))) * 4u, 0, 0))
+        const float rm = MC_REQ(g0 - 1), r0 = MC_REQ(g0), r1 = MC_REQ(g0 + 1);
+#undef MC_REQ
+        const float xm = (unsigned)(g0 - 1) < (unsigned)len ? rm : 0.f;
+        const float x0 = (unsigned)g0 < (unsigned)len ? r0 : 0.f;
+        const float x1 = (unsigned)(g0 + 1) < (unsigned)len ? r1 : 0.f;
+        const float y0 = (raw0 && i == 0) ? x0 : __fsub_rn(x0, __fmul_rn(0.65f, xm));
+        const float y1 = __fsub_rn(x1, __fmul_rn(0.65f, x0));
+        v[r] = f32x2{sHamm[i] * y0, sHamm[i + 1] * y1};
+    }
+    fft512_r8_to_mel(v, buf, sTw, sBin0, sW8, lane, mel);
+}
+
 __global__ __launch_bounds__(64 * MC_WAVES) void mel_columns_r8_kernel(FrontendConsts c, const float *__restrict__ pcm,
                                                                        const int64_t *__restrict__ clip_off, const int64_t *__restrict__ clip_len,
                                                                        const int32_t *__restrict__ frame_clip, const int64_t *__restrict__ frame_start,
@@ -509,51 +564,11 @@ __global__ __launch_bounds__(64 * MC_WAVES) void mel_columns_r8_kernel(FrontendC
     const int64_t u_end = min(nd, ((int64_t)(blockIdx.x & 7) + 1) * span);
     for (int64_t u = (int64_t)(blockIdx.x & 7) * span + (int64_t)(blockIdx.x >> 3) * MC_WAVES + wave; u < u_end; u += (int64_t)(gridDim.x >> 3) * MC_WAVES) {
         const int row = col_src[u], n = row >> 6, t = row & 63, clip = frame_clip[n];
-        // the clip as a buffer, zero padding explicit: see mel_columns_kernel
         const int64_t len64 = clip_len[clip], p = frame_start[n] + (int64_t)t * HOP;
         const int len = (int)(len64 > 0x1fffffff ? 0x1fffffff : len64);
-        const unsigned long long xb = (unsigned long long)(pcm + clip_off[clip]);
-        const unsigned long long xuni = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(xb >> 32)) << 32) |
-                                        (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xb);
-        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)xuni, 0, __builtin_amdgcn_readfirstlane(len * 4), 0x00020000);
-        const bool raw0 = t == 0;
-        f32x2 v[8];
-        // A column that lies inside its clip with one sample to spare in front (all but the first / last few of a clip: a wave-uniform
-        // test) needs no clamping and no zero fill: its three samples per element come as ONE request of four dwords (g0 - 1 .. g0 + 2,
-        // dword-aligned; the compiler keeps the three that are used: buffer_load_dwordx3).  NB the whole vector is bit-cast to float4:
-        // __builtin_bit_cast(float, q.y) on an ELEMENT of the integer vector compiles to element 0 with this clang (ROCm 7.2) -- the
-        // first build loaded one dword per element and returned garbage; found by reading the ISA.
-        const bool inside = __builtin_amdgcn_readfirstlane((int)(p >= 1 && p + WIN < (int64_t)len)) != 0;
-        if (inside) {
-            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-            const unsigned voff = (unsigned)((int)p - 1 + 2 * lane) * 4u;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int i = 2 * (lane + 64 * r);
-                const float4 q = __builtin_bit_cast(float4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(xrs, voff + 512u * r, 0, 0));
-                const float xm = q.x, x0 = q.y, x1 = q.z;
-                const float y0 = (raw0 && i == 0) ? x0 : __fsub_rn(x0, __fmul_rn(0.65f, xm));
-                const float y1 = __fsub_rn(x1, __fmul_rn(0.65f, x0));
-                const float2 hw = *reinterpret_cast<const float2 *>(&sHamm[i]);
-                v[r] = f32x2{hw.x * y0, hw.y * y1};
-            }
-        } else
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int i = 2 * (lane + 64 * r);                             // even sample of z[lane + 64 r]
-            const int g0 = (int)(p + i), last = len - 1;
-#define MC_REQ(idx) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (unsigned)((idx) < 0 ? 0 : ((idx) > last ? last : (idx))) * 4u, 0, 0))
-            const float rm = MC_REQ(g0 - 1), r0 = MC_REQ(g0), r1 = MC_REQ(g0 + 1);
-#undef MC_REQ
-            const float xm = (unsigned)(g0 - 1) < (unsigned)len ? rm : 0.f;
-            const float x0 = (unsigned)g0 < (unsigned)len ? r0 : 0.f;
-            const float x1 = (unsigned)(g0 + 1) < (unsigned)len ? r1 : 0.f;
-            const float y0 = (raw0 && i == 0) ? x0 : __fsub_rn(x0, __fmul_rn(0.65f, xm));
-            const float y1 = __fsub_rn(x1, __fmul_rn(0.65f, x0));
-            v[r] = f32x2{sHamm[i] * y0, sHamm[i + 1] * y1};
-        }
+        const __amdgpu_buffer_rsrc_t xrs = clip_buffer(pcm + clip_off[clip], len);
         float mel[2];
-        fft512_r8_to_mel(v, buf, sTw, sBin0, sW8, lane, mel);
+        column_mel_r8(xrs, len, p, t == 0, buf, sTw, sHamm, sBin0, sW8, lane, mel);
         mel_table[u * 128 + lane] = mel[0];
         mel_table[u * 128 + 64 + lane] = mel[1];
     }
@@ -630,6 +645,196 @@ __global__ __launch_bounds__(256) void gather_features_kernel(const float4 *__re
 #undef GF_ST
 }
 
+
+// ---------------------------------------------------------------------------- "spectral stream" form (round 5)
+// The two-kernel form above pays for the sharing with a table round trip: every distinct column's 128 mel values are written to HBM
+// (13.7 KB per frame) and read back by up to three frames (17.1 KB per frame past the L2) -- 1.33 x the algorithmic bytes of the stage.
+// Here the table never exists.  Hop-aligned frames of a clip form CHAINS (share.hip: prev[n] = nearest earlier frame of the clip whose
+// start differs by d whole hops, 1 <= d <= 62; at 60 fps every 12th frame, d = 25): along a chain the windows are one STFT column
+// stream, member i covering stream columns k_i .. k_i + 63, k_i = k_(i-1) + d_i.  One workgroup walks a SEGMENT of a chain (the members
+// inside an aligned block of B frame indices): its waves transform the stream's columns in order into an LDS RING of mel rows
+// (ST_RING slots), plus each member's own column 0 (whose first sample is not pre-emphasised, misc.py:17:
+// never shared), and when the members that fit the ring together are complete the whole workgroup applies the delta filters and stores the frame's
+// (T, F, C) rows -- the same instructions, in the same order, on the same mel values as gather_features_kernel: bitwise the two-kernel
+// form (a column's mel is a function of (clip, position) alone, column_mel_r8 / column_mel_r4).  HBM: the PCM once per XCD that needs
+// it + the 98,304 feature bytes per frame.  Cost: a segment of J members transforms 25 J + 39 + J columns instead of 26 J (the 39 of
+// its first window that a predecessor in another segment also holds): B = 144 -> J = 12, + 12.5 %.
+// Any frame table works (the chain structure is read from prev / shift, nothing is assumed about the frame rate): frames that share
+// nothing are segments of one member.
+constexpr int ST_WAVES = 15, ST_THREADS = 64 * ST_WAVES, ST_RING = 128, ST_RAW = 8, ST_BMAX = 256;
+
+template <int WIN>
+__global__ __launch_bounds__(ST_THREADS) void mel_stream_kernel(FrontendConsts c, const float *__restrict__ pcm, const int64_t *__restrict__ clip_off,
+                                                                const int64_t *__restrict__ clip_len, const int32_t *__restrict__ frame_clip,
+                                                                const int64_t *__restrict__ frame_start, const int32_t *__restrict__ prev,
+                                                                const int32_t *__restrict__ shift, int64_t n_frames, int B, int G,
+                                                                float *__restrict__ out) {
+    constexpr int HOP = WIN / 8;
+    constexpr int BUF = WIN == 1024 ? MC8_BUF : WIN / 2;          // float2 per wave
+    __shared__ f32x2 sFft[ST_WAVES][BUF];
+    __shared__ float2 sTw[WIN];
+    __shared__ float sHamm[WIN];
+    __shared__ int sBin0[128];
+    __shared__ float sW8[8][128];
+    __shared__ float sRing[ST_RING][128];     // mel rows of stream columns, slot = k mod ST_RING
+    __shared__ float sRawRow[ST_RAW][128];    // column 0 of member i in slot i mod ST_RAW
+    __shared__ short sNext[ST_BMAX], sShift[ST_BMAX], sMine[ST_BMAX], sMemN[ST_BMAX];      // local frame indices / hop shifts (< 256)
+    __shared__ int sMemK[ST_BMAX];
+    __shared__ unsigned long long sMask[ST_BMAX / 64];
+    __shared__ int sJ, sJob;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // workgroup -> (block of B frames, slot g of G): XCD x (= blockIdx % 8, each with its own L2) takes the blocks b = x (mod 8), all G
+    // slots of a block next to each other in its dispatch order -- the 12 chains of a block read the same stretch of PCM
+    const int64_t wi = blockIdx.x >> 3;
+    const int g = (int)(wi % G);
+    const int64_t b = (wi / G) * 8 + (blockIdx.x & 7), n_base = b * B;
+    if (n_base >= n_frames) return;
+
+    for (int i = tid; i < WIN; i += ST_THREADS) { sTw[i] = c.twiddle[i]; sHamm[i] = c.hamm[i]; }
+    for (int i = tid; i < 128; i += ST_THREADS) sBin0[i] = c.mel_bin0[i];
+    for (int i = tid; i < 1024; i += ST_THREADS) sW8[i >> 7][i & 127] = c.mel_w8[i];
+    // ---- the block's chain structure: heads (no predecessor inside the block) and successor links
+    bool head = false;
+    int pv = -1;
+    if (tid < ST_BMAX) {
+        const int64_t n = n_base + tid;
+        const bool valid = tid < B && n < n_frames;
+        pv = valid ? prev[n] : -1;
+        sShift[tid] = (short)(valid ? shift[n] : 0);
+        sNext[tid] = -1;
+        head = valid && pv < n_base;                         // also pv = -1
+        const unsigned long long m = __ballot(head);
+        if (lane == 0) sMask[wave] = m;
+    }
+    __syncthreads();
+    int n_mine = 0;
+    {
+        int total = 0;
+#pragma unroll
+        for (int w = 0; w < ST_BMAX / 64; ++w) total += __popcll(sMask[w]);
+        n_mine = total > g ? (total - g + G - 1) / G : 0;
+        if (tid < ST_BMAX && tid < B && n_base + tid < n_frames) {
+            if (!head) sNext[pv - n_base] = (short)tid;      // unique: a frame has at most one successor (nearest aligned predecessor)
+            else {
+                int rank = __popcll(sMask[wave] & ((1ull << lane) - 1ull));
+                for (int w = 0; w < wave; ++w) rank += __popcll(sMask[w]);
+                if (rank % G == g) sMine[rank / G] = (short)tid;
+            }
+        }
+    }
+    __syncthreads();
+    if (n_mine == 0) return;
+
+    const float c2[9] = {28.f / 462.f, 7.f / 462.f, -8.f / 462.f, -17.f / 462.f, -20.f / 462.f,
+                         -17.f / 462.f, -8.f / 462.f, 7.f / 462.f, 28.f / 462.f};
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    f32x2 *buf = sFft[wave];
+
+    for (int hi = 0; hi < n_mine; ++hi) {
+        if (tid == 0) {                                      // the segment's members: local frame index and first stream column
+            int i = 0, cur = sMine[hi], k = 0;
+            for (;;) {
+                sMemN[i] = (short)cur; sMemK[i] = k; ++i;
+                const int nx = sNext[cur];
+                if (nx < 0) break;
+                k += sShift[nx];
+                cur = nx;
+            }
+            sJ = i;
+            sJob = 0;
+        }
+        __syncthreads();
+        const int J = sJ;
+        // jobs in stream order: member 0 = its raw column 0 + shared columns 1..63; member i >= 1 = its raw column 0 + the d_i new shared
+        // columns k_(i-1) + 64 .. k_i + 63.  jstart(i) = first job of member i.
+        auto jstart = [&](int i) { return i == 0 ? 0 : 63 + i + sMemK[i - 1]; };
+        const int total = 63 + J + sMemK[J - 1];
+        const int64_t n0 = n_base + sMemN[0];
+        const int clip = frame_clip[n0];
+        const int64_t len64 = clip_len[clip], p0 = frame_start[n0];
+        const int len = (int)(len64 > 0x1fffffff ? 0x1fffffff : len64);
+        const __amdgpu_buffer_rsrc_t xrs = clip_buffer(pcm + clip_off[clip], len);
+        // PHASES: members em..e whose columns fit the ring together (k_e + 64 - k_em <= ST_RING: three at 25 hops apart) are produced
+        // in one go, then the workgroup meets and emits them.  Inside a phase a wave takes the NEXT job from a counter in LDS whenever
+        // it is free -- no barrier, no fixed job-to-wave map: in lock step (one column per wave, then a barrier) the waves of a SIMD all
+        // sat in the same LDS round trip at the same time (4.7 k cycles per column against 2.6 k in mel_columns_r8_kernel), and with a
+        // fixed map the SIMD that hosts one wave more than the others finished last while they idled.
+        int em = 0;
+        while (em < J) {
+            int e = em;
+            while (e + 1 < J && e + 1 - em < ST_RAW && sMemK[e + 1] + 64 - sMemK[em] <= ST_RING) ++e;
+            const int qend = e + 1 < J ? jstart(e + 1) : total;
+            int mi = em;
+            for (;;) {
+                int q = 0;
+                if (lane == 0) q = atomicAdd(&sJob, 1);
+                q = __builtin_amdgcn_readfirstlane(q);                  // wave-uniform; a wave's jobs still come in increasing order
+                if (q >= qend) break;
+                while (mi + 1 < J && jstart(mi + 1) <= q) ++mi;
+                const int o = q - jstart(mi);
+                const bool raw = o == 0;
+                const int k = raw ? sMemK[mi] : (mi == 0 ? o : sMemK[mi - 1] + 63 + o);
+                float mel[2];
+                if constexpr (WIN == 1024) column_mel_r8(xrs, len, p0 + (int64_t)k * HOP, raw, buf, sTw, sHamm, sBin0, sW8, lane, mel);
+                else column_mel_r4<WIN>(xrs, len, p0 + (int64_t)k * HOP, raw, reinterpret_cast<float2 *>(buf), sTw, sHamm, sBin0, sW8, lane, mel);
+                float *dst = raw ? sRawRow[mi & (ST_RAW - 1)] : sRing[k % ST_RING];
+                dst[lane] = mel[0];
+                dst[64 + lane] = mel[1];
+            }
+            __syncthreads();
+            for (int me = em; me <= e; ++me) {
+                // ---- member me complete: Savitzky-Golay deltas + (T,F,C) store, exactly gather_features_kernel's
+                const int64_t frame = n_base + sMemN[me];
+                const int kb = sMemK[me] % ST_RING;
+                const float *raw_row = sRawRow[me & (ST_RAW - 1)];
+                auto rowp = [&](int t) -> const float * {
+                    int sl = kb + t;
+                    sl = sl >= ST_RING ? sl - ST_RING : sl;
+                    return t == 0 ? raw_row : sRing[sl];
+                };
+                const unsigned long long ob = (unsigned long long)(out + frame * (64 * 128 * 3));
+                const unsigned long long ouni = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ob >> 32)) << 32) |
+                                                (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ob);
+                const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)ouni, 0, 64 * 128 * 3 * 4, 0x00020000);
+#define GF_ST(off, a_, b_, c_, d_) __builtin_amdgcn_raw_buffer_store_b128(u32x4{__builtin_bit_cast(unsigned, a_), __builtin_bit_cast(unsigned, b_), __builtin_bit_cast(unsigned, c_), __builtin_bit_cast(unsigned, d_)}, ors, (unsigned)(off), 0, 0)
+                for (int i4 = tid; i4 < 64 * 128 / 4; i4 += ST_THREADS) {
+                    const int t = i4 >> 5, f0 = (i4 & 31) * 4;
+                    const int tc = t < 4 ? 4 : (t > 59 ? 59 : t);
+                    float4 mv4[9];
+#pragma unroll
+                    for (int j = -4; j <= 4; ++j) mv4[j + 4] = *reinterpret_cast<const float4 *>(rowp(tc + j) + f0);
+                    const float4 mt = *reinterpret_cast<const float4 *>(rowp(t) + f0);
+                    const float mq[4] = {mt.x, mt.y, mt.z, mt.w};
+                    float m[4], d1[4], d2[4];
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int j = -4; j <= 4; ++j) {
+                            const float4 v4 = mv4[j + 4];
+                            const float mv = qq == 0 ? v4.x : (qq == 1 ? v4.y : (qq == 2 ? v4.z : v4.w));
+                            s1 += (float)j * (1.0f / 60.0f) * mv;
+                            s2 += c2[j + 4] * mv;
+                        }
+                        m[qq] = mq[qq]; d1[qq] = s1; d2[qq] = s2;
+                    }
+                    GF_ST(i4 * 48, m[0], d1[0], d2[0], m[1]);
+                    GF_ST(i4 * 48 + 16, d1[1], d2[1], m[2], d1[2]);
+                    GF_ST(i4 * 48 + 32, d2[2], m[3], d1[3], d2[3]);
+                }
+#undef GF_ST
+            }
+            em = e + 1;
+            if (em < J) {
+                if (tid == 0) sJob = qend;                   // (every wave left the job loop before the barrier above)
+                __syncthreads();                             // the next phase's columns overwrite rows this emission read
+            }
+        }
+        __syncthreads();                                     // sMem* / sJ are rewritten for the next segment
+    }
+}
+
 }  // namespace
 
 extern thread_local int g_sdfa_mel_fft_radix4;   // api.cpp ("mel_fft_radix4"): 1 = the radix-4 / LDS-staged column FFT of rounds 2-3 at 16 kHz too
@@ -664,6 +869,42 @@ hipError_t sdfa_launch_mel_columns(const FrontendConsts &c, const float *pcm, co
     else if (c.win == 512)
         hipLaunchKernelGGL(mel_columns_kernel<512>, dim3(grid), dim3(64 * MC_WAVES), 0, s, c, pcm, clip_off, clip_len, frame_clip,
                            frame_start, col_src, n_distinct, mel_table);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// The spectral-stream form: one launch behind share_prev_kernel (share.hip).  block = frames per chain-segment block (multiple of 4, <= 256;
+// 0 = the default 144: 12 members per segment at 60 fps -- measured against 96 / 192 / 240, profiles/r05_ab_frontend.txt), slots = workgroups
+// per block (0 = 12: one per chain at 60 fps).
+hipError_t sdfa_launch_mel_stream(const FrontendConsts &c, const float *pcm, const int64_t *clip_off, const int64_t *clip_len,
+                                  const int32_t *frame_clip, const int64_t *frame_start, const int32_t *prev, const int32_t *shift,
+                                  int64_t n_frames, int block, int slots, float *audio_feat, hipStream_t s) {
+    if (n_frames <= 0) return hipSuccess;
+    if (c.nbins_used > 256) return hipErrorInvalidValue;
+    // Frames per block: 144 (12 members per chain segment at 60 fps: measured optimum on the 20,352-frame batch against 96 / 192 / 240,
+    // profiles/r05_ab_frontend.txt) while that still gives every CU two workgroups; below, shorter segments (more redundant columns per
+    // frame, but the call is latency-bound there and idle CUs are worse), not under 48.
+    int B = block;
+    const int G = slots > 0 ? slots : 12;
+    if (B <= 0) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        B = 144;
+        if ((n_frames + B - 1) / B * G < 2 * (int64_t)cus) {
+            const int64_t b = n_frames * G / (2 * (int64_t)cus) / 12 * 12;
+            B = (int)(b < 48 ? 48 : (b > 144 ? 144 : b));
+        }
+    }
+    if (B > ST_BMAX || G > ST_BMAX) return hipErrorInvalidValue;
+    const int64_t nblocks = (n_frames + B - 1) / B, nb8 = (nblocks + 7) / 8 * 8;
+    const dim3 grid((unsigned)(nb8 * G));
+    if (c.win == 1024)
+        hipLaunchKernelGGL(mel_stream_kernel<1024>, grid, dim3(ST_THREADS), 0, s, c, pcm, clip_off, clip_len, frame_clip, frame_start, prev, shift,
+                           n_frames, B, G, audio_feat);
+    else if (c.win == 512)
+        hipLaunchKernelGGL(mel_stream_kernel<512>, grid, dim3(ST_THREADS), 0, s, c, pcm, clip_off, clip_len, frame_clip, frame_start, prev, shift,
+                           n_frames, B, G, audio_feat);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

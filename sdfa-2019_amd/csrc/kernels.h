@@ -54,6 +54,10 @@ struct PcaArgs {
     float *out_extra[SDFA_MAX_DESTS - 1];
     int n_extra;
     int reserve_cus;                 // pca_dgrad_res_kernel: launch (CUs - reserve_cus) workgroups
+    // split-bf16 form of pca_dgrad_res_kernel (terms == 3): both bases as bf16 octets, per triangle block
+    // [plane hi | lo][scale rows 2 ks + h (12) x 192 columns | rotat rows (24) x 96] (api.cpp: pack_pca_bf16); null / other terms = fp32
+    const void *basis_b;
+    int terms;
 };
 hipError_t sdfa_launch_pca_dgrad(const PcaArgs &a, hipStream_t s);
 hipError_t sdfa_launch_pca_dgrad_res(const PcaArgs &a, int *queue, hipStream_t s);   // basis slab resident in LDS, persistent; queue: one int of workspace
@@ -74,6 +78,9 @@ hipError_t sdfa_launch_frontend(const FrontendConsts &c, const float *pcm, const
 hipError_t sdfa_launch_mel_columns(const FrontendConsts &c, const float *pcm, const int64_t *clip_off, const int64_t *clip_len,
                                    const int32_t *frame_clip, const int64_t *frame_start, const int32_t *col_src,
                                    const int64_t *n_distinct, float *mel_table, hipStream_t s);
+hipError_t sdfa_launch_mel_stream(const FrontendConsts &c, const float *pcm, const int64_t *clip_off, const int64_t *clip_len,
+                                  const int32_t *frame_clip, const int64_t *frame_start, const int32_t *prev, const int32_t *shift,
+                                  int64_t n_frames, int block, int slots, float *audio_feat, hipStream_t s);
 hipError_t sdfa_launch_gather_features(const float *mel_table, const int32_t *col_to_u, int64_t n_frames, int64_t Nc, int frame_major,
                                        float *audio_feat, hipStream_t s);   // frame_major: col_to_u is [n][t] (ShareArgs::frame_major)
 
@@ -176,6 +183,7 @@ struct ShareArgs {
     int64_t *counts;             // [2]  out: number of distinct columns, and that rounded up to 256
 };
 hipError_t sdfa_launch_share_map(const ShareArgs &a, hipStream_t s);
+hipError_t sdfa_launch_share_prev(const ShareArgs &a, hipStream_t s);     // prev / shift only (the spectral-stream front end reads the chains from them)
 hipError_t sdfa_launch_expand_cols(const float *Zu, const int32_t *col_to_u, float *Z, int nquads, int64_t Mc, hipStream_t s);
 
 // ---- dgrad -> mesh (mesh.hip) -----------------------------------------------------------------------

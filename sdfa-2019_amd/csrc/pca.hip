@@ -131,6 +131,27 @@ __global__ __launch_bounds__(256, 2) void pca_dgrad_kernel(PcaArgs a) {
 constexpr int PR_KS = 11, PR_KR = 23;            // k-blocks that hold real coefficients (85 -> 88, 180 -> 184 of the padded 96 / 192)
 constexpr int PR_RS = 2 * PR_KS, PR_RR = 2 * PR_KR;   // their k-quad rows
 
+// Split-bf16 form (round 5, SDFA_PREC_BF16X3; BF = true): the same kernel with both contractions on v_mfma_f32_32x32x16_bf16, operands as
+// hi + lo bf16, three products per k-step, smallest first (lo*hi, hi*lo, hi*hi) -- 108 + 108 MFMAs of 32 cycles per tile instead of
+// 264 + 276 of 64.  The basis comes pre-split from the host (api.cpp: pack_pca_bf16) as OCTETS of eight consecutive k per column, the
+// operand form of the instruction: per triangle block [plane hi | lo][scale rows r = 2 ks + h (12) x 192 | rotat rows (24) x 96]; the
+// slab in LDS keeps the rows that hold real coefficients (11 + 23 per plane, 138 KiB) and ONE shared row of zeros for the all-padding
+// k-groups (k = 88..95 and 184..191).  The coefficient quads are split by the lane that loads them (the lane's frame is its A row).
+// Accumulators, means, transposition and stores are the fp32 kernel's: only the products are rounded (16 significand bits).
+typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
+constexpr int PB_SLAB = 2 * (12 * 192 + 24 * 96);      // octets per triangle block in global memory (both planes, padded rows included)
+
+__device__ __forceinline__ void pca_split(const float4 &x0, const float4 &x1, pbf16x8 &hi, pbf16x8 &lo) {
+    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 hb = (__bf16)x[e];
+        hi[e] = hb;
+        lo[e] = (__bf16)(x[e] - (float)hb);
+    }
+}
+
+template <bool BF>
 __global__ __launch_bounds__(256, 1) void pca_dgrad_res_kernel(PcaArgs a, int *queue, int fbu) {      // fbu: frame blocks (of 128 frames) per work unit
     // Only the k-quad rows that hold real coefficients are kept: 85 scale coefficients = rows 0..21 (k-blocks 0..10; k-block 11
     // of the padded K = 96 is all zeros and is skipped -- adding exact zeros changes nothing), 180 rotat coefficients = rows
@@ -138,7 +159,9 @@ __global__ __launch_bounds__(256, 1) void pca_dgrad_res_kernel(PcaArgs a, int *q
     // previous pass's reads.
     extern __shared__ float4 sRes[];                       // [PR_RS][192] scale basis | [PR_RR][96] rotat basis | 4 x 2 x 2 x PCA_ROW floats | queue slot
     float4 *sBs = sRes, *sBr = sRes + PR_RS * 192;
-    float *sOutAll = reinterpret_cast<float *>(sRes + PR_RS * 192 + PR_RR * 96);
+    // BF: [11][192] scale hi | [11][192] scale lo | [23][96] rotat hi | [23][96] rotat lo | [192] zeros  (octets of 16 bytes, like float4)
+    pbf16x8 *sBsH = reinterpret_cast<pbf16x8 *>(sRes), *sBsL = sBsH + 11 * 192, *sBrH = sBsL + 11 * 192, *sBrL = sBrH + 23 * 96, *sZero = sBrL + 23 * 96;
+    float *sOutAll = BF ? reinterpret_cast<float *>(sZero + 192) : reinterpret_cast<float *>(sRes + PR_RS * 192 + PR_RR * 96);
     int *sUnit = reinterpret_cast<int *>(sOutAll + 4 * 4 * PCA_ROW);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -171,6 +194,12 @@ __global__ __launch_bounds__(256, 1) void pca_dgrad_res_kernel(PcaArgs a, int *q
         st_ok[i] = idx < 144;
     }
 
+    if (BF && tid < 192) {
+        pbf16x8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
+        sZero[tid] = z;                                    // (visible to everyone after the first unit's barriers)
+    }
     for (;;) {
         if (tid == 0) *sUnit = atomicAdd(queue, 1);
         __syncthreads();                                   // (also: every wave is done with the previous unit's slab)
@@ -180,7 +209,21 @@ __global__ __launch_bounds__(256, 1) void pca_dgrad_res_kernel(PcaArgs a, int *q
         // the slab: 22 x 192 + 46 x 96 float4 = 135 KiB, HBM/L2 -> LDS by LDS-DMA in 1 KiB pieces (dense rows: a request costs
         // ~40-100 cycles here; through registers, with a division per element, the load took 50 k cycles per unit): scale rows
         // are three pieces, rotat rows one and a half (lanes 0..31 of the second)
-        {
+        if constexpr (BF) {
+            // 11 scale rows x 3 pieces + 23 rotat rows x 1.5 pieces per plane, 1 KiB per piece
+            const pbf16x8 *src = reinterpret_cast<const pbf16x8 *>(a.basis_b) + (int64_t)tb * PB_SLAB + lane;
+            for (int c = wave; c < 2 * 11 * 3; c += 4) {
+                const int pl = c / 33, cc = c - 33 * pl, row = cc / 3, part = cc - 3 * row;
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + pl * (PB_SLAB / 2) + row * 192 + part * 64),
+                                                 (void __attribute__((address_space(3))) *)((pl ? sBsL : sBsH) + row * 192 + part * 64), 16, 0, 0);
+            }
+            for (int c = wave; c < 2 * 23 * 2; c += 4) {
+                const int pl = c / 46, cc = c - 46 * pl, row = cc >> 1, part = cc & 1;
+                if (part == 0 || lane < 32)
+                    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + pl * (PB_SLAB / 2) + 12 * 192 + row * 96 + part * 64),
+                                                     (void __attribute__((address_space(3))) *)((pl ? sBrL : sBrH) + row * 96 + part * 64), 16, 0, 0);
+            }
+        } else {
             const float4 *bs = reinterpret_cast<const float4 *>(a.basis_s) + (int64_t)tb * 192 + lane;
             const float4 *br = reinterpret_cast<const float4 *>(a.basis_r) + (int64_t)tb * 96 + lane;
             for (int c = wave; c < PR_RS * 3; c += 4) {
@@ -211,7 +254,14 @@ __global__ __launch_bounds__(256, 1) void pca_dgrad_res_kernel(PcaArgs a, int *q
         float4 sa[12], ra[12], rb[12];     // 12 quads each: at most two of the three sets are live at a time
 #define PR_LOAD(A, fb, kq0) { const float4 *cp = coef + (int64_t)(kq0) * a.Nc + (fb) * 128 + wave * 32 + l31; _Pragma("unroll") for (int kb = 0; kb < 12; ++kb) A[kb] = cp[(int64_t)(2 * kb + h) * a.Nc]; }
 #define PR_LOAD_S(fb) PR_LOAD(sa, fb, 0)
-        PR_LOAD_S(fb0)
+        // BF: the octet of k-step ks and lane half h is quads 4 ks + 2 h, 4 ks + 2 h + 1 -> slots 2 ks, 2 ks + 1 of sa (scale), ra (rotat
+        // k-steps 0..5) and rb (6..11); requested at the same points of a tile as the fp32 form's (two of the three sets alive at a time)
+#define PB_LOAD(A, fb, kq0)                                                                                     \
+        {                                                                                                       \
+            const float4 *cp = coef + (int64_t)(kq0) * a.Nc + (fb) * 128 + wave * 32 + l31;                     \
+            _Pragma("unroll") for (int q = 0; q < 12; ++q) A[q] = cp[(int64_t)(4 * (q >> 1) + 2 * h + (q & 1)) * a.Nc]; \
+        }
+        if constexpr (BF) PB_LOAD(sa, fb0, 0) else PR_LOAD_S(fb0)
         for (int64_t fb = fb0; fb < fb1; ++fb) {
             const int64_t frame0 = fb * 128 + wave * 32;
             f32x16 accs[1][6], accr[1][3];
@@ -223,6 +273,69 @@ __global__ __launch_bounds__(256, 1) void pca_dgrad_res_kernel(PcaArgs a, int *q
             for (int t = 0; t < 3; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accr[0][t][r] = 0.f;
+            if constexpr (BF) {
+                PB_LOAD(ra, fb, 24)                        // k-steps 0..5 of the rotat part: requested before the scale part
+#define PMFMA(A_, B_, C_) __builtin_amdgcn_mfma_f32_32x32x16_bf16((A_), (B_), (C_), 0, 0, 0)
+                // row r = 2 ks + h of a plane; the last k-step's upper half (k = 88..95 / 184..191) is padding on both sides: a shared
+                // row of zeros for B, and a zero A operand there (the coefficient buffer's padding rows are the caller's)
+#define PB_ROWP(BASE, ROWLEN, ks, LAST) ((ks) == (LAST) ? (h ? sZero : (BASE) + 2 * (ks) * (ROWLEN)) : (BASE) + (2 * (ks) + h) * (ROWLEN))
+#define PB_B(NT, BASEH, BASEL, ROWLEN, LAST, ks, BH, BL)                                                        \
+                {                                                                                               \
+                    const pbf16x8 *ph = PB_ROWP(BASEH, ROWLEN, ks, LAST), *pl_ = PB_ROWP(BASEL, ROWLEN, ks, LAST); \
+                    _Pragma("unroll") for (int t = 0; t < NT; ++t) { BH[t] = ph[32 * t + l31]; BL[t] = pl_[32 * t + l31]; } \
+                }
+#define PB_MM(NT, ACC, Q0, Q1, LASTKS, BH, BL)                                                                  \
+                {                                                                                               \
+                    pbf16x8 ahi, alo;                                                                           \
+                    pca_split(Q0, Q1, ahi, alo);                                                                \
+                    if ((LASTKS) && h) { _Pragma("unroll") for (int e = 0; e < 8; ++e) { ahi[e] = (__bf16)0.f; alo[e] = (__bf16)0.f; } } \
+                    _Pragma("unroll") for (int t = 0; t < NT; ++t) ACC[0][t] = PMFMA(alo, BH[t], ACC[0][t]);    \
+                    _Pragma("unroll") for (int t = 0; t < NT; ++t) ACC[0][t] = PMFMA(ahi, BL[t], ACC[0][t]);    \
+                    _Pragma("unroll") for (int t = 0; t < NT; ++t) ACC[0][t] = PMFMA(ahi, BH[t], ACC[0][t]);    \
+                }
+                // scale part: 6 k-steps of 16 x 6 tiles x 3 products, as two passes of three tiles (B operands one k-step ahead in two
+                // alternating sets: with all six tiles' hi and lo planes in two sets the kernel needs more than 512 registers)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    pbf16x8 bh0[3], bl0[3], bh1[3], bl1[3];
+                    f32x16 (&acch)[1][3] = *reinterpret_cast<f32x16 (*)[1][3]>(&accs[0][3 * half]);
+                    PB_B(3, sBsH + 96 * half, sBsL + 96 * half, 192, 5, 0, bh0, bl0)
+#pragma unroll
+                    for (int ks = 0; ks < 6; ks += 2) {
+                        PB_B(3, sBsH + 96 * half, sBsL + 96 * half, 192, 5, ks + 1, bh1, bl1)
+                        __builtin_amdgcn_sched_barrier(0);
+                        PB_MM(3, acch, sa[2 * ks], sa[2 * ks + 1], false, bh0, bl0)
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (ks + 2 < 6) { PB_B(3, sBsH + 96 * half, sBsL + 96 * half, 192, 5, ks + 2, bh0, bl0) }
+                        __builtin_amdgcn_sched_barrier(0);
+                        PB_MM(3, acch, sa[2 * ks + 2], sa[2 * ks + 3], ks + 1 == 5, bh1, bl1)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                PB_LOAD(rb, fb, 48)                        // k-steps 6..11: land during the first half of the rotat part
+                {   // rotat part: 12 k-steps x 3 tiles x 3 products
+                    pbf16x8 bh0[3], bl0[3], bh1[3], bl1[3];
+                    PB_B(3, sBrH, sBrL, 96, 11, 0, bh0, bl0)
+#pragma unroll
+                    for (int ks = 0; ks < 12; ks += 2) {
+                        if (ks == 6 && fb + 1 < fb1) { PB_LOAD(sa, fb + 1, 0) }      // the next tile's scale part (sa is dead by now)
+                        PB_B(3, sBrH, sBrL, 96, 11, ks + 1, bh1, bl1)
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (ks < 6) { PB_MM(3, accr, ra[2 * ks], ra[2 * ks + 1], false, bh0, bl0) }
+                        else { PB_MM(3, accr, rb[2 * (ks - 6)], rb[2 * (ks - 6) + 1], false, bh0, bl0) }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (ks + 2 < 12) { PB_B(3, sBrH, sBrL, 96, 11, ks + 2, bh0, bl0) }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (ks + 1 < 6) { PB_MM(3, accr, ra[2 * ks + 2], ra[2 * ks + 3], false, bh1, bl1) }
+                        else { PB_MM(3, accr, rb[2 * (ks - 5)], rb[2 * (ks - 5) + 1], ks + 1 == 11, bh1, bl1) }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#undef PB_MM
+#undef PB_B
+#undef PB_ROWP
+#undef PMFMA
+            } else {
             PR_LOAD(ra, fb, 24)                            // first half of the rotat part: lands during the scale part (18 k cycles of MFMAs)
             {   // scale part: 11 k-blocks x 24 MFMAs, B operands one k-block ahead in two alternating sets
                 float4 b0[6], b1[6];
@@ -259,6 +372,7 @@ __global__ __launch_bounds__(256, 1) void pca_dgrad_res_kernel(PcaArgs a, int *q
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #undef PR_BR
+            }
             }
 #ifdef SDFA_PR_NOEPI   /* timing experiment only: how long do the K loops alone take? */
             if (accs[0][0][0] + accr[0][0][0] != 123.456f) continue;
@@ -328,6 +442,7 @@ __global__ __launch_bounds__(256, 1) void pca_dgrad_res_kernel(PcaArgs a, int *q
         }
 #undef PR_LOAD_S
 #undef PR_LOAD
+#undef PB_LOAD
     }
 }
 
@@ -337,8 +452,10 @@ __global__ __launch_bounds__(256, 1) void pca_dgrad_res_kernel(PcaArgs a, int *q
 hipError_t sdfa_launch_pca_dgrad_res(const PcaArgs &a, int *queue, hipStream_t s) {
     const int64_t ntb = (a.cols_r + 95) / 96;
     if (a.Nc % 128 || a.ld_s < ntb * 192 || a.ld_r < ntb * 96 || a.cols_s != 2 * a.cols_r || !queue) return hipErrorInvalidValue;
-    const size_t lds = (PR_RS * 192 + PR_RR * 96) * sizeof(float4) + 4 * 4 * PCA_ROW * sizeof(float) + 16;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pca_dgrad_res_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const bool bf = a.terms == 3 && a.basis_b != nullptr;          // split-bf16 form (SDFA_PREC_BF16X3); every other mode: exact fp32
+    const size_t lds = (bf ? (size_t)(2 * 11 * 192 + 2 * 23 * 96 + 192) * 16 : (size_t)(PR_RS * 192 + PR_RR * 96) * sizeof(float4)) + 4 * 4 * PCA_ROW * sizeof(float) + 16;
+    hipError_t e = hipFuncSetAttribute(bf ? reinterpret_cast<const void *>(pca_dgrad_res_kernel<true>) : reinterpret_cast<const void *>(pca_dgrad_res_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(queue, 0, sizeof(int), s);
     if (e != hipSuccess) return e;
@@ -350,7 +467,8 @@ hipError_t sdfa_launch_pca_dgrad_res(const PcaArgs &a, int *queue, hipStream_t s
     const int fbu = ntb * ((nfb + 15) / 16) >= 4 * cus ? 16 : (ntb * ((nfb + 7) / 8) >= 4 * cus ? 8 : 4);
     const int64_t units = ntb * ((nfb + fbu - 1) / fbu);
     cus = std::max(1, cus - a.reserve_cus);      // CUs left to kernels of other streams (sdfa_model_set_reserved_cus)
-    hipLaunchKernelGGL(pca_dgrad_res_kernel, dim3((unsigned)(units < cus ? units : cus)), dim3(256), lds, s, a, queue, fbu);
+    if (bf) hipLaunchKernelGGL(pca_dgrad_res_kernel<true>, dim3((unsigned)(units < cus ? units : cus)), dim3(256), lds, s, a, queue, fbu);
+    else hipLaunchKernelGGL(pca_dgrad_res_kernel<false>, dim3((unsigned)(units < cus ? units : cus)), dim3(256), lds, s, a, queue, fbu);
     return hipGetLastError();
 }
 

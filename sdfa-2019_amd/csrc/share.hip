@@ -151,6 +151,11 @@ hipError_t sdfa_launch_share_map(const ShareArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
+hipError_t sdfa_launch_share_prev(const ShareArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(share_prev_kernel, dim3((unsigned)((a.Nc + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 hipError_t sdfa_launch_expand_cols(const float *Zu, const int32_t *col_to_u, float *Z, int nquads, int64_t Mc, hipStream_t s) {
     hipLaunchKernelGGL(expand_cols_kernel, dim3((unsigned)((Mc + 255) / 256)), dim3(256), 0, s,
                        reinterpret_cast<const float4 *>(Zu), col_to_u, reinterpret_cast<float4 *>(Z), nquads, Mc);

@@ -1,5 +1,5 @@
 # HBM counters of the spectrogram stage alone (two separate --pmc passes, never combined with tracing): tools/time_frontend.py under
-# rocprofv3, per numbering order.  Usage (GPU box): bash tools/pmc_frontend.sh <tag>
+# rocprofv3, for the spectral-stream form (round 5) and the two-kernel form it replaces.  Usage (GPU box): bash tools/pmc_frontend.sh <tag>
 set -e
 TAG=${1:-fe}
 R=$GRAFT_REPO_ROOT
@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for ORDER in 0 1; do
   for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_${C}_$ORDER -o run -- python3 $R/tools/time_frontend.py 1 frontend_t_major=$ORDER > $OUT/pmc_${C}_$ORDER.log 2>&1
+    rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_${C}_$ORDER -o run -- python3 $R/tools/time_frontend.py 1 frontend_two_kernel=$ORDER > $OUT/pmc_${C}_$ORDER.log 2>&1
     cp $(find $OUT/pmc_${C}_$ORDER -name "*counter_collection.csv" | head -1) $OUT/${C}_order$ORDER.csv
     rm -rf $OUT/pmc_${C}_$ORDER
   done
@@ -21,9 +21,9 @@ for order in (0, 1):
         rows = sorted(csv.DictReader(open("$OUT/%s_order%d.csv" % (c, order))), key=lambda r: int(r["Dispatch_Id"]))
         for r in rows:
             name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
-            if name.startswith(("mel_columns", "gather_features", "share_")):
+            if name.startswith(("mel_columns", "gather_features", "share_", "mel_stream")):
                 tot[name][ci] += float(r["Counter_Value"]); tot[name][2] += 1
-    print("frontend_t_major =", order, "(3 calls of the stage: 20,352 frames each)")
+    print("frontend_two_kernel =", order, "(0 = spectral stream, 1 = share map + mel_columns + gather_features; 3 calls of the stage: 20,352 frames each)")
     s = 0.0
     for k, (f, w, n) in sorted(tot.items()):
         calls = n // 2
