@@ -147,7 +147,7 @@ def cpu_baseline(sr, seconds, eng, state_dict, head):
     # slows down when oversubscribed -- take the fastest of a short scan on a 1 s clip (which also warms the pools)
     probe = synth.make_pcm(99, sr)
     best = None
-    for nt in sorted({min(c, os.cpu_count() or 1) for c in (8, 16, 32, 64, 128)}):
+    for nt in sorted({min(c, os.cpu_count() or 1) for c in (8, 16, 32, 64, 128, 256)}):      # up to every logical CPU the host exposes
         torch.set_num_threads(nt)
         TO.generate_animation(orc, probe, sr, 2, batch=100)
         t0 = time.perf_counter()

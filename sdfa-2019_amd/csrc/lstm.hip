@@ -1727,11 +1727,18 @@ __global__ __launch_bounds__(512, 2) void time_lstm_bf16_kernel(TimeLstmArgs a) 
                 acc[gt][j][4 * g + 0] = v.x; acc[gt][j][4 * g + 1] = v.y; acc[gt][j][4 * g + 2] = v.z; acc[gt][j][4 * g + 3] = v.w;
             }
 
+#if defined(SDFA_STAMPS) && defined(__HIP_DEVICE_COMPILE__)    /* diagnostic build: K loop / cell update + plane split / barrier, as time_lstm_body */
+    unsigned long long bt0 = 0, bt1 = 0, bt2 = 0, bt3 = 0, bv_k = 0, bv_cell = 0, bv_bar = 0;
+#define BSTAMP(t) LSTAMP(t)
+#else
+#define BSTAMP(t)
+#endif
     for (int s = 0; s < 64; ++s) {
         const int t = dir ? 63 - s : s;
         const int tn = dir ? t - 1 : t + 1;
         const int64_t mcol = (int64_t)t * a.Nc + n0 + l31;
         const int cur = s & 1;
+        BSTAMP(bt0)
 
         if (X6 && s > 0) {      // lo, mid, hi plane of each k-step in turn, the next one requested while this one multiplies
 #define T6_W(pl, ks, gt) Wh[((size_t)(pl) * 32 + 2 * (ks) + h) * 1024 + (gt) * 32]
@@ -1812,6 +1819,10 @@ __global__ __launch_bounds__(512, 2) void time_lstm_bf16_kernel(TimeLstmArgs a) 
                 }
             }
         }
+#if defined(SDFA_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]), "v"(acc[0][NT - 1]), "v"(acc[1][NT - 1]), "v"(acc[2][NT - 1]), "v"(acc[3][NT - 1]));   // all MFMAs done
+#endif
+        BSTAMP(bt1)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             float4 hq[4];
@@ -1843,8 +1854,17 @@ __global__ __launch_bounds__(512, 2) void time_lstm_bf16_kernel(TimeLstmArgs a) 
                 }
             }
         }
+        BSTAMP(bt2)
         __syncthreads();   // h_s complete in the other buffer before anyone reads it; this one free for step s+1's writes
+#if defined(SDFA_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+        BSTAMP(bt3)
+        if (s > 0) { bv_k += bt1 - bt0; bv_cell += bt2 - bt1; bv_bar += bt3 - bt2; }
+#endif
     }
+#if defined(SDFA_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+    if (NT == 2 && lane == 0) { atomicAdd(&g_lsub[0], bv_k); atomicAdd(&g_lsub[1], bv_cell); atomicAdd(&g_lsub[2], bv_bar); atomicAdd(&g_lsub[3], 63ull); }
+#endif
+#undef BSTAMP
 #undef TB_GX
 }
 

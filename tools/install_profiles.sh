@@ -16,7 +16,19 @@ cp $T/trace/run_kernel_trace.csv profiles/${R}_kernel_trace.csv
 [ -f $T/bench_8khz.json ] && cp $T/bench_8khz.json profiles/${R}_bench_8khz.json
 [ -f $T/bench_config5.json ] && cp $T/bench_config5.json profiles/${R}_bench_config5_rehearsal.json
 [ -f $T/bench_mesh_stage.json ] && cp $T/bench_mesh_stage.json profiles/${R}_bench_mesh_stage.json
-[ -f gpurun_out/precision_modes.json ] && cp gpurun_out/precision_modes.json profiles/${R}_precision_modes.json
+# precision sweep (tests/test_gpu_precision.py): the fixture table and, from round 5, the wide table (other weight dynamics, the 10 s
+# reference fixture, full size) in ONE file; bench.py reports its worst_case_dgrad
+python3 - <<PY
+import json, os
+out = {}
+if os.path.exists("gpurun_out/precision_modes.json"):
+    out = json.load(open("gpurun_out/precision_modes.json"))
+if os.path.exists("gpurun_out/precision_modes_wide.json"):
+    w = json.load(open("gpurun_out/precision_modes_wide.json"))
+    out.update({"worst_case_dgrad": w["worst_case_dgrad"], "bounds_asserted": w["bounds_asserted"], "cases": w["cases"]})
+if out:
+    json.dump(out, open("profiles/${R}_precision_modes.json", "w"), indent=1)
+PY
 ls -la profiles/${R}_* | head -20
 # round 3: the secondary lines come from tools/collect_extras.sh <tag2>; pass it as the third argument
 if [ -n "$3" ]; then
