@@ -94,11 +94,16 @@ int sdfa_mel_frontend(const float *d_pcm, const int64_t *d_clip_off, const int64
 
 /* The same features through the "spectral gather" form: windows of one clip whose starts differ by whole hops contain
  * the same STFT columns (only window column 0 is special: misc.py:17), so each DISTINCT column is transformed once
- * (26 instead of 64 per frame at 60 fps / hop 8 ms) into a mel table, and every frame is then gathered from its 64
- * table rows (delta filters + (T,F,C) store).  Same arguments as sdfa_mel_frontend plus scratch memory of
- * sdfa_frontend_workspace_bytes(n_frames) bytes.  Results agree with sdfa_mel_frontend to float rounding (a column is
- * transformed alone, as a half-size complex FFT, instead of sharing a complex FFT with its neighbour): a column's features
- * depend on its samples only -- not on the batch it is in -- and are bit-identical in every frame that contains it. */
+ * (26 instead of 64 per frame at 60 fps / hop 8 ms; plus a few re-transformed where a chain of such frames is cut into
+ * segments) and every frame is assembled from its 64 mel rows (delta filters + (T,F,C) store).  Since round 5 the mel rows
+ * live in an LDS ring of the workgroup that walks the chain (the "spectral stream": no mel table in HBM; 100.6 KB of HBM
+ * traffic per frame against 99.4 KB algorithmic); the two-kernel form through a table stays behind the option
+ * "frontend_two_kernel" and gives the same bits.  Same arguments as sdfa_mel_frontend plus scratch memory of
+ * sdfa_frontend_workspace_bytes(n_frames) bytes (sized for the two-kernel form).  Results agree with sdfa_mel_frontend to
+ * float rounding (a column is transformed alone, as a half-size complex FFT, instead of sharing a complex FFT with its
+ * neighbour): a column's features depend on its samples only -- not on the batch it is in, not on the form or segment
+ * geometry that computed it -- and are bit-identical in every frame that contains it.  Any frame table is accepted (the
+ * sharing is read from the table, nothing is assumed about the frame rate). */
 int64_t sdfa_frontend_workspace_bytes(int64_t max_frames);
 int sdfa_mel_frontend_gather(const float *d_pcm, const int64_t *d_clip_off, const int64_t *d_clip_len,
                              int32_t n_clips, const int32_t *d_frame_clip, const int64_t *d_frame_start,
@@ -301,6 +306,9 @@ int sdfa_ensemble_mean(const float *d_a, const float *d_b, int64_t n, float *d_o
  *   "pca_fp32"         1 = SDFA_PREC_BF16X3 keeps the dgrad PCA expansion on the fp32 kernel (NOT bit-identical: the expansion's operand rounding)
  *   "frontend_two_kernel" 1 = sdfa_mel_frontend_gather as share map + mel_columns_kernel + gather_features_kernel through a mel table in
  *                      HBM (rounds 2-4) instead of the spectral stream (mel_stream_kernel: mel rows in an LDS ring, no table); same bits
+ *   "frontend_stream_phases" 1 = the spectral stream's workgroups alternate between transforming a phase's columns and emitting its frames
+ *                      (a barrier pair per phase, all 15 waves do both) instead of 12 producer waves (column transforms, no barrier) + 3
+ *                      consumer waves (delta filters and stores) handing mel rows over through LDS counters; same bits
  *   "frontend_stream_block" / "frontend_stream_slots"  segment geometry of the spectral stream: frames per block (0 = 144, at most 256)
  *                      and workgroups per block (0 = 12); same bits for every value   */
 int sdfa_debug_set_option(const char *name, int value);
@@ -310,6 +318,10 @@ int sdfa_debug_keep_intermediates(sdfa_model *m, int on);   /* un-aliased worksp
 int64_t sdfa_debug_distinct_columns(const sdfa_model *m, int64_t n_frames, const void *d_workspace, void *stream);
 int sdfa_debug_tap(const sdfa_model *m, int what, int64_t n_frames, float *d_dst, const void *d_workspace,
                    void *stream);
+/* Status word of the spectral-stream front end's last call on this front-end workspace (synchronises the stream): the number of bounded
+ * hand-off waits between the waves of a workgroup that expired -- 0 always; anything else means the frames of that call are not to be
+ * trusted.  Only the producer / consumer form (the default) has such waits.  Tests only. */
+int sdfa_debug_frontend_status(const void *d_workspace, void *stream);
 /* Per-stage device timing of the last forward calls made with profiling enabled (HIP events on the
  * caller's stream).  names: "conv1","conv23","freq_lstm","freq_proj","gx0","lstm0","gx1","lstm1",
  * "attn_proj","attn","mlp","pca".  Returns milliseconds or a negative code. */

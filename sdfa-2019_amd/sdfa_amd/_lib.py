@@ -45,6 +45,7 @@ SYMBOLS = {
     "sdfa_model_autotune": (C.c_int, [_p, _i64, _p, _i64, _p]),
     "sdfa_expand_coef": (C.c_int, [_p, _p, _i64, _p, _p, _i64, _p]),
     "sdfa_debug_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "sdfa_debug_frontend_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sdfa_debug_keep_intermediates": (C.c_int, [_p, C.c_int]),
     "sdfa_debug_distinct_columns": (_i64, [_p, _i64, _p, _p]),
     "sdfa_debug_tap": (C.c_int, [_p, C.c_int, _i64, _p, _p, _p]),

@@ -104,8 +104,9 @@ class FrontendOnly:
         return feat, tslists, counts
 
     def mel_frontend_device(self, pcm, clip_off, clip_len, frame_clip, frame_start, sr, out=None, gather=True):
-        """gather=True: the "spectral gather" form (each distinct STFT column transformed once, frames gathered from the
-        mel table; needs scratch memory); gather=False: one FFT per window column (sdfa_mel_frontend)."""
+        """gather=True: the "spectral gather" form (each distinct STFT column transformed once, frames assembled from mel rows
+        in an LDS ring -- the spectral stream of round 5; needs scratch memory); gather=False: one FFT per window column
+        (sdfa_mel_frontend)."""
         F = int(frame_clip.numel())
         if out is None:
             out = torch.empty((F,) + FEAT_SHAPE, dtype=torch.float32, device=self.device)
@@ -123,6 +124,12 @@ class FrontendOnly:
             check(lib.sdfa_mel_frontend(_ptr(pcm), _ptr(clip_off), _ptr(clip_len), int(clip_off.numel()), _ptr(frame_clip),
                                         _ptr(frame_start), F, int(sr), _ptr(out), _stream()))
         return out
+
+
+    def frontend_status(self):
+        """Expired hand-off waits of the spectral-stream front end's last call (0 always; tests only; synchronises)."""
+        ws = getattr(self, "_fe_ws", None)
+        return 0 if ws is None else int(check(lib.sdfa_debug_frontend_status(_ptr(ws), _stream())))
 
 
 class Engine(FrontendOnly):

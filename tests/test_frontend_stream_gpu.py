@@ -29,36 +29,40 @@ def _both(fe, clips, sr, tables=None, **opts):
             _lib.set_option(k, v)
         got, ts, _ = fe.mel_frontend(clips, sr, tables=tables)
     finally:
-        for k in ("frontend_two_kernel", "frontend_stream_block", "frontend_stream_slots"):
+        for k in ("frontend_two_kernel", "frontend_stream_block", "frontend_stream_slots", "frontend_stream_phases"):
             _lib.set_option(k, 0)
     assert ts == ts_ref
+    assert fe.frontend_status() == 0
     return ref, got, counts
 
 
+@pytest.mark.parametrize("phases", [0, 1])
 @pytest.mark.parametrize("sr", [16000, 8000])
-def test_stream_is_bitwise_the_two_kernel_form(fe, sr):
+def test_stream_is_bitwise_the_two_kernel_form(fe, sr, phases):
     clips = [synth.make_pcm(0, 10 * sr), np.zeros(int(0.75 * sr), np.float32), synth.make_pcm(22, int(0.568 * sr)),      # exactly one window
              synth.make_pcm(21, int(1.9 * sr) + 11, "speechlike"), synth.make_pcm(23, int(1.25 * sr), "sweep"), synth.make_pcm(3, 3 * sr)]
-    ref, got, counts = _both(fe, clips, sr)
+    ref, got, counts = _both(fe, clips, sr, frontend_stream_phases=phases)
     assert got.shape == ref.shape and torch.equal(got, ref)
     off = np.r_[0, np.cumsum(counts)]
     assert not bool(got[off[1]:off[2]].any())                      # the all-zero clip stays exactly zero
     assert bool(torch.isfinite(got).all())
 
 
+@pytest.mark.parametrize("phases", [0, 1])
 @pytest.mark.parametrize("block,slots", [(0, 1), (48, 5), (100, 12), (256, 16), (4, 3), (192, 24), (1, 1)])
-def test_segment_geometry_does_not_change_a_bit(fe, block, slots):
+def test_segment_geometry_does_not_change_a_bit(fe, block, slots, phases):
     """Frames per block and workgroups per block only decide which workgroup transforms which stretch of a chain."""
     sr = 16000
     clips = [synth.make_pcm(5, int(4.3 * sr), "speechlike"), synth.make_pcm(6, 2 * sr), synth.make_pcm(7, int(0.9 * sr))]
-    ref, got, _ = _both(fe, clips, sr, frontend_stream_block=block, frontend_stream_slots=slots)
+    ref, got, _ = _both(fe, clips, sr, frontend_stream_block=block, frontend_stream_slots=slots, frontend_stream_phases=phases)
     assert torch.equal(got, ref)
 
 
-def test_headline_batch_is_bitwise(fe):
+@pytest.mark.parametrize("phases", [0, 1])
+def test_headline_batch_is_bitwise(fe, phases):
     sr = 16000
     clips = [synth.make_pcm(c, 10 * sr) for c in range(32)]
-    ref, got, counts = _both(fe, clips, sr)
+    ref, got, counts = _both(fe, clips, sr, frontend_stream_phases=phases)
     assert sum(counts) == 20352 and torch.equal(got, ref)
 
 
@@ -84,6 +88,10 @@ def test_irregular_frame_tables(fe):
         ref, got, _ = _both(fe, [pcm], sr, tables=[(starts, ts)])
         assert torch.equal(got, ref), name
         ref, got, _ = _both(fe, [pcm], sr, tables=[(starts, ts)], frontend_stream_block=64, frontend_stream_slots=7)
+        assert torch.equal(got, ref), name
+        ref, got, _ = _both(fe, [pcm], sr, tables=[(starts, ts)], frontend_stream_phases=1)
+        assert torch.equal(got, ref), name
+        ref, got, _ = _both(fe, [pcm], sr, tables=[(starts, ts)], frontend_stream_block=64, frontend_stream_slots=7, frontend_stream_phases=1)
         assert torch.equal(got, ref), name
     delayed = np.pad(pcm[:-320], [[320, 0]], "constant")
     ref, got, _ = _both(fe, [pcm, delayed], sr, tables=[(starts0, ts0), (starts0, ts0)])
