@@ -636,6 +636,20 @@ def main():
         gather_check = bool(okt.item())
         if not gather_check:
             raise SystemExit(f"rank {rank}: gathered rows differ from the owners' rows (gather mode {Mode.kind})")
+    # front end: timed separately (same stream, HIP events), outside the headline region but RIGHT BEHIND it -- the chip in the state the
+    # steps leave it in (behind the split-bf16 legs, which run at 1.8 GHz, or in a cold process the same kernel reads 5 - 15 % differently)
+    # (one untimed call, then the mean of five back to back: inside a step the stage runs hot behind the previous step's kernels; a single
+    # cold call behind the surface block's other models read 3 - 7 % high)
+    eng.mel_frontend_device(pcm, clip_off, clip_len, frame_clip, frame_start, sr, out=feat, gather=(a.frontend == "gather"))
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(5):
+        eng.mel_frontend_device(pcm, clip_off, clip_len, frame_clip, frame_start, sr, out=feat, gather=(a.frontend == "gather"))
+    ev1.record()
+    torch.cuda.synchronize()
+    fe_ms = ev0.elapsed_time(ev1) / 5
+    stages["frontend"] = fe_ms
+
     n_chunks = (F + a.chunk - 1) // a.chunk
     # ---- optional legs.  The headline (dt, stages) is complete at this point; nothing below may cost it: every leg runs
     # under leg(), which turns an exception into an {"error": ...} entry, puts the engine back into the headline precision and checks
@@ -759,13 +773,6 @@ def main():
             surface = surface_block(sd, a.head, sr, dev)
         except Exception as e:          # never at the price of the headline line
             surface = {"error": repr(e)}
-
-    # front end: timed separately (same stream, HIP events), outside the headline region
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record(); eng.mel_frontend_device(pcm, clip_off, clip_len, frame_clip, frame_start, sr, out=feat, gather=(a.frontend == "gather")); ev1.record()
-    torch.cuda.synchronize()
-    fe_ms = ev0.elapsed_time(ev1)
-    stages["frontend"] = fe_ms
 
     if rank == 0:
         frames_total = F_all * a.steps
