@@ -26,6 +26,7 @@ extern "C" {
 #endif
 
 #define SDFA_ABI_VERSION 4   /* 4: workspace status block (sdfa_workspace_init / _status*, replaces sdfa_debug_time_lstm_timeout), unaligned sdfa_ensemble_mean (round 4);
+                                round 5 only ADDS the tests-only sdfa_debug_frontend_status and library options: no signature changed, the version stays;
                                 3: + sdfa_ensemble_mean, sdfa_model_set_reserved_cus, sdfa_debug_time_lstm_timeout (round 3); 2: + seek, resample, mesh correspondences,
                                 multi-destination regress, expand_coef, autotune (round 2); all earlier entry points unchanged */
 

@@ -101,3 +101,17 @@ def test_launcher_argv_and_self_launch_relay(tmp_path, monkeypatch, capfd):
     with pytest.raises(SystemExit) as e:
         bench.self_launch(a, argv)
     assert e.value.code == 1                                                   # ended "fine" without the line: still an error
+
+
+def test_committed_precision_sweep_is_inside_the_budget_and_reported():
+    """bench.py reports `mixed_precision.max_abs_dgrad_err_vs_cpu_ref` as the WORST case of the committed wide sweep (other weight dynamics,
+    the reference's 10 s fixture, full size: tests/test_gpu_precision.py), not the fixture case: the committed table must exist, cover the
+    modes that claim the 1e-4 budget, and hold it."""
+    bench = _load("bench_for_test4", "bench.py")
+    worst, src = bench.precision_worst_case()
+    assert src is not None and src.startswith("profiles/r")
+    assert {"fp32", "bf16x6", "bf16x3_attention", "bf16x3"} <= set(worst)
+    assert all(0.0 < worst[m] <= 1e-4 for m in worst), worst
+    assert worst["bf16x6"] <= 1e-5 and worst["fp32"] <= 1e-5 and worst["bf16x3"] > worst["bf16x6"]
+    table = json.load(open(os.path.join(ROOT, src)))
+    assert len(table["cases"]) >= 7 and all(m in table["bounds_asserted"] for m in worst)
