@@ -221,8 +221,13 @@ __global__ __launch_bounds__(256, 2) void conv23_kernel(ConvArgs a) {
 // order per output element as the two-kernel path (which stays, for the debug taps): bitwise identical results.
 __global__ __launch_bounds__(256, 2) void conv123_kernel(ConvArgs a) {
     __shared__ float4 sP1[80][32];   // 10 pool1 rows x 32 ci as 80 k-quads
+#if SDFA_CONV_OCC4           /* timing experiment only (wrong results: races): the slice and the constants ALIAS pool1, so four workgroups fit a CU */
+    float (*sIn)[33] = reinterpret_cast<float (*)[33]>(&sP1[40][0]);
+    float (*sPar)[64] = reinterpret_cast<float (*)[64]>(&sP1[70][0]);
+#else
     __shared__ float sIn[68][33];    // input rows k = (f - f_lo) * 3 + c, f_lo = 16 fc - 3; +1 column against bank conflicts
     __shared__ float sPar[6][64];
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
