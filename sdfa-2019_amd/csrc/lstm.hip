@@ -38,6 +38,7 @@ namespace {
 // values as the scalar forms sigmoidf_acc / tanhf_acc of common.h (x * -log2e == -(x * log2e); (|x| * -2) * log2e ==
 // -|x * (2 log2e)|: a scaling by two commutes with rounding).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4n __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x2 rcp2(f32x2 d) { return f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)}; }
 __device__ __forceinline__ f32x2 exp2n(f32x2 y) { return f32x2{__builtin_amdgcn_exp2f(-y.x), __builtin_amdgcn_exp2f(-y.y)}; }   // 2^-y
@@ -250,9 +251,9 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_v2_kernel(FreqLstmArgs a) {
         for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                float4 b = *reinterpret_cast<const float4 *>(&sBias[wave * 128 + gt * 32 + 8 * g + 4 * h]);
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
+                for (int j = 0; j < NJ; ++j) {      // (one read per column tile: see freq_lstm_v3_kernel)
+                    const f32x4n b = *(const volatile f32x4n __attribute__((address_space(3))) *)(&sBias[wave * 128 + gt * 32 + 8 * g + 4 * h]);
                     acc[gt][j][4 * g + 0] = b.x; acc[gt][j][4 * g + 1] = b.y;
                     acc[gt][j][4 * g + 2] = b.z; acc[gt][j][4 * g + 3] = b.w;
                 }
@@ -477,9 +478,11 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_v3_kernel(FreqLstmArgs a) {
         for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                float4 b = *reinterpret_cast<const float4 *>(&sBias[wave * 128 + gt * 32 + 8 * g + 4 * h]);
+                // one LDS read per column tile straight into its accumulator quad (round 5: one read + a v_mov per register of the second
+                // tile cost 64 vector instructions per step -- 0.25 ms of the 114; volatile only so that the two reads are not merged)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
+                    const f32x4n b = *(const volatile f32x4n __attribute__((address_space(3))) *)(&sBias[wave * 128 + gt * 32 + 8 * g + 4 * h]);
                     acc[gt][j][4 * g + 0] = b.x; acc[gt][j][4 * g + 1] = b.y;
                     acc[gt][j][4 * g + 2] = b.z; acc[gt][j][4 * g + 3] = b.w;
                 }
@@ -894,9 +897,9 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_bf16p_v3_kernel(FreqLstmArgs
         for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                float4 b = *reinterpret_cast<const float4 *>(&sBias[wave * 128 + gt * 32 + 8 * g + 4 * h]);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < 2; ++j) {       // (one read per column tile: see freq_lstm_v3_kernel)
+                    const f32x4n b = *(const volatile f32x4n __attribute__((address_space(3))) *)(&sBias[wave * 128 + gt * 32 + 8 * g + 4 * h]);
                     acc[gt][j][4 * g + 0] = b.x; acc[gt][j][4 * g + 1] = b.y;
                     acc[gt][j][4 * g + 2] = b.z; acc[gt][j][4 * g + 3] = b.w;
                 }
