@@ -33,7 +33,7 @@ ls -la profiles/${R}_* | head -20
 # round 3: the secondary lines come from tools/collect_extras.sh <tag2>; pass it as the third argument
 if [ -n "$3" ]; then
   X=gpurun_out/$3
-  for f in bench_steps20 bench_8khz bench_mesh_stage bench_1x2s bench_1x10s rehearsal_nccl_w1_dgrad rehearsal_nccl_w1_expand rehearsal_nccl_w1_plain rehearsal_nccl_w1_dgrad_reserve16; do
+  for f in bench_final bench_steps20 bench_8khz bench_mesh_stage bench_1x2s bench_1x10s rehearsal_nccl_w1_dgrad rehearsal_nccl_w1_expand rehearsal_nccl_w1_plain rehearsal_nccl_w1_dgrad_reserve16; do
     [ -f $X/$f.json ] && cp $X/$f.json profiles/${R}_$f.json
   done
   [ -f $X/bench_config5.json ] && cp $X/bench_config5.json profiles/${R}_bench_config5_rehearsal.json
