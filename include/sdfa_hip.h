@@ -310,6 +310,8 @@ int sdfa_ensemble_mean(const float *d_a, const float *d_b, int64_t n, float *d_o
  *   "frontend_stream_phases" 1 = the spectral stream's workgroups alternate between transforming a phase's columns and emitting its frames
  *                      (a barrier pair per phase, all 15 waves do both) instead of 12 producer waves (column transforms, no barrier) + 3
  *                      consumer waves (delta filters and stores) handing mel rows over through LDS counters; same bits
+ *   "frontend_stream_spin_max" n > 0 = the producer / consumer hand-off waits give up after n polls (default 4 M: never); 1 makes them
+ *                      expire at once, which exercises the repair pass (sdfa_debug_frontend_status); same bits
  *   "frontend_stream_block" / "frontend_stream_slots"  segment geometry of the spectral stream: frames per block (0 = 144, at most 256)
  *                      and workgroups per block (0 = 12); same bits for every value   */
 int sdfa_debug_set_option(const char *name, int value);
@@ -320,8 +322,10 @@ int64_t sdfa_debug_distinct_columns(const sdfa_model *m, int64_t n_frames, const
 int sdfa_debug_tap(const sdfa_model *m, int what, int64_t n_frames, float *d_dst, const void *d_workspace,
                    void *stream);
 /* Status word of the spectral-stream front end's last call on this front-end workspace (synchronises the stream): the number of bounded
- * hand-off waits between the waves of a workgroup that expired -- 0 always; anything else means the frames of that call are not to be
- * trusted.  Only the producer / consumer form (the default) has such waits.  Tests only. */
+ * hand-off waits between the waves of a workgroup that expired -- 0 always, unless the hand-off logic is wrong.  Every launch of that
+ * form is followed, in stream order, by a repair pass that exits at once when the word is 0 and otherwise does the call again in the
+ * barrier form ("frontend_stream_phases"), so the features of the call are right either way (like the time LSTM's repair pass: a
+ * forward call never returns rows of a wait that timed out); the word only counts.  Only the producer / consumer form (the default) has such waits.  Tests only ("frontend_stream_spin_max" forces them). */
 int sdfa_debug_frontend_status(const void *d_workspace, void *stream);
 /* Per-stage device timing of the last forward calls made with profiling enabled (HIP events on the
  * caller's stream).  names: "conv1","conv23","freq_lstm","freq_proj","gx0","lstm0","gx1","lstm1",

@@ -21,6 +21,7 @@ thread_local int g_sdfa_gather_plain_order = 0; // "gather_plain_order" option (
 thread_local int g_sdfa_frontend_two_kernel = 0;    // "frontend_two_kernel": 1 = share map + mel_columns + gather_features (rounds 2-4) instead of the spectral stream
 thread_local int g_sdfa_frontend_stream_block = 0; // "frontend_stream_block" / "frontend_stream_slots": segment geometry of the spectral stream (0 = default)
 thread_local int g_sdfa_frontend_stream_slots = 0;
+thread_local int g_sdfa_frontend_stream_spin_max = 0; // "frontend_stream_spin_max" (tests): bound of the producer / consumer hand-off waits in polls (0 = the kernel's 4 M); 1 makes them expire, the repair pass redoes the call in the barrier form
 thread_local int g_sdfa_frontend_stream_phases = 0; // "frontend_stream_phases": 1 = the stream kernel's workgroups alternate between transforming and emitting (a barrier pair per phase) instead of producer / consumer waves
 thread_local int g_sdfa_frontend_t_major = 0;   // "frontend_t_major" option: the front end's distinct columns numbered time-step-major (rounds 2-3)
 
@@ -454,7 +455,8 @@ FeWs fe_layout(int64_t n_frames) {
 }  // namespace
 
 // The spectral-stream kernel's status word of the LAST sdfa_mel_frontend_gather call on this workspace: bounded hand-off waits that
-// expired (0 always, unless the producer / consumer form's logic is wrong).  Synchronises the stream.  Tests only.
+// expired (0 always, unless the producer / consumer form's logic is wrong) -- the repair pass behind the kernel redid such a call, the features are right
+// either way.  Synchronises the stream.  Tests only.
 int sdfa_debug_frontend_status(const void *d_workspace, void *stream) {
     if (!d_workspace) return fail(SDFA_EINVAL, "frontend_status: null workspace");
     int32_t v = 0;
@@ -509,11 +511,11 @@ int sdfa_mel_frontend_gather(const float *d_pcm, const int64_t *d_clip_off, cons
     if (!g_sdfa_frontend_two_kernel && !g_sdfa_mel_fft_radix4 && !g_sdfa_frontend_t_major) {
         // spectral stream (frontend.hip): the chains are read from prev / shift, the mel rows live in an LDS ring, no table
         HIP_TRY(sdfa_launch_share_prev(sa, s));
-        // sh[8]: the stream kernel's status word (a bounded hand-off wait that expired: never, unless its logic is wrong) -- zeroed per
-        // call, read by sdfa_debug_frontend_status
+        // sh[8]: the stream kernel's status word (bounded hand-off waits that expired -- never, unless its logic is wrong -- and were
+        // repaired by the pass behind the kernel) -- zeroed per call, read by sdfa_debug_frontend_status
         HIP_TRY(hipMemsetAsync(sh + 8, 0, sizeof(int32_t), s));
         HIP_TRY(sdfa_launch_mel_stream(c, d_pcm, d_clip_off, d_clip_len, d_frame_clip, d_frame_start, sa.prev, sa.shift, n_frames,
-                                       g_sdfa_frontend_stream_block, g_sdfa_frontend_stream_slots, g_sdfa_frontend_stream_phases ? 0 : 1, sh + 8, d_audio_feat, s));
+                                       g_sdfa_frontend_stream_block, g_sdfa_frontend_stream_slots, g_sdfa_frontend_stream_phases ? 0 : 1, g_sdfa_frontend_stream_spin_max, sh + 8, d_audio_feat, s));
         return SDFA_OK;
     }
     HIP_TRY(sdfa_launch_share_map(sa, s));
@@ -879,6 +881,10 @@ int sdfa_debug_set_option(const char *name, int value) {
     if (name && !strcmp(name, "share_gx0_off")) { g_sdfa_share_gx0_off = value; return SDFA_OK; }
     if (name && !strcmp(name, "frontend_two_kernel")) { g_sdfa_frontend_two_kernel = value; return SDFA_OK; }
     if (name && !strcmp(name, "frontend_stream_phases")) { g_sdfa_frontend_stream_phases = value; return SDFA_OK; }
+    if (name && !strcmp(name, "frontend_stream_spin_max")) {
+        if (value < 0) return fail(SDFA_EINVAL, "frontend_stream_spin_max: 0 (default) or a positive poll count");
+        g_sdfa_frontend_stream_spin_max = value; return SDFA_OK;
+    }
     if (name && !strcmp(name, "frontend_stream_block")) {
         if (value < 0 || value > 256) return fail(SDFA_EINVAL, "frontend_stream_block: 0 (default) or 1..256 frames");
         g_sdfa_frontend_stream_block = value; return SDFA_OK;

@@ -670,15 +670,16 @@ constexpr int ST_PROD = 12;        // PC form: waves 0..11 transform columns, wa
 // each consumer wave publishes the members it is done with in sEmitW (release); a producer about to overwrite a ring row waits until the last member whose window
 // holds the row's previous column is emitted (need <= the member its own job belongs to, so the smallest blocked job always has its
 // predecessors running: no circular wait); every wait is bounded (ST_SPIN_MAX polls) and a bound that expires raises *status and makes
-// every wave of the workgroup leave -- a wrong frame that the host can see, never a hang.
+// every wave of the workgroup leave -- never a hang; and never a wrong frame either: mel_stream_repair_kernel, launched behind this one,
+// does the call again in the PC = false form (no waits) when *status is not 0 (tests force that with "frontend_stream_spin_max").
 constexpr int ST_SPIN_MAX = 1 << 22;
 
 template <int WIN, bool PC>
-__global__ __launch_bounds__(ST_THREADS) void mel_stream_kernel(FrontendConsts c, const float *__restrict__ pcm, const int64_t *__restrict__ clip_off,
-                                                                const int64_t *__restrict__ clip_len, const int32_t *__restrict__ frame_clip,
-                                                                const int64_t *__restrict__ frame_start, const int32_t *__restrict__ prev,
-                                                                const int32_t *__restrict__ shift, int64_t n_frames, int B, int G,
-                                                                float *__restrict__ out, int *__restrict__ status) {
+__device__ __forceinline__ void mel_stream_body(const FrontendConsts &c, const float *__restrict__ pcm, const int64_t *__restrict__ clip_off,
+                                                const int64_t *__restrict__ clip_len, const int32_t *__restrict__ frame_clip,
+                                                const int64_t *__restrict__ frame_start, const int32_t *__restrict__ prev,
+                                                const int32_t *__restrict__ shift, int64_t n_frames, int B, int G,
+                                                float *__restrict__ out, int *__restrict__ status, int spin_max, unsigned bid) {
     constexpr int HOP = WIN / 8;
     constexpr int BUF = WIN == 1024 ? MC8_BUF : WIN / 2;          // float2 per wave
     constexpr int NFFT = PC ? ST_PROD : ST_WAVES;                 // waves that transform
@@ -700,9 +701,9 @@ __global__ __launch_bounds__(ST_THREADS) void mel_stream_kernel(FrontendConsts c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // workgroup -> (block of B frames, slot g of G): XCD x (= blockIdx % 8, each with its own L2) takes the blocks b = x (mod 8), all G
     // slots of a block next to each other in its dispatch order -- the 12 chains of a block read the same stretch of PCM
-    const int64_t wi = blockIdx.x >> 3;
+    const int64_t wi = bid >> 3;
     const int g = (int)(wi % G);
-    const int64_t b = (wi / G) * 8 + (blockIdx.x & 7), n_base = b * B;
+    const int64_t b = (wi / G) * 8 + (bid & 7), n_base = b * B;
     if (n_base >= n_frames) return;
 
     for (int i = tid; i < WIN; i += ST_THREADS) { sTw[i] = c.twiddle[i]; sHamm[i] = c.hamm[i]; }
@@ -855,7 +856,7 @@ __global__ __launch_bounds__(ST_THREADS) void mel_stream_kernel(FrontendConsts c
                             return m;
                         };
                         while (emitted() < need) {
-                            if (++spin > ST_SPIN_MAX || __hip_atomic_load(&sAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { dead = true; break; }
+                            if (++spin > spin_max || __hip_atomic_load(&sAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { dead = true; break; }
                             __builtin_amdgcn_s_sleep(2);
                         }
                         if (dead) break;
@@ -871,7 +872,7 @@ __global__ __launch_bounds__(ST_THREADS) void mel_stream_kernel(FrontendConsts c
                     const int njobs = (me + 1 < J ? jstart(me + 1) : total) - jstart(me);
                     int spin = 0;
                     while (__hip_atomic_load(&sMemDone[me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < njobs) {
-                        if (++spin > ST_SPIN_MAX || __hip_atomic_load(&sAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { dead = true; break; }
+                        if (++spin > spin_max || __hip_atomic_load(&sAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { dead = true; break; }
                         __builtin_amdgcn_s_sleep(2);
                     }
                     if (dead) break;
@@ -919,6 +920,35 @@ __global__ __launch_bounds__(ST_THREADS) void mel_stream_kernel(FrontendConsts c
     }
 }
 
+template <int WIN, bool PC>
+__global__ __launch_bounds__(ST_THREADS) void mel_stream_kernel(FrontendConsts c, const float *__restrict__ pcm, const int64_t *__restrict__ clip_off,
+                                                                const int64_t *__restrict__ clip_len, const int32_t *__restrict__ frame_clip,
+                                                                const int64_t *__restrict__ frame_start, const int32_t *__restrict__ prev,
+                                                                const int32_t *__restrict__ shift, int64_t n_frames, int B, int G,
+                                                                float *__restrict__ out, int *__restrict__ status, int spin_max) {
+    mel_stream_body<WIN, PC>(c, pcm, clip_off, clip_len, frame_clip, frame_start, prev, shift, n_frames, B, G, out, status, spin_max, blockIdx.x);
+}
+
+// REPAIR PASS, behind every launch of the producer / consumer form, in stream order (the principle of time_lstm_repair_kernel): one load of
+// the status word; a healthy call's workgroups (one per CU) leave at once -- a few microseconds.  If a hand-off wait of that launch
+// expired (never, unless the hand-off logic is wrong; the tests force it) its frames may be incomplete: the whole call is done again
+// in the barrier form, which has no waits that can expire -- the same columns, the same filters, the same bits.  So the features a
+// caller reads are right either way; the status word only counts.  (The repair inside the producer / consumer kernel itself -- redo
+// only the segment -- was built first: it is the same few lines, and its second copy of the transform / emit code made the healthy
+// path 6 % slower, 0.97 -> 1.03 ms.)
+template <int WIN>
+__global__ __launch_bounds__(ST_THREADS) void mel_stream_repair_kernel(FrontendConsts c, const float *__restrict__ pcm, const int64_t *__restrict__ clip_off,
+                                                                       const int64_t *__restrict__ clip_len, const int32_t *__restrict__ frame_clip,
+                                                                       const int64_t *__restrict__ frame_start, const int32_t *__restrict__ prev,
+                                                                       const int32_t *__restrict__ shift, int64_t n_frames, int B, int G,
+                                                                       float *__restrict__ out, const int *__restrict__ gate, unsigned n_wg) {
+    if (__builtin_amdgcn_readfirstlane(*gate) == 0) return;
+    for (unsigned bid = blockIdx.x; bid < n_wg; bid += gridDim.x) {
+        mel_stream_body<WIN, false>(c, pcm, clip_off, clip_len, frame_clip, frame_start, prev, shift, n_frames, B, G, out, nullptr, 0, bid);
+        __syncthreads();                                     // the next segment's set-up rewrites the LDS tables
+    }
+}
+
 }  // namespace
 
 extern thread_local int g_sdfa_mel_fft_radix4;   // api.cpp ("mel_fft_radix4"): 1 = the radix-4 / LDS-staged column FFT of rounds 2-3 at 16 kHz too
@@ -963,7 +993,7 @@ hipError_t sdfa_launch_mel_columns(const FrontendConsts &c, const float *pcm, co
 // per block (0 = 12: one per chain at 60 fps).
 hipError_t sdfa_launch_mel_stream(const FrontendConsts &c, const float *pcm, const int64_t *clip_off, const int64_t *clip_len,
                                   const int32_t *frame_clip, const int64_t *frame_start, const int32_t *prev, const int32_t *shift,
-                                  int64_t n_frames, int block, int slots, int producer_consumer, int *status, float *audio_feat, hipStream_t s) {
+                                  int64_t n_frames, int block, int slots, int producer_consumer, int spin_max, int *status, float *audio_feat, hipStream_t s) {
     if (n_frames <= 0) return hipSuccess;
     if (c.nbins_used > 256) return hipErrorInvalidValue;
     // Frames per block: 144 (12 members per chain segment at 60 fps: measured optimum on the 20,352-frame batch against 96 / 192 / 240,
@@ -984,11 +1014,19 @@ hipError_t sdfa_launch_mel_stream(const FrontendConsts &c, const float *pcm, con
     const int64_t nblocks = (n_frames + B - 1) / B, nb8 = (nblocks + 7) / 8 * 8;
     const dim3 grid((unsigned)(nb8 * G));
 #define ST_LAUNCH(W, P) hipLaunchKernelGGL((mel_stream_kernel<W, P>), grid, dim3(ST_THREADS), 0, s, c, pcm, clip_off, clip_len, frame_clip, frame_start, prev, \
-                                           shift, n_frames, B, G, audio_feat, status)
+                                           shift, n_frames, B, G, audio_feat, status, spin_max > 0 ? spin_max : ST_SPIN_MAX)
     if (c.win == 1024) { if (producer_consumer) ST_LAUNCH(1024, true); else ST_LAUNCH(1024, false); }
     else if (c.win == 512) { if (producer_consumer) ST_LAUNCH(512, true); else ST_LAUNCH(512, false); }
     else return hipErrorInvalidValue;
 #undef ST_LAUNCH
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !producer_consumer || !status) return e;
+    // the repair pass (exits at once unless a hand-off wait of the launch above expired)
+    const unsigned n_wg = grid.x, rgrid = n_wg < 256u ? n_wg : 256u;
+#define ST_REPAIR(W) hipLaunchKernelGGL((mel_stream_repair_kernel<W>), dim3(rgrid), dim3(ST_THREADS), 0, s, c, pcm, clip_off, clip_len, frame_clip, frame_start, \
+                                        prev, shift, n_frames, B, G, audio_feat, status, n_wg)
+    if (c.win == 1024) ST_REPAIR(1024); else ST_REPAIR(512);
+#undef ST_REPAIR
     return hipGetLastError();
 }
 

@@ -80,7 +80,7 @@ hipError_t sdfa_launch_mel_columns(const FrontendConsts &c, const float *pcm, co
                                    const int64_t *n_distinct, float *mel_table, hipStream_t s);
 hipError_t sdfa_launch_mel_stream(const FrontendConsts &c, const float *pcm, const int64_t *clip_off, const int64_t *clip_len,
                                   const int32_t *frame_clip, const int64_t *frame_start, const int32_t *prev, const int32_t *shift,
-                                  int64_t n_frames, int block, int slots, int producer_consumer, int *status, float *audio_feat, hipStream_t s);
+                                  int64_t n_frames, int block, int slots, int producer_consumer, int spin_max, int *status, float *audio_feat, hipStream_t s);
 hipError_t sdfa_launch_gather_features(const float *mel_table, const int32_t *col_to_u, int64_t n_frames, int64_t Nc, int frame_major,
                                        float *audio_feat, hipStream_t s);   // frame_major: col_to_u is [n][t] (ShareArgs::frame_major)
 

@@ -19,7 +19,7 @@ def fe():
     return FrontendOnly()
 
 
-def _both(fe, clips, sr, tables=None, **opts):
+def _both(fe, clips, sr, tables=None, expect_status_zero=True, **opts):
     try:
         _lib.set_option("frontend_two_kernel", 1)
         ref, ts_ref, counts = fe.mel_frontend(clips, sr, tables=tables)
@@ -29,10 +29,11 @@ def _both(fe, clips, sr, tables=None, **opts):
             _lib.set_option(k, v)
         got, ts, _ = fe.mel_frontend(clips, sr, tables=tables)
     finally:
-        for k in ("frontend_two_kernel", "frontend_stream_block", "frontend_stream_slots", "frontend_stream_phases"):
+        for k in ("frontend_two_kernel", "frontend_stream_block", "frontend_stream_slots", "frontend_stream_phases", "frontend_stream_spin_max"):
             _lib.set_option(k, 0)
     assert ts == ts_ref
-    assert fe.frontend_status() == 0
+    if expect_status_zero:
+        assert fe.frontend_status() == 0
     return ref, got, counts
 
 
@@ -95,4 +96,26 @@ def test_irregular_frame_tables(fe):
         assert torch.equal(got, ref), name
     delayed = np.pad(pcm[:-320], [[320, 0]], "constant")
     ref, got, _ = _both(fe, [pcm, delayed], sr, tables=[(starts0, ts0), (starts0, ts0)])
+    assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("sr", [16000, 8000])
+def test_an_expired_hand_off_wait_is_repaired_on_the_device(fe, sr):
+    """The producer / consumer waves wait for each other with a bound.  With the bound at ONE poll nearly every wait expires: the status
+    word counts them, and the repair pass behind the kernel redoes the call in the barrier form, in stream order -- the call's
+    features are still the two-kernel form's, bit for bit (like the time LSTM's repair pass, tests/test_concurrency_gpu.py: the
+    library never returns rows of a wait that timed out).  Regular table, a multi-clip batch with short clips, and an irregular table."""
+    clips = [synth.make_pcm(0, 10 * sr), synth.make_pcm(22, int(0.568 * sr)), synth.make_pcm(21, int(1.9 * sr) + 11, "speechlike"),
+             synth.make_pcm(3, 3 * sr)]
+    ref, got, _ = _both(fe, clips, sr, expect_status_zero=False, frontend_stream_spin_max=1)
+    expired = fe.frontend_status()
+    assert expired > 0, "the forced bound did not expire a single wait: the test does not exercise the repair"
+    assert torch.equal(got, ref)
+    ref, got, _ = _both(fe, clips, sr, expect_status_zero=False, frontend_stream_spin_max=1, frontend_stream_block=64, frontend_stream_slots=7)
+    assert fe.frontend_status() > 0 and torch.equal(got, ref)
+    starts = np.cumsum(np.random.RandomState(5).choice([128, 3 * 128, 7, 25 * 128, 60 * 128], 120)).astype(np.int64) - 9000
+    ref, got, _ = _both(fe, [synth.make_pcm(9, 3 * sr, "speechlike")], sr, tables=[(starts, np.zeros(len(starts), np.int64))],
+                        expect_status_zero=False, frontend_stream_spin_max=1)
+    assert torch.equal(got, ref)
+    ref, got, _ = _both(fe, clips, sr)                            # and with the default bound nothing expires
     assert torch.equal(got, ref)
