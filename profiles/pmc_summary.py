@@ -121,17 +121,18 @@ def main():
         # map + mel_columns_kernel + gather_features_kernel of rounds 2-4.  Whichever form ran is summarised.
         fe = {}
         for k in M:
-            for stem in ("mel_stream", "share_prev", "mel_columns", "gather_features"):
-                if k[0].startswith(stem) and F.get(k) and W.get(k):
+            for stem in ("mel_stream_repair", "mel_stream", "share_prev", "mel_columns", "gather_features"):      # first match: the repair pass is not the stream kernel
+                if k[0].startswith(stem) and F.get(k) is not None and W.get(k) is not None and len(F[k]) and len(W[k]):
                     fe[stem] = {"read_bytes": F[k][-1] * 1024 * FETCH_CORRECTION, "write_bytes": W[k][-1] * 1024, "grid": k[1]}
+                    break
         form = "stream" if "mel_stream" in fe else ("two_kernel" if len([s_ for s_ in ("mel_columns", "gather_features") if s_ in fe]) == 2 else None)
         if form == "stream":
-            fe = {k: v for k, v in fe.items() if k in ("mel_stream", "share_prev")}
+            fe = {k: v for k, v in fe.items() if k in ("mel_stream", "mel_stream_repair", "share_prev")}      # the repair pass is part of the stage (one load per workgroup when healthy)
         elif form == "two_kernel":
             fe = {k: v for k, v in fe.items() if k in ("mel_columns", "gather_features")}
         if form:
             tot = sum(v["read_bytes"] + v["write_bytes"] for v in fe.values())
-            names = "share_prev_kernel + mel_stream_kernel" if form == "stream" else "mel_columns_kernel + gather_features_kernel"
+            names = "share_prev_kernel + mel_stream_kernel + mel_stream_repair_kernel" if form == "stream" else "mel_columns_kernel + gather_features_kernel"
             json.dump({"frames": frames, "form": form, "kernels": fe, "bytes_per_frame": tot / frames, "algorithmic_bytes_per_frame": 4 * 16000 / 60 + 98304,
                        "fetch_correction": FETCH_CORRECTION, "frontend_hip_sha1": file_sha1("frontend.hip"),
                        "source": f"separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes ({os.path.basename(os.path.normpath(d))}), last launch of "
