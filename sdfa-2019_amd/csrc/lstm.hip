@@ -425,8 +425,32 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_v3_kernel(FreqLstmArgs a) {
         acc[3][0] = MFMA(SDFA_OP(f4c(W3, q)), SDFA_OP(f4c(B0, q)), acc[3][0]);                               \
         acc[3][1] = MFMA(SDFA_OP(f4c(W3, q)), SDFA_OP(f4c(B1, q)), acc[3][1]);                               \
     }
+    // the step's very first MFMA group: column tile 1 starts from tile 0's seeds (C = acc[gt][0], D = acc[gt][1]) BEFORE tile 0's own
+    // first product overwrites them in place -- same sums as seeding both (bitwise)
+#define F3_QSEED(W0, W1, W2, W3, B0, B1)                                                                     \
+    {                                                                                                        \
+        acc[0][1] = MFMA(SDFA_OP(f4c(W0, 0)), SDFA_OP(f4c(B1, 0)), acc[0][0]);                               \
+        acc[0][0] = MFMA(SDFA_OP(f4c(W0, 0)), SDFA_OP(f4c(B0, 0)), acc[0][0]);                               \
+        acc[1][1] = MFMA(SDFA_OP(f4c(W1, 0)), SDFA_OP(f4c(B1, 0)), acc[1][0]);                               \
+        acc[1][0] = MFMA(SDFA_OP(f4c(W1, 0)), SDFA_OP(f4c(B0, 0)), acc[1][0]);                               \
+        acc[2][1] = MFMA(SDFA_OP(f4c(W2, 0)), SDFA_OP(f4c(B1, 0)), acc[2][0]);                               \
+        acc[2][0] = MFMA(SDFA_OP(f4c(W2, 0)), SDFA_OP(f4c(B0, 0)), acc[2][0]);                               \
+        acc[3][1] = MFMA(SDFA_OP(f4c(W3, 0)), SDFA_OP(f4c(B1, 0)), acc[3][0]);                               \
+        acc[3][0] = MFMA(SDFA_OP(f4c(W3, 0)), SDFA_OP(f4c(B0, 0)), acc[3][0]);                               \
+    }
     // one k-block on the operand set C* while the set N* is refilled for the next one: weights at scalar offset `so`,
-    // operand rows at `bp` (per-lane pointer to the row pair of the next k-block)
+    // operand rows at `bp` (per-lane pointer to the row pair of the next k-block).  F3_KB_SEED: the step's first k-block
+#define F3_KB_SEED(CW0, CW1, CW2, CW3, CB0, CB1, NW0, NW1, NW2, NW3, NB0, NB1, so, bp)                       \
+    {                                                                                                        \
+        F3_SB() NW0 = F3_W(so, 0); NW1 = F3_W(so, 1); F3_SB()                                                \
+        F3_QSEED(CW0, CW1, CW2, CW3, CB0, CB1)                                                               \
+        F3_SB() NW2 = F3_W(so, 2); NW3 = F3_W(so, 3); F3_SB()                                                \
+        F3_Q(CW0, CW1, CW2, CW3, CB0, CB1, 1)                                                                \
+        F3_SB() NB0 = (bp)[0]; F3_SB()                                                                       \
+        F3_Q(CW0, CW1, CW2, CW3, CB0, CB1, 2)                                                                \
+        F3_SB() NB1 = (bp)[32]; F3_SB()                                                                      \
+        F3_Q(CW0, CW1, CW2, CW3, CB0, CB1, 3)                                                                \
+    }
 #define F3_KB(CW0, CW1, CW2, CW3, CB0, CB1, NW0, NW1, NW2, NW3, NB0, NB1, so, bp)                            \
     {                                                                                                        \
         F3_SB() NW0 = F3_W(so, 0); NW1 = F3_W(so, 1); F3_SB()                                                \
@@ -474,38 +498,46 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_v3_kernel(FreqLstmArgs a) {
         const int cur = s & 1;
         f32x16 acc[4][NJ];
         LSTAMP(t0)
+        // the first k-block's operand rows FIRST (LDS answers a wave's reads in order): the step's first MFMA then waits for these two and
+        // its own four seed quads, the later seeds land under the MFMAs in front of them
+        const float4 *brow = &sXH[cur][h][l31];                 // row pair of k-block kb: brow + kb * 2 * BT
+        ba0 = brow[0]; ba1 = brow[32];
+        F3_SB()
 #pragma unroll
         for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                // one LDS read per column tile straight into its accumulator quad (round 5: one read + a v_mov per register of the second
-                // tile cost 64 vector instructions per step -- 0.25 ms of the 114; volatile only so that the two reads are not merged)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const f32x4n b = *(const volatile f32x4n __attribute__((address_space(3))) *)(&sBias[wave * 128 + gt * 32 + 8 * g + 4 * h]);
-                    acc[gt][j][4 * g + 0] = b.x; acc[gt][j][4 * g + 1] = b.y;
-                    acc[gt][j][4 * g + 2] = b.z; acc[gt][j][4 * g + 3] = b.w;
-                }
+                // Seeds (the bias) go into column tile 0's accumulators ONLY; tile 1's first MFMA of the step takes them from there as its C
+                // operand (F3_QSEED below) -- D != C costs nothing.  History: one read + a v_mov per register of the second tile cost 64
+                // vector instructions per step (0.6 ms of the 114.5); a second read per quad removed those but left 32 reads of 1 KiB
+                // per wave in front of every step's first MFMA, and the CU's LDS moves 4 waves x 34 KiB in ~550 cycles.
+                const float4 b = *reinterpret_cast<const float4 *>(&sBias[wave * 128 + gt * 32 + 8 * g + 4 * h]);
+                acc[gt][0][4 * g + 0] = b.x; acc[gt][0][4 * g + 1] = b.y;
+                acc[gt][0][4 * g + 2] = b.z; acc[gt][0][4 * g + 3] = b.w;
             }
         const int trips = s > 0 ? 3 : 1;       // h_{-1} = 0: the first step contracts x_f only (8 of the 24 k-blocks)
-        const float4 *brow = &sXH[cur][h][l31];                 // row pair of k-block kb: brow + kb * 2 * BT
-        ba0 = brow[0]; ba1 = brow[32];
         LSTAMP(t1)
-#pragma unroll 1
-        for (int t = 0; t < trips; ++t) {
-            const float4 *bt = brow + t * 16 * BT;
-            const float4 *bn = t + 1 < trips ? bt + 16 * BT : brow;      // behind the last trip: k-block 0 again (dropped)
-            const unsigned so = (unsigned)t * (8 * 1024 * 16);
-            const unsigned son = t + 1 < trips ? so + 8 * 1024 * 16 : 0u; // ... whose weights ARE k-block 0 of the next step
-            F3_KB(wa0, wa1, wa2, wa3, ba0, ba1, wb0, wb1, wb2, wb3, bb0, bb1, so + 1 * 1024 * 16, bt + 1 * 2 * BT)
-            F3_KB(wb0, wb1, wb2, wb3, bb0, bb1, wa0, wa1, wa2, wa3, ba0, ba1, so + 2 * 1024 * 16, bt + 2 * 2 * BT)
-            F3_KB(wa0, wa1, wa2, wa3, ba0, ba1, wb0, wb1, wb2, wb3, bb0, bb1, so + 3 * 1024 * 16, bt + 3 * 2 * BT)
-            F3_KB(wb0, wb1, wb2, wb3, bb0, bb1, wa0, wa1, wa2, wa3, ba0, ba1, so + 4 * 1024 * 16, bt + 4 * 2 * BT)
-            F3_KB(wa0, wa1, wa2, wa3, ba0, ba1, wb0, wb1, wb2, wb3, bb0, bb1, so + 5 * 1024 * 16, bt + 5 * 2 * BT)
-            F3_KB(wb0, wb1, wb2, wb3, bb0, bb1, wa0, wa1, wa2, wa3, ba0, ba1, so + 6 * 1024 * 16, bt + 6 * 2 * BT)
-            F3_KB(wa0, wa1, wa2, wa3, ba0, ba1, wb0, wb1, wb2, wb3, bb0, bb1, so + 7 * 1024 * 16, bt + 7 * 2 * BT)
-            F3_KB(wb0, wb1, wb2, wb3, bb0, bb1, wa0, wa1, wa2, wa3, ba0, ba1, son, bn)
+        // a trip = 8 k-blocks.  Trip 0 is written out in front of the loop: its first MFMA group is the seeded one, and as straight-line code
+        // the compiler sees that (a run-time `t == 0` inside the loop made it copy the 128 accumulator registers of tile 1 around the branch)
+#define F3_TRIP(FIRST_KB, t_)                                                                                                     \
+        {                                                                                                                         \
+            const float4 *bt = brow + (t_) * 16 * BT;                                                                             \
+            const float4 *bn = (t_) + 1 < trips ? bt + 16 * BT : brow;      /* behind the last trip: k-block 0 again (dropped) */  \
+            const unsigned so = (unsigned)(t_) * (8 * 1024 * 16);                                                                 \
+            const unsigned son = (t_) + 1 < trips ? so + 8 * 1024 * 16 : 0u; /* ... whose weights ARE k-block 0 of the next step */ \
+            FIRST_KB(wa0, wa1, wa2, wa3, ba0, ba1, wb0, wb1, wb2, wb3, bb0, bb1, so + 1 * 1024 * 16, bt + 1 * 2 * BT)             \
+            F3_KB(wb0, wb1, wb2, wb3, bb0, bb1, wa0, wa1, wa2, wa3, ba0, ba1, so + 2 * 1024 * 16, bt + 2 * 2 * BT)                \
+            F3_KB(wa0, wa1, wa2, wa3, ba0, ba1, wb0, wb1, wb2, wb3, bb0, bb1, so + 3 * 1024 * 16, bt + 3 * 2 * BT)                \
+            F3_KB(wb0, wb1, wb2, wb3, bb0, bb1, wa0, wa1, wa2, wa3, ba0, ba1, so + 4 * 1024 * 16, bt + 4 * 2 * BT)                \
+            F3_KB(wa0, wa1, wa2, wa3, ba0, ba1, wb0, wb1, wb2, wb3, bb0, bb1, so + 5 * 1024 * 16, bt + 5 * 2 * BT)                \
+            F3_KB(wb0, wb1, wb2, wb3, bb0, bb1, wa0, wa1, wa2, wa3, ba0, ba1, so + 6 * 1024 * 16, bt + 6 * 2 * BT)                \
+            F3_KB(wa0, wa1, wa2, wa3, ba0, ba1, wb0, wb1, wb2, wb3, bb0, bb1, so + 7 * 1024 * 16, bt + 7 * 2 * BT)                \
+            F3_KB(wb0, wb1, wb2, wb3, bb0, bb1, wa0, wa1, wa2, wa3, ba0, ba1, son, bn)                                            \
         }
+        F3_TRIP(F3_KB_SEED, 0)
+#pragma unroll 1
+        for (int t = 1; t < trips; ++t) F3_TRIP(F3_KB, t)
+#undef F3_TRIP
         F3_SB()
 #ifdef SDFA_STAMPS
         asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]), "v"(acc[0][1]), "v"(acc[1][1]), "v"(acc[2][1]), "v"(acc[3][1]));   // all MFMAs done
@@ -550,6 +582,8 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_v3_kernel(FreqLstmArgs a) {
 #undef XDMA3
 #undef XDMA3_HALF
 #undef F3_KB_LAST
+#undef F3_KB_SEED
+#undef F3_QSEED
 #undef F3_W
 #undef F3_SB
 #undef F3_Q
@@ -805,10 +839,21 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_bf16p_v3_kernel(FreqLstmArgs
     }
     // one k-step: weights of this k-step at byte offset `so`, of the next at `son`; next k-step's operand rows at `bn` (lane pointer
     // into plane 0); B0C / B0N = this / the next k-step's hi operand plane (ping-pong), b1 / b2 = mid / lo planes (refilled in place)
-#define P6_KS(B0C, B0N, so, son, bn)                                                              \
+    // the step's very first group: column tile 1 starts from tile 0's seeds (C = acc[gt][0], D = acc[gt][1]) before tile 0's own first
+    // product overwrites them in place (freq_lstm_v3_kernel: F3_QSEED) -- only tile 0 is seeded from LDS
+#define P6_GSEED(wset, bset)                                                                      \
+    {                                                                                             \
+        acc[0][1] = MFMA_BF16(wset[0], bset[1], acc[0][0]); acc[0][0] = MFMA_BF16(wset[0], bset[0], acc[0][0]); \
+        acc[1][1] = MFMA_BF16(wset[1], bset[1], acc[1][0]); acc[1][0] = MFMA_BF16(wset[1], bset[0], acc[1][0]); \
+        acc[2][1] = MFMA_BF16(wset[2], bset[1], acc[2][0]); acc[2][0] = MFMA_BF16(wset[2], bset[0], acc[2][0]); \
+        acc[3][1] = MFMA_BF16(wset[3], bset[1], acc[3][0]); acc[3][0] = MFMA_BF16(wset[3], bset[0], acc[3][0]); \
+    }
+#define P6_KS(B0C, B0N, so, son, bn) P6_KS_(P6_G, B0C, B0N, so, son, bn)
+#define P6_KS_SEED(B0C, B0N, so, son, bn) P6_KS_(P6_GSEED, B0C, B0N, so, son, bn)
+#define P6_KS_(G0, B0C, B0N, so, son, bn)                                                         \
     {                                                                                             \
         P6_SB() P6_WSET(wh, (so)) P6_SB()                                                         \
-        P6_G(wl, B0C)                                             /* lo  * hi  */                 \
+        G0(wl, B0C)                                               /* lo  * hi  */                 \
         P6_SB() P6_WSET(wl, 2u * W_PLANE + (son)) P6_SB()                                         \
         P6_G(wm, b1)                                              /* mid * mid */                 \
         P6_G(wm, B0C)                                             /* mid * hi  */                 \
@@ -821,10 +866,12 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_bf16p_v3_kernel(FreqLstmArgs
     }
     // PL 2: products hi*hi, hi*lo, lo*hi (the order of freq_lstm_bf16_kernel<3>); the hi weight plane ping-pongs (requested a whole
     // k-step ahead), the lo plane is refilled behind its group (two groups ahead of its next use)
-#define P3_KS(WHC, WHN, B0C, B0N, so, son, bn)                                                    \
+#define P3_KS(WHC, WHN, B0C, B0N, so, son, bn) P3_KS_(P6_G, WHC, WHN, B0C, B0N, so, son, bn)
+#define P3_KS_SEED(WHC, WHN, B0C, B0N, so, son, bn) P3_KS_(P6_GSEED, WHC, WHN, B0C, B0N, so, son, bn)
+#define P3_KS_(G0, WHC, WHN, B0C, B0N, so, son, bn)                                               \
     {                                                                                             \
         P6_SB() P6_WSET(WHN, (son)) P6_SB()                                                       \
-        P6_G(WHC, B0C)                                            /* hi * hi */                   \
+        G0(WHC, B0C)                                              /* hi * hi */                   \
         P6_SB() B0N[0] = (bn)[0]; B0N[1] = (bn)[32]; P6_SB()                                      \
         P6_G(WHC, b1)                                             /* hi * lo */                   \
         P6_SB() b1[0] = (bn)[ROWS * BT]; b1[1] = (bn)[ROWS * BT + 32]; P6_SB()                    \
@@ -893,42 +940,46 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_bf16p_v3_kernel(FreqLstmArgs
         const int cur = s & 1;
         f32x16 acc[4][2];
         LSTAMP(t0)
-#pragma unroll
-        for (int gt = 0; gt < 4; ++gt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {       // (one read per column tile: see freq_lstm_v3_kernel)
-                    const f32x4n b = *(const volatile f32x4n __attribute__((address_space(3))) *)(&sBias[wave * 128 + gt * 32 + 8 * g + 4 * h]);
-                    acc[gt][j][4 * g + 0] = b.x; acc[gt][j][4 * g + 1] = b.y;
-                    acc[gt][j][4 * g + 2] = b.z; acc[gt][j][4 * g + 3] = b.w;
-                }
-            }
+        // k-step 0's operand planes first, then the seeds (the bias) of column tile 0 only: freq_lstm_v3_kernel has the reasons
         const int trips = s > 0 ? 3 : 1;       // h_{-1} = 0: the first step contracts x_f only (4 of the 12 k-steps)
         const bf16x8 *brow = P6_ROW(cur, 0, h) + l31;            // operand rows of k-step ks: brow + ks * 2 * BT (+ plane * ROWS * BT, + 32 for the second column tile)
         bf16x8 b0a[2], b0b[2], b1[2], b2[2];
         b0a[0] = brow[0]; b0a[1] = brow[32];
         b1[0] = brow[ROWS * BT]; b1[1] = brow[ROWS * BT + 32];
         if constexpr (PL == 3) { b2[0] = brow[2 * ROWS * BT]; b2[1] = brow[2 * ROWS * BT + 32]; }
-        LSTAMP(t1)
-#pragma unroll 1
-        for (int t = 0; t < trips; ++t) {
-            const bf16x8 *bt = brow + t * 4 * 2 * BT;
-            const bf16x8 *bn = t + 1 < trips ? bt + 4 * 2 * BT : brow;       // behind the last trip: k-step 0 again (operands dropped)
-            const unsigned so = (unsigned)t * (4u * W_KS);
-            const unsigned son = t + 1 < trips ? so + 4u * W_KS : 0u;        // ... whose weights ARE k-step 0 of the next step
-            if constexpr (PL == 3) {
-                P6_KS(b0a, b0b, so, so + 1u * W_KS, bt + 1 * 2 * BT)
-                P6_KS(b0b, b0a, so + 1u * W_KS, so + 2u * W_KS, bt + 2 * 2 * BT)
-                P6_KS(b0a, b0b, so + 2u * W_KS, so + 3u * W_KS, bt + 3 * 2 * BT)
-                P6_KS(b0b, b0a, so + 3u * W_KS, son, bn)
-            } else {
-                P3_KS(wh, wm, b0a, b0b, so, so + 1u * W_KS, bt + 1 * 2 * BT)
-                P3_KS(wm, wh, b0b, b0a, so + 1u * W_KS, so + 2u * W_KS, bt + 2 * 2 * BT)
-                P3_KS(wh, wm, b0a, b0b, so + 2u * W_KS, so + 3u * W_KS, bt + 3 * 2 * BT)
-                P3_KS(wm, wh, b0b, b0a, so + 3u * W_KS, son, bn)
+        P6_SB()
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 b = *reinterpret_cast<const float4 *>(&sBias[wave * 128 + gt * 32 + 8 * g + 4 * h]);
+                acc[gt][0][4 * g + 0] = b.x; acc[gt][0][4 * g + 1] = b.y;
+                acc[gt][0][4 * g + 2] = b.z; acc[gt][0][4 * g + 3] = b.w;
             }
+        LSTAMP(t1)
+        // a trip = 4 k-steps; trip 0, with the seeded first group, is written out in front of the loop (straight-line code: exact LDS waits)
+#define P6_TRIP(KS6_FIRST, KS3_FIRST, t_)                                                                                         \
+        {                                                                                                                         \
+            const bf16x8 *bt = brow + (t_) * 4 * 2 * BT;                                                                          \
+            const bf16x8 *bn = (t_) + 1 < trips ? bt + 4 * 2 * BT : brow;       /* behind the last trip: k-step 0 again (operands dropped) */ \
+            const unsigned so = (unsigned)(t_) * (4u * W_KS);                                                                     \
+            const unsigned son = (t_) + 1 < trips ? so + 4u * W_KS : 0u;        /* ... whose weights ARE k-step 0 of the next step */ \
+            if constexpr (PL == 3) {                                                                                              \
+                KS6_FIRST(b0a, b0b, so, so + 1u * W_KS, bt + 1 * 2 * BT)                                                          \
+                P6_KS(b0b, b0a, so + 1u * W_KS, so + 2u * W_KS, bt + 2 * 2 * BT)                                                  \
+                P6_KS(b0a, b0b, so + 2u * W_KS, so + 3u * W_KS, bt + 3 * 2 * BT)                                                  \
+                P6_KS(b0b, b0a, so + 3u * W_KS, son, bn)                                                                          \
+            } else {                                                                                                              \
+                KS3_FIRST(wh, wm, b0a, b0b, so, so + 1u * W_KS, bt + 1 * 2 * BT)                                                  \
+                P3_KS(wm, wh, b0b, b0a, so + 1u * W_KS, so + 2u * W_KS, bt + 2 * 2 * BT)                                          \
+                P3_KS(wh, wm, b0a, b0b, so + 2u * W_KS, so + 3u * W_KS, bt + 3 * 2 * BT)                                          \
+                P3_KS(wm, wh, b0b, b0a, so + 3u * W_KS, son, bn)                                                                  \
+            }                                                                                                                     \
         }
+        P6_TRIP(P6_KS_SEED, P3_KS_SEED, 0)
+#pragma unroll 1
+        for (int t = 1; t < trips; ++t) P6_TRIP(P6_KS, P3_KS, t)
+#undef P6_TRIP
         P6_SB()
 #ifdef SDFA_STAMPS
         asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]), "v"(acc[0][1]), "v"(acc[1][1]), "v"(acc[2][1]), "v"(acc[3][1]));   // all MFMAs done
@@ -970,6 +1021,11 @@ __global__ __launch_bounds__(256, 2) void freq_lstm_bf16p_v3_kernel(FreqLstmArgs
 #undef P6_WSET
 #undef P6_G
 #undef P6_KS
+#undef P6_KS_
+#undef P6_KS_SEED
+#undef P3_KS_
+#undef P3_KS_SEED
+#undef P6_GSEED
 #undef P3_KS
 #undef P6_SPLIT_STORE
 #undef P6_XLOAD
