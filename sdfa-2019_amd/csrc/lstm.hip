@@ -1768,11 +1768,19 @@ __global__ __launch_bounds__(512, 2) void time_lstm_bf16_kernel(TimeLstmArgs a) 
     const bf16x8 *__restrict__ Wl = Wh + 32 * 1024;
     float4 *__restrict__ H = reinterpret_cast<float4 *>(a.H);
 
-    f32x16 c[NT];
+    // cell state: column tile 0 in registers; tile 1 (NT = 2) in the 32 KiB of LDS the h planes leave free, [quad g][thread] -- its 16
+    // registers hold the lo weight plane a k-step ahead instead (the K loop below); a thread only ever touches its own entries
+    constexpr bool C1_LDS = NT == 2 && !X6;
+    float4 *const sC1 = reinterpret_cast<float4 *>(sHb + (size_t)2 * NPL * 32 * BT);
+    f32x16 c[C1_LDS ? 1 : NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < (C1_LDS ? 1 : NT); ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) c[j][r] = 0.f;
+    if (C1_LDS) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) sC1[g * 512 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 
     f32x16 acc[4][NT];
 #define TB_GX(t_, gt, g, j) GX[(int64_t)(dir * 256 + wave * 32 + (gt) * 8 + 2 * (g) + h) * a.Mc + (int64_t)(t_) * a.Nc + n0 + l31 + (j) * 32]
@@ -1785,6 +1793,19 @@ __global__ __launch_bounds__(512, 2) void time_lstm_bf16_kernel(TimeLstmArgs a) 
                 const float4 v = TB_GX(dir ? 63 : 0, gt, g, j);
                 acc[gt][j][4 * g + 0] = v.x; acc[gt][j][4 * g + 1] = v.y; acc[gt][j][4 * g + 2] = v.z; acc[gt][j][4 * g + 3] = v.w;
             }
+
+    // the recurrent weights through a buffer descriptor (one per direction: [plane][32 octet rows][1024 gate rows] of 16 bytes): a request is
+    // descriptor + uniform byte offset (plane, k-step) + one loop-invariant lane offset -- no 64-bit address arithmetic in the K loop
+    typedef unsigned int tb_u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16x8 *>(reinterpret_cast<const bf16x8 *>(a.Wb) + (size_t)dir * BF16_PLANES * 32 * 1024), 0, BF16_PLANES * 32 * 1024 * 16, 0x00020000);
+    const unsigned woff = (unsigned)((h * 1024 + wave * 128 + l31) * 16);
+#define TB_W(pl, ks_, gt) __builtin_bit_cast(bf16x8, (tb_u32x4)__builtin_amdgcn_raw_buffer_load_b128(wrs, woff + (unsigned)(gt) * 512u, (unsigned)(((pl) * 32 + 2 * (ks_)) * 1024 * 16), 0))
+    bf16x8 R[4], S[4];
+    if (!X6) {
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt) { R[gt] = TB_W(0, 0, gt); if (LO) S[gt] = TB_W(1, 0, gt); }
+    }
 
 #if defined(SDFA_STAMPS) && defined(__HIP_DEVICE_COMPILE__)    /* diagnostic build: K loop / cell update + plane split / barrier, as time_lstm_body */
     unsigned long long bt0 = 0, bt1 = 0, bt2 = 0, bt3 = 0, bv_k = 0, bv_cell = 0, bv_bar = 0;
@@ -1843,40 +1864,60 @@ __global__ __launch_bounds__(512, 2) void time_lstm_bf16_kernel(TimeLstmArgs a) 
 #undef T6_W
         }
         if (!X6 && s > 0) {
-            bf16x8 whn[4];
+            // Weight planes a whole k-step ahead, in place (round 5, last): R = hi plane, S = lo plane of the current k-step, four gate
+            // tiles each.  A tile PAIR's registers are refilled with the next k-step's rows right behind the pair's last product, so every
+            // request is 16 - 20 MFMAs (512 - 640 cycles) ahead of its use with 32 weight registers in all; the last k-step requests k-step
+            // 0 again -- the next step's first rows.  The h operands: hi octets ping-pong (BHC / BHN), the lo octet is re-read behind its
+            // last use.  (The loop this replaces had `next = load; ...; cur = next` in source form; the compiler turned that back into a load
+            // at the top of the k-step that uses it -- every k-step began with an exposed L2 round trip: K loop 57 % busy in the stamps.)
+            // Per accumulator the products still arrive as hi*hi, hi*lo, lo*hi: bit-identical to the other forms.
+            bf16x8 bhA[NT], bhB[NT], bl[NT];
 #pragma unroll
-            for (int gt = 0; gt < 4; ++gt) whn[gt] = Wh[h * 1024 + gt * 32];
-#pragma unroll 1
-            for (int ks = 0; ks < 16; ++ks) {
-                bf16x8 wh[4], wl[4], bh[NT], bl[NT];
-#pragma unroll
-                for (int gt = 0; gt < 4; ++gt) {
-                    wh[gt] = whn[gt];
-                    if (LO) wl[gt] = Wl[(2 * ks + h) * 1024 + gt * 32];
-                }
-                const int kn = ks + 1 < 16 ? ks + 1 : 0;      // branch-free: the last request is dropped
-#pragma unroll
-                for (int gt = 0; gt < 4; ++gt) whn[gt] = Wh[(2 * kn + h) * 1024 + gt * 32];
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    bh[j] = SH(cur, 0)[(2 * ks + h) * BT + j * 32 + l31];
-                    if (LO) bl[j] = SH(cur, NPL - 1)[(2 * ks + h) * BT + j * 32 + l31];
-                }
-#pragma unroll
-                for (int gt = 0; gt < 4; ++gt)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[gt][j] = MFMA_BF16(wh[gt], bh[j], acc[gt][j]);
-                if (LO) {
-#pragma unroll
-                    for (int gt = 0; gt < 4; ++gt)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j) acc[gt][j] = MFMA_BF16(wh[gt], bl[j], acc[gt][j]);
-#pragma unroll
-                    for (int gt = 0; gt < 4; ++gt)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j) acc[gt][j] = MFMA_BF16(wl[gt], bh[j], acc[gt][j]);
-                }
+            for (int j = 0; j < NT; ++j) {
+                bhA[j] = SH(cur, 0)[h * BT + j * 32 + l31];
+                if (LO) bl[j] = SH(cur, NPL - 1)[h * BT + j * 32 + l31];
             }
+#define TB_SB() __builtin_amdgcn_sched_barrier(0);
+#define TB_HH(g0, BHC)                                                                                                            \
+            _Pragma("unroll") for (int gt = (g0); gt < (g0) + 2; ++gt)                                                            \
+                _Pragma("unroll") for (int j = 0; j < NT; ++j) acc[gt][j] = MFMA_BF16(R[gt], BHC[j], acc[gt][j]);                 \
+            if (LO) {                                                                                                             \
+                _Pragma("unroll") for (int gt = (g0); gt < (g0) + 2; ++gt)                                                        \
+                    _Pragma("unroll") for (int j = 0; j < NT; ++j) acc[gt][j] = MFMA_BF16(R[gt], bl[j], acc[gt][j]);              \
+            }
+#define TB_LH(g0, BHC)                                                                                                            \
+            _Pragma("unroll") for (int gt = (g0); gt < (g0) + 2; ++gt)                                                            \
+                _Pragma("unroll") for (int j = 0; j < NT; ++j) acc[gt][j] = MFMA_BF16(S[gt], BHC[j], acc[gt][j]);
+#define TB_KSTEP(BHC, BHN, ks_)                                                                                                   \
+            {                                                                                                                     \
+                const int kn_ = (ks_) + 1 < 16 ? (ks_) + 1 : 0;        /* weights: behind the last k-step, k-step 0 of the next step */ \
+                const int kh_ = (ks_) + 1 < 16 ? (ks_) + 1 : 15;       /* h operands: behind the last k-step, the same rows again (dropped) */ \
+                TB_SB()                                                                                                           \
+                TB_HH(0, BHC)                                                                                                     \
+                TB_SB() R[0] = TB_W(0, kn_, 0); R[1] = TB_W(0, kn_, 1); TB_SB()                                                   \
+                TB_HH(2, BHC)                                                                                                     \
+                TB_SB() R[2] = TB_W(0, kn_, 2); R[3] = TB_W(0, kn_, 3);                                                           \
+                _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                                  \
+                    BHN[j] = SH(cur, 0)[(2 * kh_ + h) * BT + j * 32 + l31];                                                       \
+                    if (LO) bl[j] = SH(cur, NPL - 1)[(2 * kh_ + h) * BT + j * 32 + l31];                                          \
+                }                                                                                                                 \
+                TB_SB()                                                                                                           \
+                if (LO) {                                                                                                         \
+                    TB_LH(0, BHC)                                                                                                 \
+                    TB_SB() S[0] = TB_W(1, kn_, 0); S[1] = TB_W(1, kn_, 1); TB_SB()                                               \
+                    TB_LH(2, BHC)                                                                                                 \
+                    TB_SB() S[2] = TB_W(1, kn_, 2); S[3] = TB_W(1, kn_, 3); TB_SB()                                               \
+                }                                                                                                                 \
+            }
+#pragma unroll 1
+            for (int ks = 0; ks < 16; ks += 2) {
+                TB_KSTEP(bhA, bhB, ks)
+                TB_KSTEP(bhB, bhA, ks + 1)
+            }
+#undef TB_KSTEP
+#undef TB_LH
+#undef TB_HH
+#undef TB_SB
         }
 #if defined(SDFA_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
         asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]), "v"(acc[0][NT - 1]), "v"(acc[1][NT - 1]), "v"(acc[2][NT - 1]), "v"(acc[3][NT - 1]));   // all MFMAs done
@@ -1887,7 +1928,15 @@ __global__ __launch_bounds__(512, 2) void time_lstm_bf16_kernel(TimeLstmArgs a) 
             float4 hq[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                lstm_cell_quad(acc[0][j], acc[1][j], acc[2][j], acc[3][j], c[j], g, hq[g]);
+                if (C1_LDS && j == 1) {
+                    f32x16 ct;                                  // only this quad's four entries are read and written
+                    const float4 cq = sC1[g * 512 + tid];
+                    ct[4 * g + 0] = cq.x; ct[4 * g + 1] = cq.y; ct[4 * g + 2] = cq.z; ct[4 * g + 3] = cq.w;
+                    lstm_cell_quad(acc[0][j], acc[1][j], acc[2][j], acc[3][j], ct, g, hq[g]);
+                    sC1[g * 512 + tid] = make_float4(ct[4 * g + 0], ct[4 * g + 1], ct[4 * g + 2], ct[4 * g + 3]);
+                } else {
+                    lstm_cell_quad(acc[0][j], acc[1][j], acc[2][j], acc[3][j], c[C1_LDS ? 0 : j], g, hq[g]);
+                }
                 H[(int64_t)(dir * 64 + 8 * wave + 2 * g + h) * a.Mc + mcol + j * 32] = hq[g];
                 if (s + 1 < 64) {   // this quad's gate registers are free: request the next step's input projection into them
 #pragma unroll
@@ -1925,6 +1974,7 @@ __global__ __launch_bounds__(512, 2) void time_lstm_bf16_kernel(TimeLstmArgs a) 
 #endif
 #undef BSTAMP
 #undef TB_GX
+#undef TB_W
 }
 
 }  // namespace
@@ -2056,7 +2106,8 @@ static hipError_t launch_time(const TimeLstmArgs &a, hipStream_t s) {
 
 template <int NT, int TERMS>
 static hipError_t launch_time_bf16(const TimeLstmArgs &a, hipStream_t s) {
-    const size_t lds = (size_t)2 * (TERMS == 6 ? 3 : (TERMS > 1 ? 2 : 1)) * 32 * 32 * NT * sizeof(bf16x8);   // 128 KiB (NT 2, split) ... 32 KiB; 96 KiB (NT 1, six-product)
+    const size_t lds = (size_t)2 * (TERMS == 6 ? 3 : (TERMS > 1 ? 2 : 1)) * 32 * 32 * NT * sizeof(bf16x8)    // 128 KiB (NT 2, split) ... 32 KiB; 96 KiB (NT 1, six-product)
+                       + (NT == 2 && TERMS != 6 ? 4 * 512 * sizeof(float4) : 0);                                  // + 32 KiB: column tile 1's cell state (160 KiB in all for NT 2, split)
     {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(time_lstm_bf16_kernel<NT, TERMS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
