@@ -1764,8 +1764,6 @@ __global__ __launch_bounds__(512, 2) void time_lstm_bf16_kernel(TimeLstmArgs a) 
 
     const float4 *__restrict__ GX = reinterpret_cast<const float4 *>(a.GX);
     // per direction: [plane hi | lo][32 octets][1024 gate rows]
-    const bf16x8 *__restrict__ Wh = reinterpret_cast<const bf16x8 *>(a.Wb) + (size_t)dir * BF16_PLANES * 32 * 1024 + wave * 128 + l31;
-    const bf16x8 *__restrict__ Wl = Wh + 32 * 1024;
     float4 *__restrict__ H = reinterpret_cast<float4 *>(a.H);
 
     // cell state: column tile 0 in registers; tile 1 (NT = 2) in the 32 KiB of LDS the h planes leave free, [quad g][thread] -- its 16
@@ -1801,10 +1799,13 @@ __global__ __launch_bounds__(512, 2) void time_lstm_bf16_kernel(TimeLstmArgs a) 
         const_cast<bf16x8 *>(reinterpret_cast<const bf16x8 *>(a.Wb) + (size_t)dir * BF16_PLANES * 32 * 1024), 0, BF16_PLANES * 32 * 1024 * 16, 0x00020000);
     const unsigned woff = (unsigned)((h * 1024 + wave * 128 + l31) * 16);
 #define TB_W(pl, ks_, gt) __builtin_bit_cast(bf16x8, (tb_u32x4)__builtin_amdgcn_raw_buffer_load_b128(wrs, woff + (unsigned)(gt) * 512u, (unsigned)(((pl) * 32 + 2 * (ks_)) * 1024 * 16), 0))
-    bf16x8 R[4], S[4];
+    bf16x8 R[4], S[4], H6a[4], H6b[4];        // three-product form: R = hi, S = lo plane; six-product form: H6a / H6b = hi (ping-pong), R = mid, S = lo
     if (!X6) {
 #pragma unroll
         for (int gt = 0; gt < 4; ++gt) { R[gt] = TB_W(0, 0, gt); if (LO) S[gt] = TB_W(1, 0, gt); }
+    } else {
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt) { S[gt] = TB_W(2, 0, gt); R[gt] = TB_W(1, 0, gt); H6a[gt] = TB_W(0, 0, gt); }
     }
 
 #if defined(SDFA_STAMPS) && defined(__HIP_DEVICE_COMPILE__)    /* diagnostic build: K loop / cell update + plane split / barrier, as time_lstm_body */
@@ -1820,48 +1821,41 @@ __global__ __launch_bounds__(512, 2) void time_lstm_bf16_kernel(TimeLstmArgs a) 
         const int cur = s & 1;
         BSTAMP(bt0)
 
-        if (X6 && s > 0) {      // lo, mid, hi plane of each k-step in turn, the next one requested while this one multiplies
-#define T6_W(pl, ks, gt) Wh[((size_t)(pl) * 32 + 2 * (ks) + h) * 1024 + (gt) * 32]
-            bf16x8 wa[4], wb[4];
+        if (X6 && s > 0) {
+            // six products per k-step and accumulator, smallest first: lo*hi, mid*mid, mid*hi, hi*lo, hi*mid, hi*hi (NT = 1: four
+            // accumulators, so a product pass is four independent MFMAs).  The lo (L) and mid (M) weight planes are refilled IN PLACE
+            // behind their last pass -- 20 and 16 MFMAs ahead of their next use; the hi plane, needed last and longest, ping-pongs
+            // (HC / HN: requested a whole k-step ahead); the three h operand planes ping-pong too (BC / BN).  The last k-step requests
+            // k-step 0's rows again: the next step's.  (As in the three-product loop below, the `next = load; ...; cur = next` source
+            // form this replaces was compiled back into loads at the point of use: vmcnt(0) in front of every pass.)
+            bf16x8 bA[3], bB[3];
 #pragma unroll
-            for (int gt = 0; gt < 4; ++gt) wa[gt] = T6_W(2, 0, gt);
-#pragma unroll 1
-            for (int ks = 0; ks < 16; ++ks) {
-                bf16x8 b[3][NT];
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) b[pl][j] = SH(cur, pl)[(2 * ks + h) * BT + j * 32 + l31];
-#pragma unroll
-                for (int gt = 0; gt < 4; ++gt) wb[gt] = T6_W(1, ks, gt);
-#pragma unroll
-                for (int gt = 0; gt < 4; ++gt)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[gt][j] = MFMA_BF16(wa[gt], b[0][j], acc[gt][j]);      // lo * hi
-#pragma unroll
-                for (int gt = 0; gt < 4; ++gt) wa[gt] = T6_W(0, ks, gt);
-#pragma unroll
-                for (int gt = 0; gt < 4; ++gt)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        acc[gt][j] = MFMA_BF16(wb[gt], b[1][j], acc[gt][j]);                              // mid * mid
-                        acc[gt][j] = MFMA_BF16(wb[gt], b[0][j], acc[gt][j]);                              // mid * hi
-                    }
-                const int kn = ks + 1 < 16 ? ks + 1 : 0;
-#pragma unroll
-                for (int gt = 0; gt < 4; ++gt) wb[gt] = T6_W(2, kn, gt);
-#pragma unroll
-                for (int gt = 0; gt < 4; ++gt)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        acc[gt][j] = MFMA_BF16(wa[gt], b[2][j], acc[gt][j]);                              // hi * lo
-                        acc[gt][j] = MFMA_BF16(wa[gt], b[1][j], acc[gt][j]);                              // hi * mid
-                        acc[gt][j] = MFMA_BF16(wa[gt], b[0][j], acc[gt][j]);                              // hi * hi
-                    }
-#pragma unroll
-                for (int gt = 0; gt < 4; ++gt) wa[gt] = wb[gt];
+            for (int pl = 0; pl < 3; ++pl) bA[pl] = SH(cur, pl)[h * BT + l31];
+#define TB_SB() __builtin_amdgcn_sched_barrier(0);
+#define T6_PASS(W, B) _Pragma("unroll") for (int gt = 0; gt < 4; ++gt) acc[gt][0] = MFMA_BF16(W[gt], B, acc[gt][0]);
+#define T6_KSTEP(HC, HN, BC, BN, ks_)                                                                                             \
+            {                                                                                                                     \
+                const int kn_ = (ks_) + 1 < 16 ? (ks_) + 1 : 0, kh_ = (ks_) + 1 < 16 ? (ks_) + 1 : 15;                            \
+                TB_SB() _Pragma("unroll") for (int gt = 0; gt < 4; ++gt) HN[gt] = TB_W(0, kn_, gt); TB_SB()                       \
+                T6_PASS(S, BC[0])                                                          /* lo  * hi  */                        \
+                TB_SB() _Pragma("unroll") for (int gt = 0; gt < 4; ++gt) S[gt] = TB_W(2, kn_, gt); TB_SB()                        \
+                T6_PASS(R, BC[1])                                                          /* mid * mid */                        \
+                T6_PASS(R, BC[0])                                                          /* mid * hi  */                        \
+                TB_SB() _Pragma("unroll") for (int gt = 0; gt < 4; ++gt) R[gt] = TB_W(1, kn_, gt);                                \
+                _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) BN[pl] = SH(cur, pl)[(2 * kh_ + h) * BT + l31];                  \
+                TB_SB()                                                                                                           \
+                T6_PASS(HC, BC[2])                                                         /* hi  * lo  */                        \
+                T6_PASS(HC, BC[1])                                                         /* hi  * mid */                        \
+                T6_PASS(HC, BC[0])                                                         /* hi  * hi  */                        \
             }
-#undef T6_W
+#pragma unroll 1
+            for (int ks = 0; ks < 16; ks += 2) {
+                T6_KSTEP(H6a, H6b, bA, bB, ks)
+                T6_KSTEP(H6b, H6a, bB, bA, ks + 1)
+            }
+#undef T6_KSTEP
+#undef T6_PASS
+#undef TB_SB
         }
         if (!X6 && s > 0) {
             // Weight planes a whole k-step ahead, in place (round 5, last): R = hi plane, S = lo plane of the current k-step, four gate
