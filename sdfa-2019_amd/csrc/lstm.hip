@@ -1671,8 +1671,10 @@ __global__ __launch_bounds__(256) void time_lstm_split16_kernel(TimeLstmArgs a, 
             ba = brow[0];
 #define T16_STEP(WC, BC, WN, BN, Kn)                                                                                \
             {                                                                                                       \
-                _Pragma("unroll") for (int tl = 0; tl < 8; ++tl) WN[tl] = T16_W(Kn, tl);                             \
-                BN = brow[(Kn) * 64];                                                                               \
+                __builtin_amdgcn_sched_barrier(0);      /* the requests stay HERE, a whole half-step ahead of their use (unpinned, both */ \
+                _Pragma("unroll") for (int tl = 0; tl < 8; ++tl) WN[tl] = T16_W(Kn, tl);   /* halves' 16 were issued together, 8 of them */ \
+                BN = brow[(Kn) * 64];                                                    /* right in front of the MFMAs that use them) */ \
+                __builtin_amdgcn_sched_barrier(0);                                                                  \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
                     _Pragma("unroll") for (int tl = 0; tl < 8; ++tl)                                                 \
                         acc[tl >> 1][tl & 1] = MFMA16(SDFA_OP(f4c(WC[tl], j)), SDFA_OP(f4c(BC, j)), acc[tl >> 1][tl & 1]); \
