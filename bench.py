@@ -25,6 +25,8 @@ import time
 
 import numpy as np
 
+T_PROCESS_START = time.perf_counter()        # the wall-clock budget (--budget-s) counts from here: interpreter start, imports included
+
 # dmabuf IPC (the only kind this pool's driver supports) must be selected BEFORE anything initialises HSA: torch.cuda.set_device()
 # below already does, so this cannot wait until the process group is created (VERDICT r2 / ADVICE r2)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -46,6 +48,56 @@ FLOP_ATTENTION_PER_FRAME = 10.2e6                                    # SURVEY 8(
 FRONTEND_BYTES_PER_FRAME = 4 * 16000 / 60 + 64 * 128 * 3 * 4         # new PCM + feature write = 99.4 KB (at 16 kHz; 8 kHz: 98.8 KB)
 PEAK_FP32_MFMA_TFLOPS = 157.3                                        # MI355X_MICROARCH.md chip table
 PEAK_HBM_GBPS = 8000.0
+
+
+class Budget:
+    """Wall-clock budget of one `bench.py` run.  The driver stops the command at a limit it does not tell us (600 s so far); the headline
+    is printed as soon as it exists (`emit`), and every OPTIONAL leg is admitted only while the time it is expected to take still fits --
+    a leg that does not fit is skipped and listed in the line's `legs_skipped`, never started and then lost together with the line.
+    `reserve_s` is kept back for the legs that the bench contract requires (cpu_baseline) so that the optional ones cannot eat it."""
+
+    def __init__(self, total_s, clock=time.perf_counter, t0=None, reserve_s=0.0):
+        self.total, self.clock, self.t0, self.reserve = float(total_s), clock, (clock() if t0 is None else t0), float(reserve_s)
+        self.skipped, self.seconds = [], {}
+
+    def elapsed(self):
+        return self.clock() - self.t0
+
+    def left(self):
+        return self.total - self.elapsed()
+
+    def admit(self, name, estimate_s, required=False):
+        """True when leg `name` (expected to take estimate_s) may start; otherwise it is recorded as skipped with the figures that decided it."""
+        need = float(estimate_s) + (0.0 if required else self.reserve)
+        if self.left() >= need:
+            return True
+        self.skipped.append({"leg": name, "estimate_s": round(float(estimate_s), 1), "left_s": round(self.left(), 1),
+                             "reserved_s": 0.0 if required else round(self.reserve, 1)})
+        return False
+
+    def run(self, name, estimate_s, fn, required=False):
+        """fn() if the leg is admitted (its wall time recorded in `seconds`), else None."""
+        if not self.admit(name, estimate_s, required):
+            return None
+        t = self.clock()
+        try:
+            return fn()
+        finally:
+            self.seconds[name] = round(self.clock() - t, 2)
+
+    def release_reserve(self):
+        self.reserve = 0.0
+
+    def report(self):
+        return {"budget_s": self.total if self.total != float("inf") else None, "elapsed_s": round(self.elapsed(), 1), "legs_s": dict(self.seconds)}
+
+
+def emit(res, final):
+    """One JSON line on stdout, flushed at once.  The headline goes out TWICE: right after the timed steps (`"partial": true`, the optional
+    blocks and cpu_baseline still null) and again, complete, as the LAST line -- a run that is stopped in between has still said its number."""
+    d = dict(res)
+    d["partial"] = not final
+    print(json.dumps(d), flush=True)
 
 
 def parse(argv=None):
@@ -90,6 +142,11 @@ def parse(argv=None):
                     help="side = run everything on a freshly created HIP stream instead of the default stream (HIP maps streams onto a "
                          "few hardware queues; two streams on one queue serialise -- see DESIGN.md section 5)")
     ap.add_argument("--cpu-sample-seconds", type=float, default=10.0)
+    ap.add_argument("--budget-s", type=float, default=240.0,
+                    help="wall-clock budget of the whole command, counted from interpreter start: an optional leg (column sharing, the configs[3] "
+                         "modes, the PCIe twin, the surface block) that is not expected to fit is skipped and listed in `legs_skipped`; the "
+                         "headline line is printed right after the timed steps and again, complete, as the last line")
+    ap.add_argument("--cpu-baseline-cap-s", type=float, default=25.0, help="upper bound on the whole cpu_baseline leg (thread scan + sample)")
     ap.add_argument("--all-legs", action="store_true",
                     help="at N > 1 also run the optional legs (column sharing, the configs[3] precision modes); by default a multi-GPU "
                          "run measures the headline only -- nothing optional may stand between an 8-GPU slot and its line")
@@ -119,46 +176,90 @@ def self_launch(a, argv):
     cmd = launcher_argv(a.gpus, argv, port)
     env = dict(os.environ, SDFA_BENCH_LAUNCHER="self")
     print(f"[bench] --gpus {a.gpus} without a launcher: starting {' '.join(cmd[:10])} ...", file=sys.stderr, flush=True)
-    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    import signal
+    # the ranks get a session (process group) of their own: whatever ends this parent -- the driver's SIGTERM at its limit, Ctrl-C, an
+    # exception in the relay below -- the whole group is stopped on the way out, so no orphan rank keeps a card busy
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1, start_new_session=True)
+
+    def stop_ranks(grace=5.0):
+        if child.poll() is not None:
+            return
+        for sig, wait in ((signal.SIGTERM, grace), (signal.SIGKILL, 2.0)):
+            try:
+                os.killpg(child.pid, sig)                       # child.pid IS the group id (start_new_session)
+            except (ProcessLookupError, PermissionError):
+                pass
+            try:
+                child.wait(timeout=wait)
+                return
+            except subprocess.TimeoutExpired:
+                continue
+
+    def on_signal(signum, frame):
+        stop_ranks()
+        raise SystemExit(128 + signum)
+    previous = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
     seen = False
-    for line in child.stdout:                                   # rank 0's line (and anything else the ranks print) as it arrives
-        sys.stdout.write(line)
-        sys.stdout.flush()
-        if line.startswith('{"metric"'):
-            seen = True
-    rc = child.wait()
+    try:
+        for line in child.stdout:                               # rank 0's lines (and anything else the ranks print) as they arrive
+            sys.stdout.write(line)
+            sys.stdout.flush()
+            if line.startswith('{"metric"'):
+                seen = True
+        rc = child.wait()
+    finally:
+        stop_ranks()
+        for sg, h in previous.items():
+            signal.signal(sg, h)
     if rc == 0 and not seen:
         print("[bench] the ranks ended without printing the result line", file=sys.stderr, flush=True)
         rc = 1
     raise SystemExit(rc)
 
 
-def cpu_baseline(sr, seconds, eng, state_dict, head):
+def thread_scan(probe_fn, counts, set_threads, clock=time.perf_counter, slack=1.5, cap_s=8.0):
+    """Which thread count runs `probe_fn` fastest: ONE timed pass per count (ascending), stopping as soon as a count is `slack` x slower than
+    the best so far (torch's small-operator LSTM path only gets slower once it is oversubscribed) or `cap_s` is spent.  Returns
+    (best count, [(count, seconds), ...])."""
+    t_begin, best, log = clock(), None, []
+    for nt in counts:
+        set_threads(nt)
+        t0 = clock()
+        probe_fn()
+        dt = clock() - t0
+        log.append((nt, round(dt, 3)))
+        if best is None or dt < best[0]:
+            best = (dt, nt)
+        elif dt > slack * best[0]:
+            break
+        if clock() - t_begin > cap_s:
+            break
+    return best[1], log
+
+
+def cpu_baseline(sr, seconds, eng, state_dict, head, cap_s=25.0):
     """The reference path on the reference's own operator library (oracle/torch_oracle.py: torch CPU stft / conv2d /
     LSTM / linear, pinned to the reference fixtures) timed on this box's host cores on a bounded sample: clips of
-    `seconds` s until about 10 s of CPU work are done (at most 8 clips).  Also the dgrad parity number (first clip)."""
+    `seconds` s until about 10 s of CPU work are done (at most 8 clips), the WHOLE leg -- thread scan included -- held to
+    `cap_s` seconds.  Also the dgrad parity number (first clip)."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import torch_oracle as TO
     from sdfa_amd import synth
+    t_leg = time.perf_counter()
     orc = TO.TorchOracle(state_dict, head)
     n = int(seconds * sr)
-    # thread count: the box may expose more logical CPUs than this job's share, and torch's small-operator LSTM path
-    # slows down when oversubscribed -- take the fastest of a short scan on a 1 s clip (which also warms the pools)
+    # thread count: the box may expose more logical CPUs than this job's share, and torch's small-operator LSTM path slows down when
+    # oversubscribed -- a short scan on a 1 s clip, bounded (thread_scan): the 256-thread probe of round 5 alone cost minutes
     probe = synth.make_pcm(99, sr)
-    best = None
-    for nt in sorted({min(c, os.cpu_count() or 1) for c in (8, 16, 32, 64, 128, 256)}):      # up to every logical CPU the host exposes
-        torch.set_num_threads(nt)
-        TO.generate_animation(orc, probe, sr, 2, batch=100)
-        t0 = time.perf_counter()
-        TO.generate_animation(orc, probe, sr, 2, batch=100)
-        dt = time.perf_counter() - t0
-        if best is None or dt < best[0]:
-            best = (dt, nt)
-    cores = best[1]
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    counts = sorted({min(c, ncpu) for c in (8, 16, 32, 64)})
+    torch.set_num_threads(counts[0])
+    TO.generate_animation(orc, probe, sr, 2, batch=100)                       # untimed: warms the operator library and its pools
+    cores, scan = thread_scan(lambda: TO.generate_animation(orc, probe, sr, 2, batch=100), counts, torch.set_num_threads, cap_s=0.3 * cap_s)
     torch.set_num_threads(cores)
     frames, spent, clips, first = 0, 0.0, 0, None
-    while clips < 8 and (clips == 0 or spent < 10.0):
+    while clips < 8 and (clips == 0 or (spent < 10.0 and (time.perf_counter() - t_leg) + spent / clips < cap_s)):
         pcm = synth.make_pcm(clips, n)
         t0 = time.perf_counter()
         ts, ref = TO.generate_animation(orc, pcm, sr, 2, batch=100)           # batches of 100 frames like model.py:450-461
@@ -178,7 +279,8 @@ def cpu_baseline(sr, seconds, eng, state_dict, head):
                 affinity_cpus=len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None, kind="port",
                 sample=f"{clips} clip(s) x {seconds:g} s @ {sr} Hz = {frames} frames in {spent:.1f} s; oracle/torch_oracle.py = the reference "
                        f"path on torch {torch.__version__} CPU operators (fp32, batches of 100 frames); cores = the {cores} threads used "
-                       f"(fastest of a scan), nproc = logical CPUs the host exposes"), gpu_err
+                       f"(fastest of a bounded scan {scan}), nproc = logical CPUs the host exposes",
+                leg_seconds=round(time.perf_counter() - t_leg, 1)), gpu_err
 
 
 def surface_block(sd, head, sr, dev):
@@ -394,12 +496,14 @@ def precision_worst_case():
     return {}, None
 
 
-def attention_counter_util():
-    """Time-weighted rocprofv3 MfmaUtil of the attention stage (profiles/r*_pmc/attention_mfma.json, written by profiles/pmc_summary.py
-    from the committed --pmc pass), or None when absent or csrc/attn.hip / csrc/gemm.hip have changed since."""
+def attention_counter_util(mode="fp32"):
+    """Time-weighted rocprofv3 MfmaUtil of the attention stage in precision `mode` (profiles/r*_pmc/attention_mfma.json for fp32,
+    attention_mfma_<mode>.json for a configs[3] mode; written by profiles/pmc_summary.py from the committed --pmc pass of that mode),
+    or None when absent or csrc/attn.hip / csrc/gemm.hip have changed since."""
     import glob
     try:
-        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc", "attention_mfma.json")))[-1]
+        name = "attention_mfma.json" if mode == "fp32" else f"attention_mfma_{mode}.json"
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc", name)))[-1]
         with open(path) as f:
             t = json.load(f)
         if t.get("attn_hip_sha1") != _sha1("attn.hip") or t.get("gemm_hip_sha1") != _sha1("gemm.hip"):
@@ -651,29 +755,126 @@ def main():
     stages["frontend"] = fe_ms
 
     n_chunks = (F + a.chunk - 1) // a.chunk
-    # ---- optional legs.  The headline (dt, stages) is complete at this point; nothing below may cost it: every leg runs
-    # under leg(), which turns an exception into an {"error": ...} entry, puts the engine back into the headline precision and checks
-    # that the device still answers -- if it does not, the line is still printed and the process then exits non-zero.
+    # one GPU: the budget decides which optional legs run.  N > 1: optional legs run only with --all-legs, and then on EVERY rank or none
+    # (a rank that skipped alone would leave its peers waiting in a collective), so the budget admits everything there
+    budget = Budget(a.budget_s if world == 1 else float("inf"), t0=T_PROCESS_START)
+    step_s = dt / a.steps
+    passes = a.steps + a.warmup
+
+    # ---- the headline line, complete in itself, goes out NOW (rank 0): whatever happens to the optional legs below -- an exception, a hang,
+    # the driver's limit -- the number has been said.  The same dictionary, with the optional blocks filled in, is printed again as the last line.
+    res = None
+    if rank == 0:
+        frames_total = F_all * a.steps
+        value = frames_total / dt
+        lstm_ms_per_launch = stages["freq_lstm"] / n_chunks
+        flop_per_launch = FLOP_FREQ_LSTM_PER_FRAME * (F / n_chunks)
+        achieved = flop_per_launch / (lstm_ms_per_launch * 1e-3) / 1e12
+        traffic, traffic_alg, traffic_src = traffic_from_profile(F / n_chunks)
+        fe_cnt, fe_src = frontend_counter_bytes() if (a.frontend == "gather" and sr == 16000 and not a.ragged_seconds and a.seconds == 10.0) else (None, None)
+        res = {
+            "metric": "animation frames/s/node (10 s@16 kHz clips); max|Δdgrad| vs CPU ref",
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": {"fp32": "f32", "bf16_attention": "f32 (attention projections bf16)",
+                                           "bf16x3": "split-bf16 x3 (fp32 accumulate)", "bf16": "bf16 (fp32 accumulate)",
+                                           "bf16x3_attention": "f32 (attention projections split-bf16 x3)",
+                                           "bf16x6": "split-bf16 x6 (three terms per operand, fp32-equivalent products, fp32 accumulate)"}[a.precision],
+            "data": "synthetic",
+            "config": {"workload": (f"batch={C} x {a.seconds:g} s@{sr} Hz synthetic PCM per GPU -> {a.head} (BASELINE configs[1])"
+                                    if not a.ragged_seconds else
+                                    f"stream of {C} sentences, {a.ragged_seconds} s@{sr} Hz synthetic PCM per GPU -> {a.head} (BASELINE configs[4] rehearsal)"),
+                       "clips_per_gpu": C, "frames_per_gpu": F, "head": a.head, "chunk_frames": a.chunk,
+                       "freq_lstm_form": eng.freq_lstm_form,      # picked by sdfa_model_autotune in the first warm-up step (bit-identical forms)
+                       "gather": (Mode.kind if (Mode.gatherer is not None or Mode.direct is not None or (mesh is not None and mesh[3] is not None)) else "none") if dist_on else "none (1 GPU)",
+                       "force_gather_world1": bool(a.force_gather and world == 1), "backend": (dist.get_backend() if dist_on else None),
+                       "world_size_seen": world_seen, "devices": devices,
+                       "distinct_devices": len({(d["host"], d["pci_bus_id"] or d["device"]) for d in devices}),
+                       "launcher": os.environ.get("SDFA_BENCH_LAUNCHER", "external" if "WORLD_SIZE" in os.environ else "none"),
+                       "reserved_cus": a.reserve_cus,
+                       "memory_plan_gb": _plan_or_none(world, C, a, sr),   # planned (memory_plan); peak_device_memory_gb is measured
+                       "env": __import__("sdfa_amd").runtime_env(),      # set at import by bench.py / sdfa_amd unless the caller had set them
+                       # does an asynchronous RCCL all-gather run UNDER the kernels of the stream the steps ran on?  (probe before the run)
+                       "collective_overlap_probe": comm_probe,
+                       "gather_auto_ms_per_step": None if auto is None else {k: round(v, 2) for k, v in auto.items()},
+                       "gather_checksum_ok": gather_check, "weights": "synthetic seed 1234",
+                       "mesh_stage": None if mesh is None else f"seek to 60 fps + mesh solve, {mesh[1].n_queries} video frames x {mesh[0].n_verts} vertices per GPU per step"},
+            "roofline": {"kernel": "freq_lstm_v3_kernel" if eng.freq_lstm_form in (None, 8, 9) else "freq_lstm_v2_kernel", "bound": "mfma", "achieved": round(achieved, 2),
+                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "traffic": traffic, "traffic_algorithmic": traffic_alg, "traffic_source": traffic_src,
+                         "launch_ms": round(lstm_ms_per_launch, 3), "flop_per_launch": flop_per_launch,
+                         # `frac` is ALGORITHMIC (SURVEY 8(d)): the kernel issues 752/768 of those FLOPs (step 0's recurrent k-blocks multiply
+                         # h_-1 = 0 and are skipped) -- frac_executed is the figure rocprofv3's MfmaUtil should agree with
+                         "flop_executed_per_launch": flop_per_launch * FREQ_LSTM_EXECUTED_FRACTION,
+                         "frac_executed": round(achieved * FREQ_LSTM_EXECUTED_FRACTION / PEAK_FP32_MFMA_TFLOPS, 4)},
+            "cpu_baseline": None,                                # filled in below (the complete, last line carries it)
+            "model_tflops": round(value / world * FLOP_MODEL_PER_FRAME / 1e12, 2),
+            "model_frac_of_fp32_mfma_peak": round(value / world * FLOP_MODEL_PER_FRAME / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+            "frontend": {"ms": round(fe_ms, 3), "frames_per_s": round(F / (fe_ms * 1e-3), 1),
+                         "hbm_gbps_algorithmic": round(F * FRONTEND_BYTES_PER_FRAME / (fe_ms * 1e-3) / 1e9, 1),
+                         "frac_of_hbm_peak": round(F * FRONTEND_BYTES_PER_FRAME / (fe_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                         # what the HBM counters saw (FETCH_SIZE x 2 + WRITE_SIZE of the stage's two kernels, committed PMC passes) over
+                         # this run's stage time; null when the passes are absent or csrc/frontend.hip has changed since
+                         "hbm_gbps_counters": None if fe_cnt is None else round(F * fe_cnt / (fe_ms * 1e-3) / 1e9, 1),
+                         "frac_of_hbm_peak_counters": None if fe_cnt is None else round(F * fe_cnt / (fe_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                         "counters_source": fe_src},
+            "stage_ms_per_step": {k: round(v, 3) for k, v in stages.items()},
+        }
+        # north_star: "MFMA utilisation on the attention stage against gfx950 peak" (target >= 40 %): key / query projections (MFMA GEMMs)
+        # + the softmax / context tail (vector + HBM), live stage time and the counter figure of the committed pass
+        att_util, att_src = attention_counter_util("fp32") if a.precision == "fp32" else (None, None)
+        att_ms = stages.get("attn_proj", 0.0) + stages.get("attn", 0.0)
+        res["attention"] = {"ms": round(att_ms, 3), "flop_per_frame": FLOP_ATTENTION_PER_FRAME,
+                            "frac_of_fp32_mfma_peak_by_flop": round(F * FLOP_ATTENTION_PER_FRAME / (att_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if att_ms > 0 else None,
+                            "mfma_util_pct_counters": att_util, "counters_source": att_src}
+        res["peak_device_memory_gb"] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 2)
+        res["wall_clock"] = dict(budget.report(), headline_at_s=round(budget.elapsed(), 1))
+        emit(res, final=False)
+
+    # ---- the legs behind the headline.  Each runs under leg(), which turns an exception into an {"error": ...} entry, puts the engine back
+    # into the headline precision and checks that the device still answers -- if it does not, the line is still printed and the process
+    # then exits non-zero -- and each is admitted by `budget` first: a leg that is not expected to fit is skipped and listed.
     leg_errors, fatal = {}, []
 
-    def leg(name, fn):
-        try:
-            if a.inject_failure == name:
-                raise RuntimeError(f"injected failure in optional leg {name} (--inject-failure)")
-            return fn()
-        except Exception as e:
-            leg_errors[name] = repr(e)
+    def leg(name, fn, estimate_s, required=False):
+        def guarded():
             try:
-                eng.profile(False)
-            except Exception:
-                pass
-            return None
-        finally:
-            try:
-                eng.set_precision(a.precision)
-                torch.cuda.synchronize()
+                if a.inject_failure == name:
+                    raise RuntimeError(f"injected failure in optional leg {name} (--inject-failure)")
+                return fn()
             except Exception as e:
-                fatal.append(f"after leg {name}: {e!r}")
+                leg_errors[name] = repr(e)
+                try:
+                    eng.profile(False)
+                except Exception:
+                    pass
+                return None
+            finally:
+                try:
+                    eng.set_precision(a.precision)
+                    torch.cuda.synchronize()
+                except Exception as e:
+                    fatal.append(f"after leg {name}: {e!r}")
+        return budget.run(name, estimate_s, guarded, required)
+
+    # cpu_baseline first: the bench contract asks for it in the line, the legs behind it are extras.  Bounded (--cpu-baseline-cap-s).
+    cpu, gpu_err = None, None
+    if world == 1 and rank == 0 and not a.no_cpu_baseline:
+        def run_cpu():
+            return cpu_baseline(sr, a.cpu_sample_seconds, eng, sd, a.head, cap_s=a.cpu_baseline_cap_s)
+        got = leg("cpu_baseline", run_cpu, a.cpu_baseline_cap_s + 5.0, required=True)
+        if got is not None:
+            cpu, gpu_err = got
+            res["cpu_baseline"] = cpu
+            try:
+                res["max_abs_dgrad_err_vs_cpu_ref"], res["tslist_bit_exact"] = gpu_err(a.precision)
+            except Exception as e:
+                res["max_abs_dgrad_err_vs_cpu_ref"] = {"error": repr(e)}
+            finally:
+                eng.set_precision(a.precision)
+        else:
+            why = leg_errors.get("cpu_baseline") or "skipped: did not fit --budget-s"
+            res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": None, "nproc": int(os.cpu_count() or 0), "kind": "port", "sample": f"failed: {why}"}
 
     optional = world == 1 or a.all_legs         # at N > 1 a rank that failed alone would leave its peers waiting in a collective: headline only
     shared = None
@@ -681,7 +882,7 @@ def main():
         def run_shared():
             dt_s, st_s = timed(True)
             return dt_s, st_s, eng.distinct_columns(min(F - (n_chunks - 1) * a.chunk, a.chunk))
-        shared = leg("column_sharing", run_shared)
+        shared = leg("column_sharing", run_shared, 1.0 + 0.75 * passes * step_s)
     mixed = None
     if a.precision == "fp32" and not a.no_mixed_precision and optional:      # BASELINE configs[3]: same workload on split-bf16 MFMA
         def run_mode(mode, share=False):
@@ -689,10 +890,11 @@ def main():
                 eng.set_precision(mode)
                 return timed(share)
             return go
-        mixed = {"bf16x3": leg("bf16x3", run_mode("bf16x3")),
-                 "bf16x3_column_sharing": None if a.no_column_sharing else leg("bf16x3_column_sharing", run_mode("bf16x3", True)),
-                 "bf16x3_attention": leg("bf16x3_attention", run_mode("bf16x3_attention")),   # configs[3] literally: only the attention stage
-                 "bf16x6": leg("bf16x6", run_mode("bf16x6"))}                                  # the six-product split: fp32-equivalent products
+        # expected cost relative to an fp32 step (BENCH_r05: 0.44 / 1.0 / 0.71 / 0.32), with margin
+        mixed = {"bf16x3": leg("bf16x3", run_mode("bf16x3"), 1.0 + 0.55 * passes * step_s),
+                 "bf16x3_attention": leg("bf16x3_attention", run_mode("bf16x3_attention"), 1.0 + 1.05 * passes * step_s),   # configs[3] literally: only the attention stage
+                 "bf16x6": leg("bf16x6", run_mode("bf16x6"), 1.0 + 0.8 * passes * step_s),                                  # the six-product split: fp32-equivalent products
+                 "bf16x3_column_sharing": None if a.no_column_sharing else leg("bf16x3_column_sharing", run_mode("bf16x3", True), 1.0 + 0.45 * passes * step_s)}
     # ---- PCIe-inclusive twin (SURVEY 8(d) "report both"): the same K steps with the PCM arriving from pinned host memory inside
     # the step (H2D) and every output row delivered to pinned host memory inside the step (D2H, 359 KB per frame): pieces of
     # `chunk` frames, piece i's copy on a copy stream under piece i+1's kernels (Engine.forward_host), two alternating host
@@ -756,87 +958,27 @@ def main():
         del outs_host, pcm_host
         return host_io
 
+
     host_io, host_io_error = None, None
     if world == 1 and not dist_on and not a.no_host_io and mesh is None:
-        try:
-            host_io = host_io_twin()
-        except Exception as e:      # the headline above stands on its own: say what went wrong with the twin (e.g. no pinned memory)
-            host_io, host_io_error = None, repr(e)
-            torch.cuda.synchronize()
-            if Mode.out is None:
-                Mode.out = torch.empty((F, eng.out_dim), dtype=torch.float32, device=dev)
+        def run_host_io():
+            try:
+                return host_io_twin()
+            finally:
+                if Mode.out is None:
+                    Mode.out = torch.empty((F, eng.out_dim), dtype=torch.float32, device=dev)
+        # two pinned output buffers (F x out_dim x 4 B each: pinning runs at a few GB/s) + (warm-up + steps) x 2 forms + one plain step
+        host_io = leg("with_h2d_d2h", run_host_io, 6.0 + 2 * F * eng.out_dim * 4 / 2.0e9 + (1 if a.no_column_sharing else 1.8) * (passes + 1) * step_s * 1.1)
+        host_io_error = leg_errors.get("with_h2d_d2h")
 
     # ---- the speech_anime surface: what a caller of generate_animation sees, wall clock, host work + copies included
     surface = None
     if world == 1 and not dist_on and not a.no_surface and a.precision == "fp32":
-        try:
-            surface = surface_block(sd, a.head, sr, dev)
-        except Exception as e:          # never at the price of the headline line
-            surface = {"error": repr(e)}
+        surface = leg("surface", lambda: surface_block(sd, a.head, sr, dev), 30.0)
+        if surface is None and "surface" in leg_errors:
+            surface = {"error": leg_errors["surface"]}
 
     if rank == 0:
-        frames_total = F_all * a.steps
-        value = frames_total / dt
-        lstm_ms_per_launch = stages["freq_lstm"] / n_chunks
-        flop_per_launch = FLOP_FREQ_LSTM_PER_FRAME * (F / n_chunks)
-        achieved = flop_per_launch / (lstm_ms_per_launch * 1e-3) / 1e12
-        traffic, traffic_alg, traffic_src = traffic_from_profile(F / n_chunks)
-        fe_cnt, fe_src = frontend_counter_bytes() if (a.frontend == "gather" and sr == 16000 and not a.ragged_seconds and a.seconds == 10.0) else (None, None)
-        res = {
-            "metric": "animation frames/s/node (10 s@16 kHz clips); max|Δdgrad| vs CPU ref",
-            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"fp32": "f32", "bf16_attention": "f32 (attention projections bf16)",
-                                           "bf16x3": "split-bf16 x3 (fp32 accumulate)", "bf16": "bf16 (fp32 accumulate)",
-                                           "bf16x3_attention": "f32 (attention projections split-bf16 x3)",
-                                           "bf16x6": "split-bf16 x6 (three terms per operand, fp32-equivalent products, fp32 accumulate)"}[a.precision],
-            "data": "synthetic",
-            "config": {"workload": (f"batch={C} x {a.seconds:g} s@{sr} Hz synthetic PCM per GPU -> {a.head} (BASELINE configs[1])"
-                                    if not a.ragged_seconds else
-                                    f"stream of {C} sentences, {a.ragged_seconds} s@{sr} Hz synthetic PCM per GPU -> {a.head} (BASELINE configs[4] rehearsal)"),
-                       "clips_per_gpu": C, "frames_per_gpu": F, "head": a.head, "chunk_frames": a.chunk,
-                       "freq_lstm_form": eng.freq_lstm_form,      # picked by sdfa_model_autotune in the first warm-up step (bit-identical forms)
-                       "gather": (Mode.kind if (Mode.gatherer is not None or Mode.direct is not None or (mesh is not None and mesh[3] is not None)) else "none") if dist_on else "none (1 GPU)",
-                       "force_gather_world1": bool(a.force_gather and world == 1), "backend": (dist.get_backend() if dist_on else None),
-                       "world_size_seen": world_seen, "devices": devices,
-                       "distinct_devices": len({(d["host"], d["pci_bus_id"] or d["device"]) for d in devices}),
-                       "launcher": os.environ.get("SDFA_BENCH_LAUNCHER", "external" if "WORLD_SIZE" in os.environ else "none"),
-                       "reserved_cus": a.reserve_cus,
-                       "memory_plan_gb": _plan_or_none(world, C, a, sr),   # planned (memory_plan); peak_device_memory_gb is measured
-                       "env": __import__("sdfa_amd").runtime_env(),      # set at import by bench.py / sdfa_amd unless the caller had set them
-                       # does an asynchronous RCCL all-gather run UNDER the kernels of the stream the steps ran on?  (probe before the run)
-                       "collective_overlap_probe": comm_probe,
-                       "gather_auto_ms_per_step": None if auto is None else {k: round(v, 2) for k, v in auto.items()},
-                       "gather_checksum_ok": gather_check, "weights": "synthetic seed 1234",
-                       "mesh_stage": None if mesh is None else f"seek to 60 fps + mesh solve, {mesh[1].n_queries} video frames x {mesh[0].n_verts} vertices per GPU per step"},
-            "roofline": {"kernel": "freq_lstm_v3_kernel" if eng.freq_lstm_form in (None, 8, 9) else "freq_lstm_v2_kernel", "bound": "mfma", "achieved": round(achieved, 2),
-                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                         "traffic": traffic, "traffic_algorithmic": traffic_alg, "traffic_source": traffic_src,
-                         "launch_ms": round(lstm_ms_per_launch, 3), "flop_per_launch": flop_per_launch,
-                         # `frac` is ALGORITHMIC (SURVEY 8(d)): the kernel issues 752/768 of those FLOPs (step 0's recurrent k-blocks multiply
-                         # h_-1 = 0 and are skipped) -- frac_executed is the figure rocprofv3's MfmaUtil should agree with
-                         "flop_executed_per_launch": flop_per_launch * FREQ_LSTM_EXECUTED_FRACTION,
-                         "frac_executed": round(achieved * FREQ_LSTM_EXECUTED_FRACTION / PEAK_FP32_MFMA_TFLOPS, 4)},
-            "model_tflops": round(value / world * FLOP_MODEL_PER_FRAME / 1e12, 2),
-            "model_frac_of_fp32_mfma_peak": round(value / world * FLOP_MODEL_PER_FRAME / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-            "frontend": {"ms": round(fe_ms, 3), "frames_per_s": round(F / (fe_ms * 1e-3), 1),
-                         "hbm_gbps_algorithmic": round(F * FRONTEND_BYTES_PER_FRAME / (fe_ms * 1e-3) / 1e9, 1),
-                         "frac_of_hbm_peak": round(F * FRONTEND_BYTES_PER_FRAME / (fe_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
-                         # what the HBM counters saw (FETCH_SIZE x 2 + WRITE_SIZE of the stage's two kernels, committed PMC passes) over
-                         # this run's stage time; null when the passes are absent or csrc/frontend.hip has changed since
-                         "hbm_gbps_counters": None if fe_cnt is None else round(F * fe_cnt / (fe_ms * 1e-3) / 1e9, 1),
-                         "frac_of_hbm_peak_counters": None if fe_cnt is None else round(F * fe_cnt / (fe_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
-                         "counters_source": fe_src},
-            "stage_ms_per_step": {k: round(v, 3) for k, v in stages.items()},
-        }
-        # north_star: "MFMA utilisation on the attention stage against gfx950 peak" (target >= 40 %): key / query projections (MFMA GEMMs)
-        # + the softmax / context tail (vector + HBM), live stage time and the counter figure of the committed pass
-        att_util, att_src = attention_counter_util() if a.precision == "fp32" else (None, None)
-        att_ms = stages.get("attn_proj", 0.0) + stages.get("attn", 0.0)
-        res["attention"] = {"ms": round(att_ms, 3), "flop_per_frame": FLOP_ATTENTION_PER_FRAME,
-                            "frac_of_fp32_mfma_peak_by_flop": round(F * FLOP_ATTENTION_PER_FRAME / (att_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if att_ms > 0 else None,
-                            "mfma_util_pct_counters": att_util, "counters_source": att_src}
-        res["peak_device_memory_gb"] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 2)
         if host_io is not None:
             tw = host_io["fp32"]
             host_io["copy_stream_overlaps"] = None if eng._host is None else {"overlaps": bool(eng._host.copy_overlaps), "probes": eng._host.copy_probe}
@@ -876,6 +1018,10 @@ def main():
             def st(r):
                 return None if r is None else {k: round(v, 3) for k, v in r[1].items()}
             m3, m3s, ma, m6 = mixed["bf16x3"], mixed["bf16x3_column_sharing"], mixed["bf16x3_attention"], mixed["bf16x6"]
+            # configs[3] as worded: the attention stage's MFMA utilisation IN the bf16 attention mode (committed --pmc pass of that mode,
+            # nulled once csrc/attn.hip or csrc/gemm.hip change), next to the live stage time
+            ma_util, ma_src = attention_counter_util("bf16x3_attention")
+            ma_att_ms = None if ma is None else ma[1].get("attn_proj", 0.0) + ma[1].get("attn", 0.0)
             res["mixed_precision"] = {
                 "note": "BASELINE configs[3]: same workload with the conv stack, the frequency LSTM, the BiLSTM recurrences and every GEMM "
                         "on split-bf16 MFMA (operands as hi+lo bf16, three v_mfma_f32_32x32x16_bf16 per product, fp32 "
@@ -886,40 +1032,38 @@ def main():
                                              "(key / query projections, query conv) on v_mfma_f32_32x32x16_bf16 with split-bf16 operands, the rest exact fp32",
                                      "value": rate(ma), "unit": "frames/s", "ms_per_step": ms(ma),
                                      "attn_proj_ms_per_step": None if ma is None else round(ma[1].get("attn_proj", 0.0), 3),
-                                     "attn_proj_ms_per_step_fp32": round(stages.get("attn_proj", 0.0), 3)},
+                                     "attn_proj_ms_per_step_fp32": round(stages.get("attn_proj", 0.0), 3),
+                                     "attention_stage_ms_per_step": None if ma_att_ms is None else round(ma_att_ms, 3),
+                                     "mfma_util_pct_counters": ma_util, "counters_source": ma_src},
                 "bf16x6": {"note": "six-product split: operands as three bf16 terms (24 significand bits), six v_mfma_f32_32x32x16_bf16 per product, "
                                    "the same stages as bf16x3: fp32-equivalent products at 16 / 6 of the fp32 MFMA rate",
                            "value": rate(m6), "unit": "frames/s", "ms_per_step": ms(m6), "stage_ms_per_step": st(m6)}}
             for k in ("bf16x3", "bf16x3_column_sharing", "bf16x3_attention", "bf16x6"):
                 if k in leg_errors:
                     res["mixed_precision"].setdefault("errors", {})[k] = leg_errors[k]
+            if gpu_err is not None and not fatal:
+                worst, worst_src = precision_worst_case()
+                for mode, block, ran in (("bf16x3", res["mixed_precision"], m3), ("bf16x3_attention", res["mixed_precision"]["bf16x3_attention"], ma),
+                                         ("bf16x6", res["mixed_precision"]["bf16x6"], m6)):
+                    if ran is None or budget.left() < 3.0:
+                        continue
+                    try:
+                        live = gpu_err(mode)[0]
+                        block["max_abs_dgrad_err_vs_cpu_ref_10s_clip"] = live
+                        # the WORST case on record, not the fixture case: this run's clip and the committed wide sweep
+                        block["max_abs_dgrad_err_vs_cpu_ref"] = max(live, worst.get(mode, 0.0))
+                        block["max_abs_dgrad_err_source"] = f"max(this run's 10 s clip, worst case of {worst_src})" if mode in worst else "this run's 10 s clip only"
+                    except Exception as e:
+                        block["max_abs_dgrad_err_vs_cpu_ref"] = {"error": repr(e)}
+                    finally:
+                        eng.set_precision(a.precision)
         if not optional and (not a.no_column_sharing or not a.no_mixed_precision):
             res["optional_legs"] = "skipped at N > 1 (headline only; --all-legs runs them)"
         if fatal:
             res["device_unusable_after_optional_leg"] = fatal
-        if world == 1 and not a.no_cpu_baseline:
-            try:
-                cb, gpu_err = cpu_baseline(sr, a.cpu_sample_seconds, eng, sd, a.head)
-                res["cpu_baseline"] = cb
-                res["max_abs_dgrad_err_vs_cpu_ref"], res["tslist_bit_exact"] = gpu_err(a.precision)
-                if mixed is not None and not fatal:
-                    worst, worst_src = precision_worst_case()
-                    for mode, block in (("bf16x3", res["mixed_precision"]), ("bf16x3_attention", res["mixed_precision"]["bf16x3_attention"]),
-                                        ("bf16x6", res["mixed_precision"]["bf16x6"])):
-                        try:
-                            live = gpu_err(mode)[0]
-                            block["max_abs_dgrad_err_vs_cpu_ref_10s_clip"] = live
-                            # the WORST case on record, not the fixture case: this run's clip and the committed wide sweep
-                            block["max_abs_dgrad_err_vs_cpu_ref"] = max(live, worst.get(mode, 0.0))
-                            block["max_abs_dgrad_err_source"] = f"max(this run's 10 s clip, worst case of {worst_src})" if mode in worst else "this run's 10 s clip only"
-                        except Exception as e:
-                            block["max_abs_dgrad_err_vs_cpu_ref"] = {"error": repr(e)}
-            except Exception as e:      # the GPU measurement above stands on its own; say what went wrong with the CPU leg
-                res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": None, "nproc": int(os.cpu_count() or 0), "kind": "port",
-                                       "sample": f"failed: {e!r}"}
-            finally:
-                eng.set_precision(a.precision)
-        print(json.dumps(res), flush=True)
+        res["legs_skipped"] = budget.skipped
+        res["wall_clock"] = dict(budget.report(), headline_at_s=res["wall_clock"]["headline_at_s"])
+        emit(res, final=True)
     if fatal:
         raise SystemExit(f"the headline line was printed, but the device did not recover from an optional leg: {fatal}")
     if dist_on:

@@ -25,8 +25,9 @@
 extern "C" {
 #endif
 
-#define SDFA_ABI_VERSION 4   /* 4: workspace status block (sdfa_workspace_init / _status*, replaces sdfa_debug_time_lstm_timeout), unaligned sdfa_ensemble_mean (round 4);
-                                round 5 only ADDS the tests-only sdfa_debug_frontend_status and library options: no signature changed, the version stays;
+#define SDFA_ABI_VERSION 5   /* bumped whenever an export is added or a signature changes: the Python binding refuses a library of another version with
+                                "stale library, run make" instead of a bare AttributeError.  5: + sdfa_debug_frontend_status (added in round 5 without a bump);
+                                4: workspace status block (sdfa_workspace_init / _status*, replaces sdfa_debug_time_lstm_timeout), unaligned sdfa_ensemble_mean (round 4);
                                 3: + sdfa_ensemble_mean, sdfa_model_set_reserved_cus, sdfa_debug_time_lstm_timeout (round 3); 2: + seek, resample, mesh correspondences,
                                 multi-destination regress, expand_coef, autotune (round 2); all earlier entry points unchanged */
 

@@ -508,12 +508,13 @@ int sdfa_mel_frontend_gather(const float *d_pcm, const int64_t *d_clip_off, cons
     sa.prev = sh + 16; sa.shift = sa.prev + w.Nc;
     sa.owner = sa.shift + w.Nc; sa.flag = sa.owner + w.Mc; sa.uid = sa.flag + w.Mc;
     sa.col_src = sa.uid + w.Mc; sa.col_to_u = sa.col_src + w.Mc; sa.tile_sum = sa.col_to_u + w.Mc;
+    // sh[8]: the stream kernel's status word (bounded hand-off waits that expired -- never, unless its logic is wrong -- and were
+    // repaired by the pass behind the kernel).  Zeroed by EVERY call, whichever form runs, so that sdfa_debug_frontend_status never
+    // reads a stale or uninitialised word after a two-kernel / radix-4 / t-major call or on a fresh workspace.
+    HIP_TRY(hipMemsetAsync(sh + 8, 0, sizeof(int32_t), s));
     if (!g_sdfa_frontend_two_kernel && !g_sdfa_mel_fft_radix4 && !g_sdfa_frontend_t_major) {
         // spectral stream (frontend.hip): the chains are read from prev / shift, the mel rows live in an LDS ring, no table
         HIP_TRY(sdfa_launch_share_prev(sa, s));
-        // sh[8]: the stream kernel's status word (bounded hand-off waits that expired -- never, unless its logic is wrong -- and were
-        // repaired by the pass behind the kernel) -- zeroed per call, read by sdfa_debug_frontend_status
-        HIP_TRY(hipMemsetAsync(sh + 8, 0, sizeof(int32_t), s));
         HIP_TRY(sdfa_launch_mel_stream(c, d_pcm, d_clip_off, d_clip_len, d_frame_clip, d_frame_start, sa.prev, sa.shift, n_frames,
                                        g_sdfa_frontend_stream_block, g_sdfa_frontend_stream_slots, g_sdfa_frontend_stream_phases ? 0 : 1, g_sdfa_frontend_stream_spin_max, sh + 8, d_audio_feat, s));
         return SDFA_OK;

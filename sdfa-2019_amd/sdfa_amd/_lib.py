@@ -14,6 +14,7 @@ import torch  # noqa: F401,E402
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SDFA_HIP_LIB", os.path.join(_HERE, "libsdfa_hip.so"))
 
+ABI_VERSION = 5      # include/sdfa_hip.h SDFA_ABI_VERSION this binding was written against
 OK, EINVAL, ESHORTCLIP, EHIP, ESTATE, ENOSPACE = 0, -1, -2, -3, -4, -5
 HEAD_DGRAD, HEAD_OFFSETS = 0, 1
 
@@ -85,8 +86,20 @@ def _load():
             f"{LIB_PATH} not found: build it with `make -C sdfa-2019_amd/csrc` "
             "(or __graft_entry__.build()).  There is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
+    stale = (f"{LIB_PATH} is a stale build (%s): rebuild it with `make -C sdfa-2019_amd/csrc` (or __graft_entry__.build()).  "
+             "There is no CPU fallback.")
+    try:
+        lib.sdfa_abi_version.restype = C.c_int
+        have = int(lib.sdfa_abi_version())
+    except AttributeError:
+        raise ImportError(stale % "it does not export sdfa_abi_version") from None
+    if have != ABI_VERSION:
+        raise ImportError(stale % f"ABI version {have}, this binding needs {ABI_VERSION}")
     for name, (res, args) in SYMBOLS.items():
-        fn = getattr(lib, name)      # AttributeError if the symbol is not exported
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise ImportError(stale % f"symbol {name} is not exported") from None
         fn.restype = res
         fn.argtypes = args
     return lib

@@ -73,9 +73,21 @@ class DatasetSlidingWindow:
             return eng
         # a bare front end lives on the configured device (hparams.device; api.evaluate_model sets it per rank), else the CURRENT one
         want = (cls.hparams.get("device") if cls.hparams is not None else None) or None
-        if cls._engine is None or (want is not None and str(cls._engine.device) != str(torch.device(want))):
+        if cls._engine is None or (want is not None and cls._same_device(cls._engine.device, want) is False):
             cls._engine = _engine.FrontendOnly(device=want)
         return cls._engine
+
+    @staticmethod
+    def _same_device(have, want):
+        """torch.device comparison with an index-less "cuda" meaning the CURRENT device (FrontendOnly normalises its own the same way):
+        'cuda' against 'cuda:0' is the same card, not a reason to build a new front end -- and a new 0.7 GB workspace -- per call."""
+        a, b = torch.device(have), torch.device(want)
+        if a.type != b.type:
+            return False
+        if a.type != "cuda":
+            return True
+        cur = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        return (cur if a.index is None else a.index) == (cur if b.index is None else b.index)
 
     @staticmethod
     def _energy(signal, sr, starts=None):

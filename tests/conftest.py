@@ -23,7 +23,17 @@ def _ensure_library():
     global LIB_PROBLEM
     built = os.path.join(ROOT, "sdfa-2019_amd", "sdfa_amd", "libsdfa_hip.so")
     so = os.environ.get("SDFA_HIP_LIB") or built
-    if os.path.exists(so):
+    csrc = os.path.join(ROOT, "sdfa-2019_amd", "csrc")
+
+    def stale():
+        """the in-tree library is older than one of its sources (or the header): `make` decides what to rebuild"""
+        if so != built or not os.path.exists(built):
+            return False
+        t = os.path.getmtime(built)
+        srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".cpp", ".h")) or f == "Makefile"]
+        srcs.append(os.path.join(ROOT, "include", "sdfa_hip.h"))
+        return any(os.path.getmtime(f) > t for f in srcs if os.path.exists(f))
+    if os.path.exists(so) and not stale():
         return
     if so != built:
         LIB_PROBLEM = f"SDFA_HIP_LIB={so} does not exist"
@@ -33,13 +43,15 @@ def _ensure_library():
     import subprocess
     hipcc = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
-        LIB_PROBLEM = "libsdfa_hip.so is not built and there is no hipcc to build it"
+        if not os.path.exists(built):                    # (an existing library that only LOOKS older than its sources is used as it is:
+            LIB_PROBLEM = "libsdfa_hip.so is not built and there is no hipcc to build it"      # sdfa_amd._lib refuses a real ABI mismatch)
         return
     with open(os.path.join(ROOT, "sdfa-2019_amd", "csrc", ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
-        if not os.path.exists(built):                    # another worker may have built it while this one waited
+        had = os.path.exists(built)
+        if not had or stale():                           # another worker may have built it while this one waited
             r = subprocess.run(["make", "-C", os.path.join(ROOT, "sdfa-2019_amd", "csrc")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-            if r.returncode != 0 or not os.path.exists(built):
+            if not os.path.exists(built) or (r.returncode != 0 and not had):
                 LIB_PROBLEM = "building libsdfa_hip.so failed:\n" + r.stdout[-2000:]
 
 

@@ -20,7 +20,7 @@ def test_header_symbols_all_bound_and_exported():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(_lib.lib, name)
-    assert _lib.lib.sdfa_abi_version() == 4
+    assert _lib.lib.sdfa_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_frame_index_matches_reference_fixtures(golden):

@@ -115,3 +115,65 @@ def test_committed_precision_sweep_is_inside_the_budget_and_reported():
     assert worst["bf16x6"] <= 1e-5 and worst["fp32"] <= 1e-5 and worst["bf16x3"] > worst["bf16x6"]
     table = json.load(open(os.path.join(ROOT, src)))
     assert len(table["cases"]) >= 7 and all(m in table["bounds_asserted"] for m in worst)
+
+
+def test_budget_skips_legs_that_do_not_fit_and_both_lines_are_printed(capfd):
+    """bench.py prints the headline right after the timed steps and again, complete, as the LAST line; a leg that is not
+    expected to fit the wall-clock budget is never started and is listed in `legs_skipped`; time kept back for the required leg
+    (cpu_baseline) cannot be eaten by the optional ones."""
+    bench = _load("bench_for_test5", "bench.py")
+    now = {"t": 100.0}
+    b = bench.Budget(60.0, clock=lambda: now["t"], t0=100.0, reserve_s=20.0)
+    ran = []
+
+    def work(name, cost):
+        def fn():
+            ran.append(name)
+            now["t"] += cost
+            return name
+        return fn
+    res = {"metric": "m", "value": 1.0, "cpu_baseline": None}
+    bench.emit(res, final=False)                                              # the early line
+    assert b.run("column_sharing", 10.0, work("column_sharing", 12.0)) == "column_sharing"      # 60 left >= 10 + 20 reserved
+    assert b.run("bf16x3", 25.0, work("bf16x3", 25.0)) == "bf16x3"                              # 48 left >= 25 + 20
+    assert b.run("surface", 30.0, work("surface", 30.0)) is None                                # 23 left < 30 + 20: skipped, not started
+    assert b.run("tiny", 2.0, work("tiny", 2.0)) == "tiny"                                      # 23 >= 2 + 20
+    assert b.run("cpu_baseline", 20.0, work("cpu_baseline", 19.0), required=True) == "cpu_baseline"   # required: the reserve is its own
+    assert b.run("late", 5.0, work("late", 5.0)) is None
+    assert ran == ["column_sharing", "bf16x3", "tiny", "cpu_baseline"]
+    assert [s["leg"] for s in b.skipped] == ["surface", "late"] and b.skipped[0]["estimate_s"] == 30.0
+    assert b.seconds == {"column_sharing": 12.0, "bf16x3": 25.0, "tiny": 2.0, "cpu_baseline": 19.0}
+    res["cpu_baseline"] = {"value": 127.0}
+    res["legs_skipped"] = b.skipped
+    res["wall_clock"] = b.report()
+    bench.emit(res, final=True)
+    first, last = [json.loads(l) for l in capfd.readouterr().out.splitlines()]
+    assert first["partial"] is True and first["value"] == 1.0 and first["cpu_baseline"] is None
+    assert last["partial"] is False and last["value"] == first["value"] and last["cpu_baseline"]["value"] == 127.0
+    assert [s["leg"] for s in last["legs_skipped"]] == ["surface", "late"] and last["wall_clock"]["budget_s"] == 60.0
+    # a leg that raises still records its time and the exception propagates to the caller's own handler
+    import pytest
+    with pytest.raises(ZeroDivisionError):
+        b2 = bench.Budget(10.0, clock=lambda: now["t"], t0=now["t"])
+        b2.run("boom", 1.0, lambda: 1 / 0)
+    # unlimited budget (N > 1 with --all-legs: every rank must take the same legs): admits everything, reports null
+    binf = bench.Budget(float("inf"), clock=lambda: now["t"], t0=0.0)
+    assert binf.admit("anything", 1e9) and binf.report()["budget_s"] is None and json.dumps(binf.report())
+
+
+def test_thread_scan_is_bounded():
+    """cpu_baseline's thread scan (the 256-thread probe cost minutes): one pass per count, stop at 1.5 x the best or at the cap."""
+    bench = _load("bench_for_test6", "bench.py")
+    now = {"t": 0.0, "nt": None}
+    cost = {8: 1.0, 16: 0.8, 32: 1.3, 64: 50.0, 128: 500.0}
+    calls = []
+
+    def probe():
+        calls.append(now["nt"])
+        now["t"] += cost[now["nt"]]
+    best, log = bench.thread_scan(probe, [8, 16, 32, 64, 128], lambda n: now.update(nt=n), clock=lambda: now["t"], cap_s=100.0)
+    assert best == 16 and calls == [8, 16, 32] and [c for c, _ in log] == [8, 16, 32]       # 1.3 > 1.5 x 0.8: 64 and 128 never run
+    now.update(t=0.0); calls.clear()
+    cost.update({8: 3.0, 16: 2.9, 32: 2.8})
+    best, log = bench.thread_scan(probe, [8, 16, 32, 64], lambda n: now.update(nt=n), clock=lambda: now["t"], cap_s=5.0)
+    assert calls == [8, 16] and best == 16                                                    # the cap ends the scan

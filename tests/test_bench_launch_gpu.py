@@ -26,8 +26,9 @@ def test_gpus_2_without_a_launcher_starts_its_own_ranks():
     """Two ranks on this box's ONE GPU over gloo (a bookkeeping rehearsal: the collectives' data is staged through the host): the line
     says n_gpus 2, the process group saw 2 ranks, every rank's record is there, and the gathered rows checksum."""
     lines, res = _run("--gpus", "2", "--backend", "gloo", "--gather", "expand", *SMALL)
-    assert len(lines) == 1, res.stdout[-2000:]
-    d = json.loads(lines[0])
+    assert len(lines) == 2, res.stdout[-2000:]                             # the early headline line, then the complete one (last)
+    early, d = json.loads(lines[0]), json.loads(lines[-1])
+    assert early["partial"] is True and d["partial"] is False and early["value"] == d["value"] and early["roofline"] == d["roofline"]
     cfg = d["config"]
     assert d["n_gpus"] == 2 and cfg["world_size_seen"] == 2 and cfg["backend"] == "gloo" and cfg["launcher"] == "self"
     assert cfg["gather"] == "expand" and cfg["gather_checksum_ok"] is True
@@ -54,3 +55,18 @@ def test_an_optional_leg_that_raises_does_not_cost_the_headline(leg):
         assert "injected failure" in d["mixed_precision"]["errors"]["bf16x6"] and d["mixed_precision"]["bf16x6"]["value"] is None
         assert d["mixed_precision"]["value"] > 0 and d["column_sharing"]["value"] > 0
     assert "device_unusable_after_optional_leg" not in d
+
+
+def test_a_tiny_budget_skips_the_legs_and_both_lines_are_still_printed():
+    """`--budget-s` smaller than what the set-up alone takes -- every optional leg AND the cpu_baseline leg are skipped (listed in
+    `legs_skipped`), the headline is printed twice (early, then complete as the last line) with the same value."""
+    small = [x for x in SMALL if x not in ("--no-cpu-baseline", "--no-host-io", "--no-surface")]
+    lines, res = _run("--gpus", "1", "--budget-s", "1", *small)
+    assert len(lines) == 2
+    early, d = json.loads(lines[0]), json.loads(lines[-1])
+    assert early["partial"] is True and d["partial"] is False and early["value"] == d["value"] > 0 and d["roofline"]["frac"] > 0
+    skipped = [s["leg"] for s in d["legs_skipped"]]
+    assert skipped == ["cpu_baseline", "column_sharing", "bf16x3", "bf16x3_attention", "bf16x6", "bf16x3_column_sharing", "with_h2d_d2h", "surface"]
+    assert d["cpu_baseline"]["value"] is None and "did not fit" in d["cpu_baseline"]["sample"]
+    assert "column_sharing" not in d and "surface" not in d and d["mixed_precision"]["value"] is None
+    assert d["wall_clock"]["budget_s"] == 1.0 and d["wall_clock"]["legs_s"] == {}

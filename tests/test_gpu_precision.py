@@ -347,12 +347,15 @@ def test_dgrad_pca_expansion_on_split_bf16(eng, golden):
         c0, o0 = eng.regress(z, spk, want_coef=True)
         o0 = o0.clone()
         _lib.set_option("pca_fp32", 0)
-        c1, o1 = eng.regress(z, spk, want_coef=True)
+        # the split-bf16 kernel writes into a buffer pre-filled with NaN: an element it skipped (ragged frame tile, last partial triangle
+        # block) stays NaN instead of silently keeping the exact row a previous call left in a reused output buffer
+        sentinel = torch.full_like(o0, float("nan"))
+        c1, o1 = eng.regress(z, spk, want_coef=True, out=sentinel)
+        assert o1.data_ptr() == sentinel.data_ptr()
         assert torch.equal(c0, c1)
-        d = float((o0 - o1).abs().max())
-        assert 0.0 < d <= 2e-5, d
-        # every column of every row was written by the bf16 kernel: no stale / unwritten element (compare against the exact expansion)
-        assert float((o0 - o1).abs().max(dim=0).values.min()) >= 0.0 and bool(torch.isfinite(o1).all())
+        assert bool(torch.isfinite(o1).all()), "pca_dgrad_res_kernel<true> left elements unwritten"
+        d = (o0 - o1).abs()
+        assert 0.0 < float(d.max()) <= 2e-5, float(d.max())
         rows = eng.expand_coef(c1)
         assert torch.equal(rows, o1)
     finally:
