@@ -499,7 +499,7 @@ def precision_worst_case():
 def attention_counter_util(mode="fp32"):
     """Time-weighted rocprofv3 MfmaUtil of the attention stage in precision `mode` (profiles/r*_pmc/attention_mfma.json for fp32,
     attention_mfma_<mode>.json for a configs[3] mode; written by profiles/pmc_summary.py from the committed --pmc pass of that mode),
-    or None when absent or csrc/attn.hip / csrc/gemm.hip have changed since."""
+    or None when absent or csrc/attn.hip / csrc/gemm.hip have changed since.  Returns (whole stage %, source, the stage's MFMA kernels alone %)."""
     import glob
     try:
         name = "attention_mfma.json" if mode == "fp32" else f"attention_mfma_{mode}.json"
@@ -507,10 +507,11 @@ def attention_counter_util(mode="fp32"):
         with open(path) as f:
             t = json.load(f)
         if t.get("attn_hip_sha1") != _sha1("attn.hip") or t.get("gemm_hip_sha1") != _sha1("gemm.hip"):
-            return None, None
-        return float(t["mfma_util_pct_time_weighted"]), os.path.relpath(path, ROOT)
+            return None, None, None
+        g = t.get("mfma_util_pct_gemms")        # the stage's MFMA kernels alone (without the softmax / context tail), from round 6
+        return float(t["mfma_util_pct_time_weighted"]), os.path.relpath(path, ROOT), (None if g is None else float(g))
     except Exception:
-        return None, None
+        return None, None, None
 
 
 def main():
@@ -822,11 +823,11 @@ def main():
         }
         # north_star: "MFMA utilisation on the attention stage against gfx950 peak" (target >= 40 %): key / query projections (MFMA GEMMs)
         # + the softmax / context tail (vector + HBM), live stage time and the counter figure of the committed pass
-        att_util, att_src = attention_counter_util("fp32") if a.precision == "fp32" else (None, None)
+        att_util, att_src, att_gemms = attention_counter_util("fp32") if a.precision == "fp32" else (None, None, None)
         att_ms = stages.get("attn_proj", 0.0) + stages.get("attn", 0.0)
         res["attention"] = {"ms": round(att_ms, 3), "flop_per_frame": FLOP_ATTENTION_PER_FRAME,
                             "frac_of_fp32_mfma_peak_by_flop": round(F * FLOP_ATTENTION_PER_FRAME / (att_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if att_ms > 0 else None,
-                            "mfma_util_pct_counters": att_util, "counters_source": att_src}
+                            "mfma_util_pct_counters": att_util, "mfma_util_pct_gemms_counters": att_gemms, "counters_source": att_src}
         res["peak_device_memory_gb"] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 2)
         res["wall_clock"] = dict(budget.report(), headline_at_s=round(budget.elapsed(), 1))
         emit(res, final=False)
@@ -1020,7 +1021,7 @@ def main():
             m3, m3s, ma, m6 = mixed["bf16x3"], mixed["bf16x3_column_sharing"], mixed["bf16x3_attention"], mixed["bf16x6"]
             # configs[3] as worded: the attention stage's MFMA utilisation IN the bf16 attention mode (committed --pmc pass of that mode,
             # nulled once csrc/attn.hip or csrc/gemm.hip change), next to the live stage time
-            ma_util, ma_src = attention_counter_util("bf16x3_attention")
+            ma_util, ma_src, ma_gemms = attention_counter_util("bf16x3_attention")
             ma_att_ms = None if ma is None else ma[1].get("attn_proj", 0.0) + ma[1].get("attn", 0.0)
             res["mixed_precision"] = {
                 "note": "BASELINE configs[3]: same workload with the conv stack, the frequency LSTM, the BiLSTM recurrences and every GEMM "
@@ -1034,7 +1035,8 @@ def main():
                                      "attn_proj_ms_per_step": None if ma is None else round(ma[1].get("attn_proj", 0.0), 3),
                                      "attn_proj_ms_per_step_fp32": round(stages.get("attn_proj", 0.0), 3),
                                      "attention_stage_ms_per_step": None if ma_att_ms is None else round(ma_att_ms, 3),
-                                     "mfma_util_pct_counters": ma_util, "counters_source": ma_src},
+                                     # whole stage (GEMMs + key-projection / score kernel + softmax / context tail), and its MFMA kernels alone
+                                     "mfma_util_pct_counters": ma_util, "mfma_util_pct_gemms_counters": ma_gemms, "counters_source": ma_src},
                 "bf16x6": {"note": "six-product split: operands as three bf16 terms (24 significand bits), six v_mfma_f32_32x32x16_bf16 per product, "
                                    "the same stages as bf16x3: fp32-equivalent products at 16 / 6 of the fp32 MFMA rate",
                            "value": rate(m6), "unit": "frames/s", "ms_per_step": ms(m6), "stage_ms_per_step": st(m6)}}

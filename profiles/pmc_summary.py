@@ -101,7 +101,36 @@ def attention_stage(path):
     return (sum(u * t for _, u, t in picked) / tot if tot else None), tot, per
 
 
+def attention_json(csv_path, out_path, label, mode="fp32"):
+    """Writes the attention-stage record bench.py reads (attention_counter_util): the whole stage time-weighted, and the stage's MFMA
+    kernels alone (everything but the softmax / context tail attn_kernel) -- VERDICT r5 asks for the latter in the bf16 attention mode."""
+    util, ns, per = attention_stage(csv_path)
+    if util is None:
+        return None
+    gem = [e for e in per if not e["kernel"].startswith("attn_kernel")]
+    gns = sum(e["ns"] for e in gem)
+    gutil = sum(e["mfma_util_pct"] * e["ns"] for e in gem) / gns if gns else None
+    print()
+    print(f"attention stage, precision {mode} (after the second BiLSTM recurrence .. attn_kernel), one step: {ns / 1e6:.3f} ms under the counter pass, "
+          f"time-weighted MfmaUtil {util:.1f} % (its MFMA kernels alone: {gutil:.1f} % over {gns / 1e6:.3f} ms)")
+    for e in per:
+        print(f"  {e['kernel'][:60]:60s} calls {e['calls']:3d}  MfmaUtil {e['mfma_util_pct']:5.1f} %  {e['ns'] / 1e6:7.3f} ms")
+    json.dump({"precision": mode, "mfma_util_pct_time_weighted": round(util, 2), "stage_ns_under_counters": ns,
+               "mfma_util_pct_gemms": None if gutil is None else round(gutil, 2), "gemms_ns_under_counters": gns, "kernels": per,
+               "attn_hip_sha1": file_sha1("attn.hip"), "gemm_hip_sha1": file_sha1("gemm.hip"),
+               "source": f"rocprofv3 --pmc MfmaUtil pass ({label}), one step of the headline workload in precision {mode}; every dispatch between a launch "
+                         "group's second time_lstm launch and its attn_kernel, weighted by its duration in that pass; mfma_util_pct_gemms leaves "
+                         "out attn_kernel (softmax + context: vector work and the H stream, no matrix instructions)"},
+              open(out_path, "w"), indent=1)
+    return util
+
+
 def main():
+    if "--attention-only" in sys.argv:      # pmc_summary.py --attention-only <MfmaUtil csv> <out json> <precision mode> [label]
+        i = sys.argv.index("--attention-only")
+        csv_path, out, mode = sys.argv[i + 1:i + 4]
+        attention_json(csv_path, out, sys.argv[i + 4] if len(sys.argv) > i + 4 else os.path.basename(os.path.dirname(os.path.abspath(csv_path))), mode)
+        return
     d = sys.argv[1]
     M, F, W = (load(os.path.join(d, f"{c}_counter_collection.csv")) for c in ("MfmaUtil", "FETCH_SIZE", "WRITE_SIZE"))
     print(f"{'kernel':46s} {'grid':>10s} {'calls':>5s} {'MfmaUtil %':>10s} {'FETCH KiB raw':>14s} {'read GB (x2)':>13s} {'write GB':>10s}")
@@ -139,17 +168,7 @@ def main():
                                  f"{names} (the full batch); FETCH_SIZE doubled per MI355X_MICROARCH.md"},
                       open(sys.argv[sys.argv.index("--frontend-json") + 1], "w"), indent=1)
     if "--attention-json" in sys.argv:
-        util, ns, per = attention_stage(os.path.join(d, "MfmaUtil_counter_collection.csv"))
-        if util is not None:
-            print()
-            print(f"attention stage (after the second BiLSTM recurrence .. attn_kernel), one step: {ns / 1e6:.3f} ms under the counter pass, time-weighted MfmaUtil {util:.1f} %")
-            for e in per:
-                print(f"  {e['kernel'][:60]:60s} calls {e['calls']:3d}  MfmaUtil {e['mfma_util_pct']:5.1f} %  {e['ns'] / 1e6:7.3f} ms")
-            json.dump({"mfma_util_pct_time_weighted": round(util, 2), "stage_ns_under_counters": ns, "kernels": per,
-                       "attn_hip_sha1": file_sha1("attn.hip"), "gemm_hip_sha1": file_sha1("gemm.hip"),
-                       "source": f"rocprofv3 --pmc MfmaUtil pass ({os.path.basename(os.path.normpath(d))}), one step of the headline workload; every dispatch between a launch "
-                                 "group's second time_lstm launch and its attn_kernel, weighted by its duration in that pass"},
-                      open(sys.argv[sys.argv.index("--attention-json") + 1], "w"), indent=1)
+        attention_json(os.path.join(d, "MfmaUtil_counter_collection.csv"), sys.argv[sys.argv.index("--attention-json") + 1], os.path.basename(os.path.normpath(d)))
     if "--traffic-json" in sys.argv:
         key = max((k for k in M if k[0].startswith(("freq_lstm_v3_kernel<false, false", "freq_lstm_v2_kernel<false, false", "freq_lstm_kernel<false"))),
                   key=lambda k: (k[0].startswith("freq_lstm_v3"), k[0].startswith("freq_lstm_v2"), k[1]))      # hardware-dispatched forms: grid = tiles

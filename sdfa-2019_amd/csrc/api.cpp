@@ -878,7 +878,9 @@ thread_local int g_sdfa_time_lstm_split = 0;
 thread_local int g_sdfa_time_lstm_handoff = 0;
 thread_local int g_sdfa_time_lstm_timeout_us = 0;
 thread_local int g_sdfa_share_gx0_off = 0;
+thread_local int g_sdfa_attn_unfused = 0;  // "attn_unfused": 1 = the bf16 attention modes keep the three-GEMM + attn_kernel form of round 5 (A/B)
 int sdfa_debug_set_option(const char *name, int value) {
+    if (name && !strcmp(name, "attn_unfused")) { g_sdfa_attn_unfused = value; return SDFA_OK; }
     if (name && !strcmp(name, "share_gx0_off")) { g_sdfa_share_gx0_off = value; return SDFA_OK; }
     if (name && !strcmp(name, "frontend_two_kernel")) { g_sdfa_frontend_two_kernel = value; return SDFA_OK; }
     if (name && !strcmp(name, "frontend_stream_phases")) { g_sdfa_frontend_stream_phases = value; return SDFA_OK; }
@@ -1127,12 +1129,17 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
             xin = hout[l];
         }
         // attention: proj_key over all 64 keys, Conv1d query over time steps 31..33, proj_qry
+        const int at_terms = stage_terms(m, STAGE_ATTENTION);
+        // bf16 attention modes (BASELINE configs[3]): the key projection never leaves the matrix core's accumulators -- one HBM-bound
+        // streaming pass over the BiLSTM output computes projection + tanh + v-dot and writes one score per column (attn.hip:
+        // attn_key_score_kernel); attn_kernel then does softmax + context from the scores.  The query path runs first.
+        const bool key_fused = (at_terms == 1 || at_terms == 3) && !g_sdfa_attn_unfused;
         pf.begin("attn_proj");
         GemmArgs gk{};
         gk.P = m->kp_w; gk.Q = ws + w.H1; gk.D = ws + w.KP;
         gk.ldp = 128; gk.ldq = Mc; gk.ldd = Mc; gk.Ppad = 128; gk.Qpad = Mc; gk.Pstore = 128; gk.Qreal = Mc;
-        gk.K = 512; gk.seg_k = 512; gk.act = ACT_NONE; gk.out_mode = OUT_K4; gk.terms = stage_terms(m, STAGE_ATTENTION);
-        HIP_TRY(sdfa_launch_gemm(gk, s));
+        gk.K = 512; gk.seg_k = 512; gk.act = ACT_NONE; gk.out_mode = OUT_K4; gk.terms = at_terms;
+        if (!key_fused) HIP_TRY(sdfa_launch_gemm(gk, s));
         GemmArgs gc{};
         gc.P = m->qc_w; gc.Q = ws + w.H1 + 31 * Nc * 4; gc.D = ws + w.QC;
         gc.ldp = 512; gc.ldq = Mc; gc.ldd = Nc; gc.Ppad = 512; gc.Qpad = Nc; gc.Pstore = 512; gc.Qreal = Nc;
@@ -1143,12 +1150,20 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
         gq.ldp = 128; gq.ldq = Nc; gq.ldd = Nc; gq.Ppad = 128; gq.Qpad = Nc; gq.Pstore = 128; gq.Qreal = Nc;
         gq.K = 512; gq.seg_k = 512; gq.act = ACT_NONE; gq.out_mode = OUT_K4; gq.terms = gk.terms;
         HIP_TRY(sdfa_launch_gemm(gq, s));
+        if (key_fused) {
+            AttnKeyArgs ak{};
+            ak.Wk = m->kp_w; ak.H = ws + w.H1; ak.QP = ws + w.QP; ak.v = m->at_v; ak.b = m->at_b;
+            ak.S = ws + w.KP;                                  // the partial scores take the first 8 Mc floats of the (unused) key-projection region
+            ak.Nc = Nc; ak.Mc = Mc; ak.terms = at_terms; ak.reserve_cus = m->reserved_cus.load();
+            HIP_TRY(sdfa_launch_attn_key_score(ak, s));
+        }
         pf.end();
 
         AttnArgs aa{};
         aa.KP = ws + w.KP; aa.QP = ws + w.QP; aa.H = ws + w.H1; aa.v = m->at_v; aa.b = m->at_b;
         aa.Zk4 = ws + w.ZK; aa.z_out = d_z + f0 * 512; aa.align_out = d_align ? d_align + f0 * 64 : nullptr;
         aa.N = N; aa.Nc = Nc; aa.Mc = Mc;
+        aa.S = key_fused ? ws + w.KP : nullptr;
         pf.begin("attn"); HIP_TRY(sdfa_launch_attn(aa, s)); pf.end();
     }
     return SDFA_OK;

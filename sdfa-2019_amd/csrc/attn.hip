@@ -15,11 +15,15 @@
 //   context: the 64 weights of a frame go through LDS once; wave w / part p accumulates feature quads 32w+8p .. +7.
 #include "common.h"
 #include "kernels.h"
+#include <algorithm>
 
 namespace {
 
 constexpr int ATT_FR = 16;   // frames per workgroup
 
+// GIVEN: the scores were written by attn_key_score_kernel (a.S, [t * Nc + n]); the key projections are never materialised and
+// a.KP / a.QP are not read.
+template <bool GIVEN>
 __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
     __shared__ float sAlign[64][ATT_FR];     // [t][frame]
     __shared__ float2 sStat[4][ATT_FR];      // per wave: (max, sum of exp) over its 16 time steps
@@ -33,7 +37,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
 
     // ---- scores: this quarter wave sums units 32p .. 32p+31 (quads 8p .. 8p+7)
     float sc[16];
-    {
+    if constexpr (GIVEN) {
+        // eight partial scores per column (one per wave of attn_key_score_kernel), added in a fixed order
+        const float4 *__restrict__ S = reinterpret_cast<const float4 *>(a.S) + ((int64_t)(16 * wave) * a.Nc + n) * 2;
+#pragma unroll
+        for (int tt = 0; tt < 16; ++tt) {                      // the four quarters of a wave read the same words
+            const float4 p0 = S[(int64_t)tt * a.Nc * 2], p1 = S[(int64_t)tt * a.Nc * 2 + 1];
+            sc[tt] = ((p0.x + p0.y) + (p0.z + p0.w)) + ((p1.x + p1.y) + (p1.z + p1.w));
+        }
+    } else {
         float4 qb[8], vv[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -106,6 +118,219 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Key projection + scores of the bf16 attention modes (BASELINE configs[3]: "bf16 attention with MFMA"), one streaming pass over H:
+//     score[t, n] = v . tanh(Wk x[:, t, n] + qp[:, n] + b)            (speech_anime/layers/attentions.py:107-121)
+// The projection is 128 outputs x 512 features over 64 * Nc columns: 192 FLOP per byte of H in the three-product split, under the
+// chip's ~400 FLOP per HBM byte -- an HBM-bound kernel whose only large operand is H itself.  So:
+//   * the WEIGHTS live in registers for the whole launch: eight waves, wave w owns outputs 16w .. 16w+15 as v_mfma_f32_16x16x32_bf16
+//     A fragments, 16 k-steps x (hi, lo) = 128 VGPRs, two waves per SIMD -- one wave's MFMAs run under the other's vector work (a
+//     first form with four waves of 32 outputs measured 0.62 ms of serial instruction issue per step for 0.2 ms of MFMAs);
+//   * the grid is persistent (one workgroup per CU) over work units of (16 frames) x (a range of time steps); the unit's tiles --
+//     16 columns x 512 features = 32 KiB of H each -- travel HBM -> LDS by LDS-DMA into a ring of five slots, three tiles in flight
+//     behind the one being split (no staging registers: with 256 registers of weights the allocator had no room left for register sets
+//     in flight and copied them at the loop's back edge behind a full vmcnt(0)).  The DMA requests are inline assembly, invisible to
+//     the compiler's waitcnt bookkeeping (which puts a vmcnt(0) in front of any LDS read while a DMA it knows of is in flight), and
+//     are waited for by hand with counted vmcnt;
+//   * a landed tile is split into bf16 planes once per workgroup, IN PLACE: the thread that owns octet o of column c reads the two
+//     fp32 quads (2o, 2o + 1) of that column and writes the hi octet over the first and the lo octet over the second (one
+//     ds_read_b128 = one B fragment; every wave reads the same planes) -- no plane buffers, the whole LDS is ring.  The split of tile
+//     i + 1 is spread between the MFMAs of tile i;
+//   * the 128 x 16 key projections never leave the accumulators: + qp + b, tanh, the dot product with v and the sum over the wave's
+//     32 outputs happen in registers, and each wave writes ITS partial score per column (attn_kernel adds the four in a fixed order) --
+//     instead of 512 bytes of key projection per column written here and read again by attn_kernel.
+// One workgroup barrier per tile.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int KS_COLS = 16;                                   // columns per tile = one MFMA column block
+constexpr int KS_RING = 5;                                    // ring slots of 32 KiB: all 160 KiB of LDS
+constexpr size_t ks_lds_bytes(int) { return (size_t)KS_RING * 128 * KS_COLS * 16; }
+
+__device__ __forceinline__ void ks_split8(const float4 &x0, const float4 &x1, bf16x8 &hi, bf16x8 &lo) {
+    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 hb = (__bf16)x[e];
+        hi[e] = hb;
+        lo[e] = (__bf16)(x[e] - (float)hb);
+    }
+}
+
+#ifndef SDFA_KS_EXP
+#define SDFA_KS_EXP 0      /* timing experiments only (make EXP=KS_EXP EXPVAL=n; wrong results by design): 1 no MFMAs, 2 no DMA, 3 no split, 4 no tanh */
+#endif
+
+template <int TERMS>
+__global__ __launch_bounds__(512, 2) void attn_key_score_kernel(AttnKeyArgs a) {
+    constexpr bool LO = TERMS > 1;
+    constexpr int SLOT = 128 * KS_COLS;                       // 16-byte cells per ring slot
+    extern __shared__ float4 sRing[];                         // [KS_RING][128 quads][16 columns]: fp32 tiles as the DMA writes them, then
+                                                              // [64 octets][hi | lo][16 columns] bf16x8 once split in place
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kg = lane >> 4;
+    const int c = tid & 15, pr = tid >> 4;                    // splitting: column c, octets pr and pr + 32 of the tile
+    const float4 *__restrict__ H4 = reinterpret_cast<const float4 *>(a.H);
+    const float4 *__restrict__ QP4 = reinterpret_cast<const float4 *>(a.QP);
+    const int64_t Mc = a.Mc, Nc = a.Nc;
+    const int G = gridDim.x;
+    const int ts_shift = a.ts_shift, TT = 64 >> ts_shift;    // a unit = 16 frames x TT time steps
+    const int n_units = (int)(Nc / KS_COLS) << ts_shift;
+
+    // ---- this wave's 16 rows of proj_key as A fragments, for the whole launch: lane (row 16w + l15, k group kg) of k-step s holds
+    // Wk[row][32 s + 8 kg .. + 7]
+    bf16x8 wh[16], wl[16];
+    {
+        const float4 *__restrict__ W4 = reinterpret_cast<const float4 *>(a.Wk) + 16 * wave + l15;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float4 w0 = W4[(int64_t)(2 * (4 * s + kg)) * 128], w1 = W4[(int64_t)(2 * (4 * s + kg) + 1) * 128];
+            bf16x8 lo;
+            ks_split8(w0, w1, wh[s], lo);
+            if (LO) wl[s] = lo;
+        }
+    }
+    // epilogue constants: accumulator register r is output 16w + 4 kg + r, i.e. quad 4w + kg
+    const float4 vv = ld4(a.v + (4 * wave + kg) * 4), bb = ld4(a.b + (4 * wave + kg) * 4);
+
+    // LDS-DMA of one tile: 32 requests of 1 KiB (4 quad rows x 16 columns x 16 B), wave w issues requests w, w + 8, w + 16, w + 24: lane
+    // l of request j reads quad 4j + (l >> 4), column l & 15 and lands at slot + j KiB + 16 l.  Scalar 64-bit base + one loop-invariant
+    // 32-bit lane offset (global_load_lds saddr form); M0 = LDS byte address of the request.
+    const unsigned voff = (unsigned)(((int64_t)kg * Mc + l15) * 16);
+    const unsigned ring_lds = (unsigned)(uintptr_t)sRing;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);  // provably wave-uniform: the request's base and M0 must be scalar registers
+#define KS_DMA1(slot, j, gcol)                                                                       \
+    if (SDFA_KS_EXP != 2) {                                                                          \
+        const char *gb = reinterpret_cast<const char *>(H4 + (int64_t)(4 * (j)) * Mc + (gcol));     \
+        const unsigned la = ring_lds + (unsigned)(((slot) * 32 + (j)) * 1024);                      \
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(la), "v"(voff), "s"(gb) : "memory"); \
+    }
+#define KS_SB() __builtin_amdgcn_sched_barrier(0);
+#define KS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    float *__restrict__ Sw = a.S + wave;                       // partial scores: [column][8 waves]
+
+    for (int u = blockIdx.x; u < n_units; u += G) {
+        const int f = u >> ts_shift, tb = u & ((1 << ts_shift) - 1);
+        const int64_t col0 = (int64_t)(tb * TT) * Nc + (int64_t)f * KS_COLS;      // first column of the unit's first tile; the next tile is Nc columns on
+        // the unit's query projections (+ b): a plain load, waited for HERE (builtin wait: the compiler's bookkeeping sees it) -- the ring
+        // is empty at this point, later it would drain the tiles in flight
+        float4 qb;
+        {
+            const float4 q0 = QP4[(int64_t)(4 * wave + kg) * Nc + f * KS_COLS + l15];
+            __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0)
+            qb = make_float4(q0.x + bb.x, q0.y + bb.y, q0.z + bb.z, q0.w + bb.w);
+        }
+        KS_SB()
+        // every wave is past the previous unit's last MFMA read (its last barrier), so the ring is free.  Tiles 0 .. 3 -> slots 0 .. 3.
+#pragma unroll
+        for (int k = 0; k < KS_RING - 1; ++k)
+            if (k < TT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) KS_DMA1(k, wave_u + 8 * r, col0 + (int64_t)k * Nc)
+            }
+        // tile 0: landed -> split in place, not overlapped (once per unit)
+        if (TT >= KS_RING - 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        KS_BARRIER()
+        {
+            float4 *rs = sRing + (2 * pr) * KS_COLS + c;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float4 xa = rs[(64 * q) * KS_COLS], xb = rs[(64 * q + 1) * KS_COLS];
+                bf16x8 hi, lo;
+                ks_split8(xa, xb, hi, lo);
+                *reinterpret_cast<bf16x8 *>(rs + (64 * q) * KS_COLS) = hi;
+                if (LO) *reinterpret_cast<bf16x8 *>(rs + (64 * q + 1) * KS_COLS) = lo;
+            }
+        }
+        // tile 1 must have landed before the loop's first trip splits it
+        if (TT >= KS_RING - 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        KS_BARRIER()
+        int slot = 0;                                         // ring slot of tile i
+        for (int i = 0; i < TT; ++i) {
+            // the slot tile i - 1 left at the end of the previous trip takes tile i + 4
+            const bool more = i + KS_RING - 1 < TT;
+            const int64_t gnext = col0 + (int64_t)(i + KS_RING - 1) * Nc;
+            const int slotp = slot == 0 ? KS_RING - 1 : slot - 1, slot1 = slot == KS_RING - 1 ? 0 : slot + 1;
+            f32x4 acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = 0.f;
+            // B fragments one k-step ahead of the MFMAs that use them; between the k-steps: the four DMA requests of tile i + 4 (every
+            // fourth step) and the in-place split of tile i + 1 -- octet q = s >> 3 of this thread: s & 7 == 0 read the two quads,
+            // 2 hi plane, 4 lo plane, 6 store both.  The SIMD's other wave fills the gaps with its own MFMAs.
+            const bf16x8 *rd = reinterpret_cast<const bf16x8 *>(sRing + (size_t)slot * SLOT) + (2 * kg) * KS_COLS + l15;
+            float4 *rs = sRing + (size_t)slot1 * SLOT + (2 * pr) * KS_COLS + c;
+            bf16x8 bh[2], bl[2], shi, slo;
+            float4 xa, xb;
+            bh[0] = rd[0];
+            if (LO) bl[0] = rd[KS_COLS];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                KS_SB()
+                if (s + 1 < 16) {
+                    bh[(s + 1) & 1] = rd[(8 * (s + 1)) * KS_COLS];
+                    if (LO) bl[(s + 1) & 1] = rd[(8 * (s + 1) + 1) * KS_COLS];
+                }
+                if ((s & 3) == 1 && more) KS_DMA1(slotp, wave_u + 8 * (s >> 2), gnext)
+                if (SDFA_KS_EXP != 3) {
+                    const int q = s >> 3;
+                    if ((s & 7) == 0) { xa = rs[(64 * q) * KS_COLS]; xb = rs[(64 * q + 1) * KS_COLS]; }
+                    if ((s & 7) == 2) {
+                        const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) shi[e] = (__bf16)x[e];
+                    }
+                    if ((s & 7) == 4 && LO) {
+                        const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) slo[e] = (__bf16)(x[e] - (float)shi[e]);
+                    }
+                    if ((s & 7) == 6) {
+                        *reinterpret_cast<bf16x8 *>(rs + (64 * q) * KS_COLS) = shi;
+                        if (LO) *reinterpret_cast<bf16x8 *>(rs + (64 * q + 1) * KS_COLS) = slo;
+                    }
+                }
+                KS_SB()
+                if (SDFA_KS_EXP != 1) {
+                    if (LO) {
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[s], bh[s & 1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], bl[s & 1], acc, 0, 0, 0);
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], bh[s & 1], acc, 0, 0, 0);
+                }
+            }
+            KS_SB()
+            float part;
+            if (SDFA_KS_EXP == 4) part = acc[0] + acc[1] + acc[2] + acc[3];
+            else {
+                part = vv.x * tanhf_acc(acc[0] + qb.x);
+                part += vv.y * tanhf_acc(acc[1] + qb.y);
+                part += vv.z * tanhf_acc(acc[2] + qb.z);
+                part += vv.w * tanhf_acc(acc[3] + qb.w);
+            }
+            part += __shfl_xor(part, 16);
+            part += __shfl_xor(part, 32);
+            if (kg == 0) Sw[(col0 + (int64_t)i * Nc + l15) * 8] = part;
+            slot = slot1;
+            // end of the trip: tile i + 1 is split once every wave is here, and tile i + 2 must have landed for the next trip's split.
+            // vmcnt retires in order and counts this wave's score stores too: behind tile i + 2's requests came the store of trip i - 2,
+            // tile i + 3's four requests, the store of trip i - 1, tile i + 4's four, this trip's store = 11 operations that may stay out
+            // (the first two trips have fewer stores behind them; a count too LARGE would let the split read a tile that is not there,
+            // one too small waits for a request issued a few hundred cycles ago -- an HBM round trip per tile).  The last tiles of a
+            // unit, with no requests behind them, drain.
+            if (i + KS_RING - 1 < TT) {
+                if (i >= 2) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+                else if (i == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            KS_BARRIER()
+        }
+    }
+#undef KS_DMA1
+#undef KS_SB
+#undef KS_BARRIER
+}
+
 // row-major [n][F] -> K4 [F/4][ld]; columns n >= N are zero-filled
 __global__ void rows_to_k4_kernel(const float *__restrict__ src, int64_t N, int F, float *__restrict__ dst, int64_t ld) {
     const int64_t n = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
@@ -170,7 +395,32 @@ __global__ void tap_kernel(const float *__restrict__ src, int what, int64_t N, i
 }  // namespace
 
 hipError_t sdfa_launch_attn(const AttnArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(attn_kernel, dim3((unsigned)(a.Nc / ATT_FR)), dim3(256), 0, s, a);
+    if (a.S) hipLaunchKernelGGL(attn_kernel<true>, dim3((unsigned)(a.Nc / ATT_FR)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(attn_kernel<false>, dim3((unsigned)(a.Nc / ATT_FR)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t sdfa_launch_attn_key_score(const AttnKeyArgs &a, hipStream_t s) {
+    if ((a.terms != 1 && a.terms != 3) || a.Nc % 128 || a.Mc != 64 * a.Nc || 3 * a.Mc * 16 + 256 >= ((int64_t)1 << 32)) return hipErrorInvalidValue;
+    // work units: (16 frames) x (64 >> ts_shift time steps); enough of them to give every CU two where the batch allows, never fewer
+    // than eight time steps per unit (the ring is five tiles deep)
+    const int cus = std::max(1, sdfa_cu_count() - a.reserve_cus);
+    AttnKeyArgs b = a;
+    b.ts_shift = 0;
+    while (b.ts_shift < 3 && ((a.Nc / KS_COLS) << b.ts_shift) < 2 * (int64_t)cus) ++b.ts_shift;
+    const int64_t n_units = (a.Nc / KS_COLS) << b.ts_shift;
+    const int grid = (int)std::min<int64_t>(n_units, cus);
+    const size_t lds = ks_lds_bytes(a.terms);
+    hipError_t e;
+    if (a.terms == 3) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_key_score_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(attn_key_score_kernel<3>, dim3(grid), dim3(512), lds, s, b);
+    } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_key_score_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(attn_key_score_kernel<1>, dim3(grid), dim3(512), lds, s, b);
+    }
     return hipGetLastError();
 }
 

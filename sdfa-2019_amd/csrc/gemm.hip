@@ -1197,12 +1197,17 @@ thread_local int g_sdfa_gemm_variant = 0;
 
 template <int OUT_MODE, int ACT, bool BIAS_P, bool BIAS_Q, bool COND>
 hipError_t launch_any(const GemmArgs &a, hipStream_t s) {
-    const int variant = (g_sdfa_gemm_variant == 2 || g_sdfa_gemm_variant == 6 || g_sdfa_gemm_variant == 10 || g_sdfa_gemm_variant == 11) ? 0 : g_sdfa_gemm_variant;   // 2 / 6 / 10 / 11 only steer the tile choice of the LDS-tiled kernel (launch)
-    if (a.terms == 6)      // six-product split: the 256 x 256 tile wherever it divides the problem ("gemm_variant" 7 = never)
-        return (a.Ppad % 256 == 0 && a.Qpad % 256 == 0 && a.K % 16 == 0 && variant != 7) ? launch_bf16x6_big<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s)
-                                                                                         : launch_bf16x6<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
+    const int variant = (g_sdfa_gemm_variant == 2 || g_sdfa_gemm_variant == 6 || g_sdfa_gemm_variant == 10 || g_sdfa_gemm_variant == 11) ? 0 : g_sdfa_gemm_variant;      // (12: split-bf16 tile choice, below)   // 2 / 6 / 10 / 11 only steer the tile choice of the LDS-tiled kernel (launch)
+    // split-bf16 kernels: the 256 x 256 tile wherever it divides the problem AND gives at least half the CUs a tile ("gemm_variant" 7 =
+    // never, 12 = whenever it divides): a launch of 64 such tiles -- the attention query Conv1d, the MLP layers, a single clip's
+    // frequency projection -- runs on a quarter of the chip for four times as long (106 us for the 1536-deep query conv of an
+    // 8192-frame chunk); four times as many 128 x 128 tiles do the same arithmetic in the same order per accumulator (bit-identical)
+    const bool big_fills_half = variant == 12 || (a.Ppad / 256) * (a.Qpad / 256) * 2 >= sdfa_cu_count();
+    if (a.terms == 6)      // six-product split
+        return (a.Ppad % 256 == 0 && a.Qpad % 256 == 0 && a.K % 16 == 0 && variant != 7 && big_fills_half) ? launch_bf16x6_big<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s)
+                                                                                                           : launch_bf16x6<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND>(a, s);
     if (a.terms) {   // mixed-precision modes
-        const bool big = a.Ppad % 256 == 0 && a.Qpad % 256 == 0 && variant != 7;
+        const bool big = a.Ppad % 256 == 0 && a.Qpad % 256 == 0 && variant != 7 && big_fills_half;
         if (a.terms == 1) return big ? launch_bf16_big<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 1>(a, s) : launch_bf16<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 1>(a, s);
         return big ? launch_bf16_big<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 3>(a, s) : launch_bf16<OUT_MODE, ACT, BIAS_P, BIAS_Q, COND, 3>(a, s);
     }

@@ -153,8 +153,23 @@ struct AttnArgs {
     float *z_out;        // [N][512] row-major (may be null)
     float *align_out;    // [N][64]  row-major (may be null)
     int64_t N, Nc, Mc;
+    const float *S;      // [Mc][8] partial scores written by attn_key_score_kernel (then KP / QP / v / b are not read); null = computed here from KP
 };
 hipError_t sdfa_launch_attn(const AttnArgs &a, hipStream_t s);
+
+// bf16 attention modes: key projection + scores in one streaming pass over H (attn.hip: attn_key_score_kernel)
+struct AttnKeyArgs {
+    const float *Wk;     // K4 [512/4][128]  proj_key weights, as the GEMM takes them
+    const float *H;      // K4 [512/4][Mc]   BiLSTM output
+    const float *QP;     // K4 [128/4][Nc]   query projection
+    const float *v, *b;  // [128]
+    float *S;            // out [Mc][8]  partial score (outputs 16w .. 16w+15) of column m = t * Nc + n per wave w
+    int64_t Nc, Mc;
+    int terms;           // 1 = bf16 operands, 3 = split-bf16
+    int reserve_cus;
+    int ts_shift;        // set by the launcher: a work unit is 16 frames x (64 >> ts_shift) time steps
+};
+hipError_t sdfa_launch_attn_key_score(const AttnKeyArgs &a, hipStream_t s);
 
 // ---- layout helpers --------------------------------------------------------------------------
 // row-major [n][F] (n < N) -> K4 [F/4][ld]  (zero for n >= N), and back

@@ -23,12 +23,14 @@ def test_counter_figures_are_nulled_when_the_kernel_source_changed(tmp_path, mon
     (prof / "freq_lstm_traffic.json").write_text(json.dumps({"frames": 8192, "traffic_bytes": 1000, "algorithmic_bytes": 800, "lstm_hip_sha1": "L"}))
     (prof / "frontend_traffic.json").write_text(json.dumps({"bytes_per_frame": 164000.0, "frontend_hip_sha1": "F"}))
     (prof / "attention_mfma.json").write_text(json.dumps({"mfma_util_pct_time_weighted": 50.6, "attn_hip_sha1": "A", "gemm_hip_sha1": "G"}))
+    (prof / "attention_mfma_bf16x3_attention.json").write_text(json.dumps({"mfma_util_pct_time_weighted": 21.5, "mfma_util_pct_gemms": 33.0, "attn_hip_sha1": "A", "gemm_hip_sha1": "G"}))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     sha = {"lstm.hip": "L", "frontend.hip": "F", "attn.hip": "A", "gemm.hip": "G"}
     monkeypatch.setattr(bench, "_sha1", lambda name: sha[name])
     assert bench.traffic_from_profile(4096)[:2] == (500, 400)                  # scaled to the frames of a launch
     assert bench.frontend_counter_bytes()[0] == 164000.0
-    assert bench.attention_counter_util()[0] == 50.6
+    assert bench.attention_counter_util()[0] == 50.6 and bench.attention_counter_util()[2] is None
+    assert bench.attention_counter_util("bf16x3_attention") == (21.5, os.path.join("profiles", "r99_pmc", "attention_mfma_bf16x3_attention.json"), 33.0)
     for changed in ("lstm.hip", "frontend.hip", "attn.hip", "gemm.hip"):
         sha2 = dict(sha, **{changed: "other"})
         monkeypatch.setattr(bench, "_sha1", lambda name, s=sha2: s[name])
@@ -36,6 +38,7 @@ def test_counter_figures_are_nulled_when_the_kernel_source_changed(tmp_path, mon
         assert (t is None and alg == 400 and "stale" in why) if changed == "lstm.hip" else t == 500
         assert (bench.frontend_counter_bytes()[0] is None) == (changed == "frontend.hip")
         assert (bench.attention_counter_util()[0] is None) == (changed in ("attn.hip", "gemm.hip"))
+        assert (bench.attention_counter_util("bf16x3_attention")[0] is None) == (changed in ("attn.hip", "gemm.hip"))
 
 
 def test_committed_counter_files_match_the_committed_kernels():

@@ -11,6 +11,8 @@ for M in $MODES; do
   rocprofv3 --pmc MfmaUtil --output-format csv -d $OUT/pmc_$M -o run -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-mixed-precision --no-column-sharing --no-host-io --no-surface --precision $M > $OUT/pmc_$M.json 2> $OUT/pmc_$M.err
   cp $(find $OUT/pmc_$M -name "*counter_collection.csv" | head -1) $OUT/MfmaUtil_$M.csv
   rm -rf $OUT/pmc_$M
+  # the attention stage of this mode (bench.py: mixed_precision.<mode>.mfma_util_pct_counters reads profiles/r*_pmc/attention_mfma_<mode>.json)
+  python3 $R/profiles/pmc_summary.py --attention-only $OUT/MfmaUtil_$M.csv $OUT/attention_mfma_$M.json $M $TAG > $OUT/attention_$M.txt 2>&1 || true
   python3 - <<PY
 import csv, collections
 rows = sorted(csv.DictReader(open("$OUT/MfmaUtil_$M.csv")), key=lambda r: int(r["Dispatch_Id"]))
@@ -31,4 +33,5 @@ for (name, grid), (n, w, t) in sorted(by.items(), key=lambda kv: -kv[1][2]):
     print(f"{name[:62]:62s} {grid:10d} {n:5d} {w / t:10.1f} {t / 1e6:9.3f}")
 PY
 done > $OUT/summary.txt 2>&1
+cat $OUT/attention_*.txt >> $OUT/summary.txt 2>/dev/null || true
 cat $OUT/summary.txt
