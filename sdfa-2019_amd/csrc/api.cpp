@@ -1086,8 +1086,11 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
             pf.begin("conv23"); HIP_TRY(sdfa_launch_conv123(ca, s)); pf.end();
         }
 
-        FreqLstmArgs fa{ws + w.X3, m->fl_w, m->fl_b, ws + w.HF, Mc, d_ulimit, m->fl_wb, stage_terms(m, STAGE_BODY), reinterpret_cast<int *>(ws + w.CT),
-                        g_sdfa_freq_lstm_shape ? g_sdfa_freq_lstm_shape : m->freq_shape.load(), m->reserved_cus.load()};
+        // launch form: the "freq_lstm_shape" option if set; else, for the fp32 kernel, what sdfa_model_autotune measured (the split-bf16
+        // kernels have their own default: the autotuned fp32 form says nothing about them)
+        const int fl_terms = stage_terms(m, STAGE_BODY);
+        FreqLstmArgs fa{ws + w.X3, m->fl_w, m->fl_b, ws + w.HF, Mc, d_ulimit, m->fl_wb, fl_terms, reinterpret_cast<int *>(ws + w.CT),
+                        g_sdfa_freq_lstm_shape ? g_sdfa_freq_lstm_shape : (fl_terms ? 0 : m->freq_shape.load()), m->reserved_cus.load()};
         pf.begin("freq_lstm"); HIP_TRY(sdfa_launch_freq_lstm(fa, s)); pf.end();
 
         GemmArgs g{};   // FreqLstm._proj: Linear(8192 -> 256) + bias
