@@ -177,7 +177,7 @@ int64_t sdfa_workspace_bytes(const sdfa_model *m, int64_t max_frames);
 /* Status block = the first SDFA_WS_STATUS_BYTES bytes of a workspace: counters the kernels only ever INCREMENT.
  *   word SDFA_WS_TIME_LSTM_REPAIRS  waits of the small-batch time-LSTM kernels that expired.  For a single clip the BiLSTM recurrence
  *       runs on pairs of cooperating workgroups that hand h to each other every step and wait for each other with a wall-clock
- *       bound (0.2 s; "time_lstm_timeout_us").  A wait can only expire when other work keeps a partner off the device for that
+ *       bound (20 ms; "time_lstm_timeout_us").  A wait can only expire when other work keeps a partner off the device for that
  *       long; the launch then marks itself and a repair pass that needs no co-residency recomputes the layer ON THE DEVICE, in
  *       stream order, before anything reads it -- a forward call never returns rows of a timed-out launch (the reference never
  *       returns partial results either: speech_anime/model/model.py:428-489).  The counter only says that it happened (a
@@ -293,7 +293,7 @@ int sdfa_ensemble_mean(const float *d_a, const float *d_b, int64_t n, float *d_o
  *   "time_lstm_handoff" how those workgroups publish / consume h: 0 = write-through (sc1) stores + sc1 loads (default); bit 0 = plain
  *                      stores + agent-scope release; bit 1 = agent-scope acquire + plain loads (the always-valid form, slower);
  *                      bit 2 (tests only) = the second workgroup of every pair never publishes, so every wait of the first expires
- *   "time_lstm_timeout_us" bound of one such wait in microseconds (0 = the default, 200,000)
+ *   "time_lstm_timeout_us" bound of one such wait in microseconds (0 = the default, 20,000: ten single-clip layers; an expiry is repaired on the device)
  *   "mel_fft_radix4"   1 = the 16 kHz column FFT as four LDS-staged radix-4 passes + a radix-2 pass (rounds 2-3) instead of three register-resident
  *                      radix-8 passes (NOT bit-identical: another order of additions; both inside the 5e-5 feature tolerance)
  *   "gather_plain_order" 1 = workgroup b of the feature gather takes frame b (rounds 2-3) instead of the XCD-aware chain order (same bits)

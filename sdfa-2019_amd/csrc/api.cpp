@@ -1136,7 +1136,9 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
         // bf16 attention modes (BASELINE configs[3]): the key projection never leaves the matrix core's accumulators -- one HBM-bound
         // streaming pass over the BiLSTM output computes projection + tanh + v-dot and writes one score per column (attn.hip:
         // attn_key_score_kernel); attn_kernel then does softmax + context from the scores.  The query path runs first.
-        const bool key_fused = (at_terms == 1 || at_terms == 3) && !g_sdfa_attn_unfused;
+        // fp32 (round 6, second half): the same pass on v_mfma_f32_16x16x4_f32 -- matrix-bound there, at the MFMA rate.  The six-product
+        // mode (fp32-equivalent products) takes the exact fp32 pass too: faster than six bf16 products through a GEMM, and exact.
+        const bool key_fused = !g_sdfa_attn_unfused;
         pf.begin("attn_proj");
         GemmArgs gk{};
         gk.P = m->kp_w; gk.Q = ws + w.H1; gk.D = ws + w.KP;
@@ -1157,7 +1159,7 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
             AttnKeyArgs ak{};
             ak.Wk = m->kp_w; ak.H = ws + w.H1; ak.QP = ws + w.QP; ak.v = m->at_v; ak.b = m->at_b;
             ak.S = ws + w.KP;                                  // the partial scores take the first 8 Mc floats of the (unused) key-projection region
-            ak.Nc = Nc; ak.Mc = Mc; ak.terms = at_terms; ak.reserve_cus = m->reserved_cus.load();
+            ak.Nc = Nc; ak.Mc = Mc; ak.terms = at_terms == 6 ? 0 : at_terms; ak.reserve_cus = m->reserved_cus.load();
             HIP_TRY(sdfa_launch_attn_key_score(ak, s));
         }
         pf.end();

@@ -331,6 +331,122 @@ __global__ __launch_bounds__(512, 2) void attn_key_score_kernel(AttnKeyArgs a) {
 #undef KS_BARRIER
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same pass in exact fp32 (the headline precision): v_mfma_f32_16x16x4_f32, eight waves, wave w owns outputs 16w .. 16w+15 with its
+// 16 x 512 slice of proj_key in 128 registers (lane (row, k group g) holds Wk[row][16 s + 4 g + c] as component c of quad register s:
+// MFMA 4 s + c contracts k = 16 s + 4 g + c, g = 0 .. 3), the B operand straight out of the ring -- the DMA's [quad][column] image IS
+// the fragment layout (lane (column, g) reads quad 4 s + g: one ds_read_b128 feeds four MFMAs), so there is no split pass and the ring
+// slots are read-only: five slots, four tiles in flight.  fp32 MFMA makes this pass MATRIX-bound (16 x fewer FLOP per cycle than
+// bf16: 8,192 cycles of MFMAs per tile and SIMD against 3,900 of HBM time), at the MFMA rate instead of the 128 x 128 GEMM's 0.78 of
+// it, and the key projections (0.67 GB per step written and read back) no longer exist.  A dot product's k order differs from the
+// GEMM's (two accumulators, even and odd quads), so the scores differ from round 5's in the last bits -- the parity bounds (align 1e-5
+// against the reference) are unchanged.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void attn_key_score_f32_kernel(AttnKeyArgs a) {
+    constexpr int SLOT = 128 * KS_COLS;
+    extern __shared__ float4 sRingF[];                        // [KS_RING][128 quads][16 columns]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kg = lane >> 4;
+    const float4 *__restrict__ H4 = reinterpret_cast<const float4 *>(a.H);
+    const float4 *__restrict__ QP4 = reinterpret_cast<const float4 *>(a.QP);
+    const int64_t Mc = a.Mc, Nc = a.Nc;
+    const int G = gridDim.x;
+    const int ts_shift = a.ts_shift, TT = 64 >> ts_shift;
+    const int n_units = (int)(Nc / KS_COLS) << ts_shift;
+
+    float4 wq[32];
+    {
+        const float4 *__restrict__ W4 = reinterpret_cast<const float4 *>(a.Wk) + 16 * wave + l15;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) wq[s] = W4[(int64_t)(4 * s + kg) * 128];
+    }
+    const float4 vv = ld4(a.v + (4 * wave + kg) * 4), bb = ld4(a.b + (4 * wave + kg) * 4);
+    const unsigned voff = (unsigned)(((int64_t)kg * Mc + l15) * 16);
+    const unsigned ring_lds = (unsigned)(uintptr_t)sRingF;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#define KF_DMA1(slot, j, gcol)                                                                       \
+    {                                                                                               \
+        const char *gb = reinterpret_cast<const char *>(H4 + (int64_t)(4 * (j)) * Mc + (gcol));     \
+        const unsigned la = ring_lds + (unsigned)(((slot) * 32 + (j)) * 1024);                      \
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(la), "v"(voff), "s"(gb) : "memory"); \
+    }
+#define KF_SB() __builtin_amdgcn_sched_barrier(0);
+#define KF_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    float *__restrict__ Sw = a.S + wave;
+
+    for (int u = blockIdx.x; u < n_units; u += G) {
+        const int f = u >> ts_shift, tb = u & ((1 << ts_shift) - 1);
+        const int64_t col0 = (int64_t)(tb * TT) * Nc + (int64_t)f * KS_COLS;
+        float4 qb;
+        {
+            const float4 q0 = QP4[(int64_t)(4 * wave + kg) * Nc + f * KS_COLS + l15];
+            __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the ring is empty here (see attn_key_score_kernel)
+            qb = make_float4(q0.x + bb.x, q0.y + bb.y, q0.z + bb.z, q0.w + bb.w);
+        }
+        KF_SB()
+        KF_BARRIER()                                          // every wave is past the previous unit's last ring read
+#pragma unroll
+        for (int k = 0; k < KS_RING - 1; ++k)
+            if (k < TT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) KF_DMA1(k, wave_u + 8 * r, col0 + (int64_t)k * Nc)
+            }
+        int slot = 0;
+        for (int i = 0; i < TT; ++i) {
+            // tile i has landed once at most the operations issued behind its four requests are outstanding: the requests of the three
+            // tiles behind it (12) and one score store per trip since (vmcnt retires in order; a count too large would read a tile that
+            // is not there, one too small waits for a request issued a moment ago).  The last tiles of a unit drain.
+            if (i + KS_RING - 2 < TT) {
+                if (i >= 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else if (i == 3) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+                else if (i == 2) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+                else if (i == 1) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            KF_BARRIER()                                      // tile i is in LDS for every wave; every wave is done with tile i - 1
+            const bool more = i + KS_RING - 1 < TT;
+            const int64_t gnext = col0 + (int64_t)(i + KS_RING - 1) * Nc;
+            const int slotp = slot == 0 ? KS_RING - 1 : slot - 1;
+            const float4 *rd = sRingF + (size_t)slot * SLOT + kg * KS_COLS + l15;
+            f32x4 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+            float4 bq[2];
+            bq[0] = rd[0];
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                KF_SB()
+                if (s + 1 < 32) bq[(s + 1) & 1] = rd[(4 * (s + 1)) * KS_COLS];
+                if ((s & 7) == 1 && more) KF_DMA1(slotp, wave_u + 8 * (s >> 3), gnext)
+                KF_SB()
+                const float4 b4 = bq[s & 1], w4 = wq[s];
+                if (s & 1) {
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, b4.x, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, b4.y, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, b4.z, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, b4.w, acc1, 0, 0, 0);
+                } else {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, b4.x, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, b4.y, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, b4.z, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, b4.w, acc0, 0, 0, 0);
+                }
+            }
+            KF_SB()
+            float part = vv.x * tanhf_acc((acc0[0] + acc1[0]) + qb.x);
+            part += vv.y * tanhf_acc((acc0[1] + acc1[1]) + qb.y);
+            part += vv.z * tanhf_acc((acc0[2] + acc1[2]) + qb.z);
+            part += vv.w * tanhf_acc((acc0[3] + acc1[3]) + qb.w);
+            part += __shfl_xor(part, 16);
+            part += __shfl_xor(part, 32);
+            if (kg == 0) Sw[(col0 + (int64_t)i * Nc + l15) * 8] = part;
+            slot = slot == KS_RING - 1 ? 0 : slot + 1;
+        }
+    }
+#undef KF_DMA1
+#undef KF_SB
+#undef KF_BARRIER
+}
+
 // row-major [n][F] -> K4 [F/4][ld]; columns n >= N are zero-filled
 __global__ void rows_to_k4_kernel(const float *__restrict__ src, int64_t N, int F, float *__restrict__ dst, int64_t ld) {
     const int64_t n = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
@@ -401,7 +517,7 @@ hipError_t sdfa_launch_attn(const AttnArgs &a, hipStream_t s) {
 }
 
 hipError_t sdfa_launch_attn_key_score(const AttnKeyArgs &a, hipStream_t s) {
-    if ((a.terms != 1 && a.terms != 3) || a.Nc % 128 || a.Mc != 64 * a.Nc || 3 * a.Mc * 16 + 256 >= ((int64_t)1 << 32)) return hipErrorInvalidValue;
+    if ((a.terms != 0 && a.terms != 1 && a.terms != 3) || a.Nc % 128 || a.Mc != 64 * a.Nc || 3 * a.Mc * 16 + 256 >= ((int64_t)1 << 32)) return hipErrorInvalidValue;
     // work units: (16 frames) x (64 >> ts_shift time steps); enough of them to give every CU two where the batch allows, never fewer
     // than eight time steps per unit (the ring is five tiles deep)
     const int cus = std::max(1, sdfa_cu_count() - a.reserve_cus);
@@ -412,7 +528,11 @@ hipError_t sdfa_launch_attn_key_score(const AttnKeyArgs &a, hipStream_t s) {
     const int grid = (int)std::min<int64_t>(n_units, cus);
     const size_t lds = ks_lds_bytes(a.terms);
     hipError_t e;
-    if (a.terms == 3) {
+    if (a.terms == 0) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_key_score_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(attn_key_score_f32_kernel, dim3(grid), dim3(512), lds, s, b);
+    } else if (a.terms == 3) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_key_score_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(attn_key_score_kernel<3>, dim3(grid), dim3(512), lds, s, b);

@@ -165,7 +165,7 @@ struct AttnKeyArgs {
     const float *v, *b;  // [128]
     float *S;            // out [Mc][8]  partial score (outputs 16w .. 16w+15) of column m = t * Nc + n per wave w
     int64_t Nc, Mc;
-    int terms;           // 1 = bf16 operands, 3 = split-bf16
+    int terms;           // 0 = exact fp32 (v_mfma_f32_16x16x4_f32), 1 = bf16 operands, 3 = split-bf16
     int reserve_cus;
     int ts_shift;        // set by the launcher: a work unit is 16 frames x (64 >> ts_shift) time steps
 };

@@ -2127,7 +2127,10 @@ static hipError_t launch_time_repair(const TimeLstmArgs &a, hipStream_t s) {
 }
 
 static SplitCtl split_ctl(const TimeLstmArgs &a) {
-    const long long us = g_sdfa_time_lstm_timeout_us > 0 ? g_sdfa_time_lstm_timeout_us : 200000;   // default 0.2 s: four times the longest kernel of this library
+    // default 20 ms (round 6; 0.2 s before): 2,000 x a healthy hand-off wait and 10 x a whole single-clip layer.  A wait only gets that long
+    // when other work keeps the partner workgroup off the device; the repair pass behind the launch makes an expiry safe (it redoes
+    // the layer, about 2 ms), so the bound is a latency cap, not a correctness margin: waiting longer than the repair costs buys nothing.
+    const long long us = g_sdfa_time_lstm_timeout_us > 0 ? g_sdfa_time_lstm_timeout_us : 20000;
     return SplitCtl{a.flags + 4, a.flags, a.status, (unsigned)std::min<long long>(us * 100, 0xffffffffll), g_sdfa_time_lstm_handoff};
 }
 

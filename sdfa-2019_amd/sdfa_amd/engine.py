@@ -205,7 +205,7 @@ class Engine(FrontendOnly):
     def time_lstm_repairs(self):
         """Waits of the cooperating-workgroup time-LSTM kernels that expired since this engine was made (include/sdfa_hip.h, "Status
         block").  Every one was repaired on the device before anything read the layer -- rows are right either way; the count says
-        that the device was so oversubscribed that a single-clip call lost about 0.2 s.  Synchronises the stream."""
+        that the device was so oversubscribed that a single-clip call lost about 20 ms (the bound of a wait) plus the 2 ms repair.  Synchronises the stream."""
         if self._ws is None:
             return self._repairs_carried
         return self._repairs_carried + int(check(lib.sdfa_workspace_status(_ptr(self._ws), 0, _stream())))

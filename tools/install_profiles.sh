@@ -30,6 +30,11 @@ if out:
     json.dump(out, open("profiles/${R}_precision_modes.json", "w"), indent=1)
 PY
 ls -la profiles/${R}_* | head -20
+# round 6: the per-mode attention counter records of tools/pmc_precision.sh <tag>_prec (bench.py: mixed_precision.<mode>.mfma_util_pct_counters)
+if [ -d ${T}_prec ]; then
+  cp ${T}_prec/attention_mfma_*.json profiles/${R}_pmc/ 2>/dev/null || true
+  [ -f ${T}_prec/summary.txt ] && cp ${T}_prec/summary.txt profiles/${R}_pmc_precision_modes.txt
+fi
 # round 3: the secondary lines come from tools/collect_extras.sh <tag2>; pass it as the third argument
 if [ -n "$3" ]; then
   X=gpurun_out/$3
