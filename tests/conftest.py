@@ -50,7 +50,7 @@ def _ensure_library():
         fcntl.flock(lock, fcntl.LOCK_EX)
         had = os.path.exists(built)
         if not had or stale():                           # another worker may have built it while this one waited
-            r = subprocess.run(["make", "-C", os.path.join(ROOT, "sdfa-2019_amd", "csrc")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            r = subprocess.run(["make", "-j", "4", "-C", os.path.join(ROOT, "sdfa-2019_amd", "csrc")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
             if not os.path.exists(built) or (r.returncode != 0 and not had):
                 LIB_PROBLEM = "building libsdfa_hip.so failed:\n" + r.stdout[-2000:]
 
