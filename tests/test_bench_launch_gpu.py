@@ -66,7 +66,7 @@ def test_a_tiny_budget_skips_the_legs_and_both_lines_are_still_printed():
     early, d = json.loads(lines[0]), json.loads(lines[-1])
     assert early["partial"] is True and d["partial"] is False and early["value"] == d["value"] > 0 and d["roofline"]["frac"] > 0
     skipped = [s["leg"] for s in d["legs_skipped"]]
-    assert skipped == ["cpu_baseline", "column_sharing", "bf16x3", "bf16x3_attention", "bf16x6", "bf16x3_column_sharing", "with_h2d_d2h", "surface"]
+    assert skipped == ["column_sharing", "bf16x3", "bf16x3_attention", "bf16x6", "bf16x3_column_sharing", "with_h2d_d2h", "surface", "cpu_baseline"]
     assert d["cpu_baseline"]["value"] is None and "did not fit" in d["cpu_baseline"]["sample"]
     assert "column_sharing" not in d and "surface" not in d and d["mixed_precision"]["value"] is None
     assert d["wall_clock"]["budget_s"] == 1.0 and d["wall_clock"]["legs_s"] == {}
