@@ -283,7 +283,8 @@ int sdfa_ensemble_mean(const float *d_a, const float *d_b, int64_t n, float *d_o
  *                      most two 128 x 128 tiles per CU with K <= 512, and any launch of less than half a tile per CU);
  *                      10 / 11 = the 64 x 128 tile of the LDS-tiled kernel never / wherever that kernel runs (default: the 8192-deep frequency
  *                      projection while it has fewer than four 128 x 128 tiles per CU -- single-clip and few-clip calls);
- *                      4 = split-bf16 x3 products (NOT exact fp32)
+ *                      4 = split-bf16 x3 products (NOT exact fp32); 7 / 12 = the split-bf16 kernels' 256 x 256 tile never / wherever it
+ *                      divides the problem (default: only where such tiles reach half the CUs -- else the 128 x 128 tile, same bits)
  *   "pca_lds"          0 = pca_dgrad_res_kernel (basis slab resident in LDS, persistent); 4 = pca_dgrad_kernel (register-direct, two
  *                      workgroups per CU: the fallback that shares a CU)
  *   "time_lstm_split"  0 = by size: a chunk whose 32-frame time-LSTM tiles leave most CUs idle (a single clip) splits each tile's gate rows
@@ -306,6 +307,9 @@ int sdfa_ensemble_mean(const float *d_a, const float *d_b, int64_t n, float *d_o
  *   "conv_fp32"        1 = the body precision modes (bf16, bf16x3, bf16x6) keep the conv stack on the fp32 kernel instead of
  *                      conv123_bf16_kernel (NOT bit-identical: that stack's operand rounding)
  *   "pca_fp32"         1 = SDFA_PREC_BF16X3 keeps the dgrad PCA expansion on the fp32 kernel (NOT bit-identical: the expansion's operand rounding)
+ *   "attn_unfused"     1 = the attention stage as key-projection GEMM + attn_kernel computing the scores from the stored projections (rounds 1-5)
+ *                      instead of attn_key_score_*_kernel (key projection + tanh + v-dot in one pass, nothing stored) + attn_kernel<true>;
+ *                      NOT bit-identical (a dot product's k order and the order of the score's partial sums differ: last-bit differences)
  *   "frontend_two_kernel" 1 = sdfa_mel_frontend_gather as share map + mel_columns_kernel + gather_features_kernel through a mel table in
  *                      HBM (rounds 2-4) instead of the spectral stream (mel_stream_kernel: mel rows in an LDS ring, no table); same bits
  *   "frontend_stream_phases" 1 = the spectral stream's workgroups alternate between transforming a phase's columns and emitting its frames
