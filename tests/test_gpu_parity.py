@@ -473,3 +473,37 @@ def test_other_weight_dynamics_vs_the_reference_operators(seed, lstm_gain, flip_
     fc, fs, hop = eng.last_frame_table
     z2, a2 = eng.encoder(feat, frame_clip=fc, frame_start=fs, hop=hop)
     assert torch.equal(z, z2) and torch.equal(align, a2)
+
+
+@pytest.mark.parametrize("mode,tol_z,tol_a", [("fp32", 3e-6, 1e-6), ("bf16x3_attention", 2e-5, 5e-6), ("bf16x6", 3e-6, 1e-6)])
+def test_one_pass_attention_agrees_with_the_three_gemm_form(synth_sd, mode, tol_z, tol_a):
+    """Round 6: attn_key_score_*_kernel computes key projection + tanh + v-dot in ONE pass over the BiLSTM output (weights in registers,
+    tiles through an LDS-DMA ring with hand-counted vmcnt, partial scores per wave) and attn_kernel<true> does softmax + context from the
+    scores; option attn_unfused = 1 brings back the key-projection GEMM + attn_kernel of rounds 1-5.  Same arithmetic up to the order of
+    a dot product's terms: z and the attention weights agree to a few ulps -- for every work-unit shape the launcher picks (a unit is 16
+    frames x 64 >> ts_shift time steps: 8 steps for a single short clip, 64 from 4,096 frames on), for ragged frame counts that leave
+    padded frames in the last tile, and run to run bitwise (the pipeline's waits are counted by hand: a miscount would show here as
+    stale tiles)."""
+    from sdfa_amd import _lib
+    eng = Engine(synth_sd["dgrad"], max_frames=4096)
+    rs = np.random.RandomState(61)
+    try:
+        eng.set_precision(mode)
+        for n in (1, 72, 129, 300, 1100, 2304, 4096):
+            x = torch.from_numpy(rs.uniform(0, 1, (n, 64, 128, 3)).astype(np.float32)).cuda()
+            _lib.set_option("attn_unfused", 1)
+            z0, a0 = eng.encoder(x)
+            z0, a0 = z0.clone(), a0.clone()
+            _lib.set_option("attn_unfused", 0)
+            z1, a1 = eng.encoder(x)
+            z1, a1 = z1.clone(), a1.clone()
+            z2, a2 = eng.encoder(x)
+            assert torch.equal(z1, z2) and torch.equal(a1, a2), (mode, n)
+            assert bool(torch.isfinite(z1).all()) and float((a1.sum(-1) - 1).abs().max()) <= 1e-5
+            dz, da = float((z0 - z1).abs().max()), float((a0 - a1).abs().max())
+            assert dz <= tol_z and da <= tol_a, (mode, n, dz, da)
+            if mode == "fp32":
+                assert dz > 0.0 or n < 16                 # the two forms really are different kernels
+    finally:
+        _lib.set_option("attn_unfused", 0)
+        eng.set_precision("fp32")
