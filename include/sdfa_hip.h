@@ -309,7 +309,9 @@ int sdfa_ensemble_mean(const float *d_a, const float *d_b, int64_t n, float *d_o
  *   "pca_fp32"         1 = SDFA_PREC_BF16X3 keeps the dgrad PCA expansion on the fp32 kernel (NOT bit-identical: the expansion's operand rounding)
  *   "attn_unfused"     1 = the attention stage as key-projection GEMM + attn_kernel computing the scores from the stored projections (rounds 1-5)
  *                      instead of attn_key_score_*_kernel (key projection + tanh + v-dot in one pass, nothing stored) + attn_kernel<true>;
- *                      NOT bit-identical (a dot product's k order and the order of the score's partial sums differ: last-bit differences)
+ *                      2 = that two-kernel form also where exact fp32 would run the WHOLE layer in one launch (attn_fused_f32_kernel: running
+ *                      softmax + context while the tile is in LDS; chunks of about 3,600 frames and more).  The three forms are NOT
+ *                      bit-identical to each other (order of a dot product's terms / of the softmax's sums: last-bit differences)
  *   "frontend_two_kernel" 1 = sdfa_mel_frontend_gather as share map + mel_columns_kernel + gather_features_kernel through a mel table in
  *                      HBM (rounds 2-4) instead of the spectral stream (mel_stream_kernel: mel rows in an LDS ring, no table); same bits
  *   "frontend_stream_phases" 1 = the spectral stream's workgroups alternate between transforming a phase's columns and emitting its frames

@@ -5,8 +5,8 @@ Usage: python profiles/pmc_summary.py <dir with MfmaUtil_/FETCH_SIZE_/WRITE_SIZE
                                       [--chunks 8192,8192,3968] [--frontend-json out.json --frames 20352] [--attention-json out.json]
 
 --attention-json: the attention stage (north_star: "MFMA utilisation on the attention stage against gfx950 peak") = every dispatch
-between a launch group's second BiLSTM recurrence and its attn_kernel, inclusive: key projection, query Conv1d, query projection
-(gemm_k4_kernel) and the softmax / context tail.  MfmaUtil is weighted by each dispatch's duration in the same pass.
+between a launch group's second BiLSTM recurrence and its attn_kernel (or attn_fused_f32_kernel, which is the whole layer in one
+launch), inclusive: query Conv1d, query projection, key projection + scores, softmax / context.  MfmaUtil is weighted by each dispatch's duration in the same pass.
 
 --chunks: the frames of the consecutive launch groups of one step (bench.py --chunk: 20,352 frames = 8192 + 8192 + 3968).  A
 PERSISTENT kernel launches the same grid whatever the problem size, so (symbol, grid) cannot tell its 8192-frame launches from
@@ -90,7 +90,7 @@ def attention_stage(path):
             continue
         if inside and "at::" not in name and not name.startswith("__amd"):
             picked.append((name, float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
-            if name.startswith("attn_kernel"):
+            if name.startswith(("attn_kernel", "attn_fused_f32_kernel")):      # the stage's last dispatch (round 6: the whole layer may be ONE launch)
                 inside = False
     tot = sum(t for _, _, t in picked)
     by = collections.OrderedDict()
@@ -107,7 +107,7 @@ def attention_json(csv_path, out_path, label, mode="fp32"):
     util, ns, per = attention_stage(csv_path)
     if util is None:
         return None
-    gem = [e for e in per if not e["kernel"].startswith("attn_kernel")]
+    gem = [e for e in per if not e["kernel"].startswith("attn_kernel")]      # (attn_fused_f32_kernel IS a matrix kernel: it stays in)
     gns = sum(e["ns"] for e in gem)
     gutil = sum(e["mfma_util_pct"] * e["ns"] for e in gem) / gns if gns else None
     print()

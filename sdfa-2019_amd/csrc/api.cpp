@@ -1138,7 +1138,7 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
         // attn_key_score_kernel); attn_kernel then does softmax + context from the scores.  The query path runs first.
         // fp32 (round 6, second half): the same pass on v_mfma_f32_16x16x4_f32 -- matrix-bound there, at the MFMA rate.  The six-product
         // mode (fp32-equivalent products) takes the exact fp32 pass too: faster than six bf16 products through a GEMM, and exact.
-        const bool key_fused = !g_sdfa_attn_unfused;
+        const bool key_fused = g_sdfa_attn_unfused != 1;
         pf.begin("attn_proj");
         GemmArgs gk{};
         gk.P = m->kp_w; gk.Q = ws + w.H1; gk.D = ws + w.KP;
@@ -1155,11 +1155,17 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
         gq.ldp = 128; gq.ldq = Nc; gq.ldd = Nc; gq.Ppad = 128; gq.Qpad = Nc; gq.Pstore = 128; gq.Qreal = Nc;
         gq.K = 512; gq.seg_k = 512; gq.act = ACT_NONE; gq.out_mode = OUT_K4; gq.terms = gk.terms;
         HIP_TRY(sdfa_launch_gemm(gq, s));
+        // exact fp32, large chunks: the whole layer in ONE pass over H (running softmax + context while the tile is in LDS: attn_fused_f32_kernel);
+        // "attn_unfused" = 2 keeps the two-kernel form
+        const bool tail_fused = key_fused && (at_terms == 0 || at_terms == 6) && g_sdfa_attn_unfused != 2 && sdfa_attn_fuses_tail(Nc, m->reserved_cus.load());
         if (key_fused) {
             AttnKeyArgs ak{};
             ak.Wk = m->kp_w; ak.H = ws + w.H1; ak.QP = ws + w.QP; ak.v = m->at_v; ak.b = m->at_b;
             ak.S = ws + w.KP;                                  // the partial scores take the first 8 Mc floats of the (unused) key-projection region
             ak.Nc = Nc; ak.Mc = Mc; ak.terms = at_terms == 6 ? 0 : at_terms; ak.reserve_cus = m->reserved_cus.load();
+            if (tail_fused) {
+                ak.fuse_tail = 1; ak.Zk4 = ws + w.ZK; ak.z_out = d_z + f0 * 512; ak.align_out = d_align ? d_align + f0 * 64 : nullptr; ak.N = N;
+            }
             HIP_TRY(sdfa_launch_attn_key_score(ak, s));
         }
         pf.end();
@@ -1169,7 +1175,7 @@ static int encoder_impl(const sdfa_model *m, const float *d_audio_feat, int64_t 
         aa.Zk4 = ws + w.ZK; aa.z_out = d_z + f0 * 512; aa.align_out = d_align ? d_align + f0 * 64 : nullptr;
         aa.N = N; aa.Nc = Nc; aa.Mc = Mc;
         aa.S = key_fused ? ws + w.KP : nullptr;
-        pf.begin("attn"); HIP_TRY(sdfa_launch_attn(aa, s)); pf.end();
+        pf.begin("attn"); if (!tail_fused) HIP_TRY(sdfa_launch_attn(aa, s)); pf.end();
     }
     return SDFA_OK;
 }

@@ -21,6 +21,28 @@ namespace {
 
 constexpr int ATT_FR = 16;   // frames per workgroup
 
+// One key of a frame's RUNNING softmax and context (the flash-attention recurrence over the 64 keys, t = 0 .. 63):
+//     m' = max(m, s);  alpha = exp(m - m');  p = exp(s - m');  l = l alpha + p;  ctx = ctx alpha + p x
+// Shared, operation for operation (explicit fma, un-contracted products), by attn_fused_f32_kernel -- which folds a tile in while it is
+// in LDS -- and by attn_kernel<true>, which streams H again: the two forms give the SAME bits, so a frame's rows do not depend on
+// the size of the chunk it is computed in (the launcher picks the form by size).
+__device__ __forceinline__ float score_of_partials(float p0, float p1, float p2, float p3, float p4, float p5, float p6, float p7) {
+    return fadd_exact(fadd_exact(fadd_exact(p0, p1), fadd_exact(p2, p3)), fadd_exact(fadd_exact(p4, p5), fadd_exact(p6, p7)));
+}
+__device__ __forceinline__ void soft_step(float sc, float &m, float &l, float &alpha, float &pw) {
+    const float mn = fmaxf(m, sc);
+    alpha = __expf(m - mn);
+    pw = __expf(sc - mn);
+    m = mn;
+    l = __builtin_fmaf(l, alpha, pw);
+}
+__device__ __forceinline__ void ctx_step(float4 &c, float alpha, float pw, const float4 &x) {
+    c.x = __builtin_fmaf(pw, x.x, fmul_exact(c.x, alpha));
+    c.y = __builtin_fmaf(pw, x.y, fmul_exact(c.y, alpha));
+    c.z = __builtin_fmaf(pw, x.z, fmul_exact(c.z, alpha));
+    c.w = __builtin_fmaf(pw, x.w, fmul_exact(c.w, alpha));
+}
+
 // GIVEN: the scores were written by attn_key_score_kernel (a.S, [t * Nc + n]); the key projections are never materialised and
 // a.KP / a.QP are not read.
 template <bool GIVEN>
@@ -35,6 +57,62 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
     const float4 *__restrict__ QP = reinterpret_cast<const float4 *>(a.QP);
     const float4 *__restrict__ H = reinterpret_cast<const float4 *>(a.H);
 
+    if constexpr (GIVEN) {
+        // Scores given (eight partial sums per column): running softmax + context in ONE sweep over the 64 keys, the recurrence
+        // attn_fused_f32_kernel runs while the tiles are in its ring (same helpers: same bits).  Lane (frame fr, part), wave w: feature
+        // quads 32w + 8 part .. + 7; every lane of a frame carries the frame's (m, l) itself -- no LDS, no barrier.
+        const float4 *__restrict__ S2 = reinterpret_cast<const float4 *>(a.S) + n * 2;
+        const float4 *__restrict__ hp = H + (int64_t)(32 * wave + 8 * part) * a.Mc + n;
+        float4 acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float m_run = -3.0e38f, l_run = 0.f;
+        // two register sets, the requests of time step t + 1 issued before step t is folded in (ten 16-byte requests per step and lane;
+        // left to itself the compiler issued them one by one, each behind a full wait: 0.9 ms per step instead of 0.5)
+        float4 pa[2], xa[8], pb[2], xb[8];
+#define AT_LOAD(P, X, t_)                                                                           \
+        {                                                                                           \
+            P[0] = S2[(int64_t)(t_) * a.Nc * 2]; P[1] = S2[(int64_t)(t_) * a.Nc * 2 + 1];           \
+            _Pragma("unroll") for (int q = 0; q < 8; ++q) X[q] = hp[(int64_t)q * a.Mc + (int64_t)(t_) * a.Nc]; \
+        }
+#define AT_FOLD(P, X)                                                                               \
+        {                                                                                           \
+            float alpha, pw;                                                                        \
+            soft_step(score_of_partials(P[0].x, P[0].y, P[0].z, P[0].w, P[1].x, P[1].y, P[1].z, P[1].w), m_run, l_run, alpha, pw); \
+            _Pragma("unroll") for (int q = 0; q < 8; ++q) ctx_step(acc[q], alpha, pw, X[q]);        \
+        }
+        AT_LOAD(pa, xa, 0)
+#pragma unroll 1
+        for (int t = 0; t < 64; t += 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            AT_LOAD(pb, xb, t + 1)
+            __builtin_amdgcn_sched_barrier(0);
+            AT_FOLD(pa, xa)
+            __builtin_amdgcn_sched_barrier(0);
+            AT_LOAD(pa, xa, t + 2 < 64 ? t + 2 : t)           // (behind the last step: a dropped re-read)
+            __builtin_amdgcn_sched_barrier(0);
+            AT_FOLD(pb, xb)
+        }
+#undef AT_LOAD
+#undef AT_FOLD
+        const float inv = 1.0f / l_run;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int fq = 32 * wave + 8 * part + q;
+            const float4 z = make_float4(acc[q].x * inv, acc[q].y * inv, acc[q].z * inv, acc[q].w * inv);
+            st4(a.Zk4 + ((int64_t)fq * a.Nc + n) * 4, z);
+            if (a.z_out && n < a.N) st4(a.z_out + n * 512 + fq * 4, z);
+        }
+        if (a.align_out && n < a.N) {              // weights of time steps 16 w + 4 part .. + 3 (each (wave, part) pair its four)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int t = 16 * wave + 4 * part + e;
+                const float4 p0 = S2[(int64_t)t * a.Nc * 2], p1 = S2[(int64_t)t * a.Nc * 2 + 1];
+                a.align_out[n * 64 + t] = __expf(score_of_partials(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w) - m_run) * inv;
+            }
+        }
+        return;
+    }
     // ---- scores: this quarter wave sums units 32p .. 32p+31 (quads 8p .. 8p+7)
     float sc[16];
     if constexpr (GIVEN) {
@@ -447,6 +525,157 @@ __global__ __launch_bounds__(512, 2) void attn_key_score_f32_kernel(AttnKeyArgs 
 #undef KF_BARRIER
 }
 
+// ------------------------------------------------------------------------------------------------
+// The WHOLE attention layer in one pass over H (exact fp32, large batches: a work unit = 16 frames x all 64 time steps).
+// attn_key_score_f32_kernel + attn_kernel<true> read H twice (projection, then context); here the context is accumulated while the
+// tile is still in the ring, with a running softmax (the flash-attention recurrence over the 64 keys of a frame):
+//     m' = max(m, s_t);  alpha = exp(m - m');  p = exp(s_t - m');  l = l alpha + p;  ctx = ctx alpha + p x_t          (t = 0 .. 63)
+//     z = ctx / l;  align_t = exp(s_t - m_final) / l      (scores kept in 4 KiB of LDS for the weights)
+// -- mathematically torch.softmax + bmm (attentions.py:69-75,121-124), rounding in another order than a two-pass softmax.  The
+// two-kernel form (attn_kernel<true>) runs the SAME recurrence with the same helpers: the forms agree bit for bit.  The pass stays matrix-bound: the context update is 16 FMAs per thread and tile, done
+// at the top of the next trip (the tile's eight partial scores meet in LDS behind the trip's barrier) before the tile's slot is handed
+// to the DMA.  Ring of four slots (being folded, being multiplied, two in flight), one barrier per tile, 133 KiB of LDS.  Thread (frame n = tid & 15, feature group fg = tid >> 4)
+// owns features 16 fg .. 16 fg + 15 of frame n's context.
+// ------------------------------------------------------------------------------------------------
+constexpr int KA_RING = 4;
+constexpr size_t ka_lds_bytes() { return (size_t)KA_RING * 128 * KS_COLS * 16 + 2 * 8 * KS_COLS * 4 + 64 * KS_COLS * 4; }
+
+__global__ __launch_bounds__(512, 2) void attn_fused_f32_kernel(AttnKeyArgs a) {
+    constexpr int SLOT = 128 * KS_COLS, TT = 64;
+    extern __shared__ float4 sRingA[];                        // [KA_RING][128 quads][16 columns]
+    float *sPart = reinterpret_cast<float *>(sRingA + KA_RING * SLOT);      // [2][8 waves][16] partial scores of a tile
+    float *sScore = sPart + 2 * 8 * KS_COLS;                                // [64][16] the unit's scores
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kg = lane >> 4;
+    const int cn = tid & 15, fg = tid >> 4;                   // context role: frame cn, features 16 fg ..
+    const float4 *__restrict__ H4 = reinterpret_cast<const float4 *>(a.H);
+    const float4 *__restrict__ QP4 = reinterpret_cast<const float4 *>(a.QP);
+    const int64_t Mc = a.Mc, Nc = a.Nc;
+    const int G = gridDim.x;
+    const int n_units = (int)(Nc / KS_COLS);
+
+    float4 wq[32];
+    {
+        const float4 *__restrict__ W4 = reinterpret_cast<const float4 *>(a.Wk) + 16 * wave + l15;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) wq[s] = W4[(int64_t)(4 * s + kg) * 128];
+    }
+    const float4 vv = ld4(a.v + (4 * wave + kg) * 4), bb = ld4(a.b + (4 * wave + kg) * 4);
+    const unsigned voff = (unsigned)(((int64_t)kg * Mc + l15) * 16);
+    const unsigned ring_lds = (unsigned)(uintptr_t)sRingA;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#define KA_DMA1(slot, j, gcol)                                                                       \
+    {                                                                                               \
+        const char *gb = reinterpret_cast<const char *>(H4 + (int64_t)(4 * (j)) * Mc + (gcol));     \
+        const unsigned la = ring_lds + (unsigned)(((slot) * 32 + (j)) * 1024);                      \
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(la), "v"(voff), "s"(gb) : "memory"); \
+    }
+#define KA_SB() __builtin_amdgcn_sched_barrier(0);
+#define KA_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // tile t_ (in ring slot sl_) is complete behind the barrier: its score, the running softmax, the context
+#define KA_FOLD(t_, sl_)                                                                            \
+    {                                                                                               \
+        const float *pp = sPart + ((t_) & 1) * 8 * KS_COLS + cn;                                    \
+        const float sc = score_of_partials(pp[0], pp[KS_COLS], pp[2 * KS_COLS], pp[3 * KS_COLS], pp[4 * KS_COLS], pp[5 * KS_COLS], pp[6 * KS_COLS], pp[7 * KS_COLS]); \
+        if (fg == 0) sScore[(t_) * KS_COLS + cn] = sc;                                              \
+        float alpha, pw;                                                                            \
+        soft_step(sc, m_run, l_run, alpha, pw);                                                     \
+        const float4 *xs = sRingA + (size_t)(sl_) * SLOT + (4 * fg) * KS_COLS + cn;                 \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) ctx_step(ctx[q], alpha, pw, xs[q * KS_COLS]); \
+    }
+
+    for (int u = blockIdx.x; u < n_units; u += G) {
+        const int64_t col0 = (int64_t)u * KS_COLS;            // first column of the unit's first tile (t = 0); the next tile is Nc columns on
+        float4 qb;
+        {
+            const float4 q0 = QP4[(int64_t)(4 * wave + kg) * Nc + u * KS_COLS + l15];
+            __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the ring is empty here; also drains the previous unit's stores
+            qb = make_float4(q0.x + bb.x, q0.y + bb.y, q0.z + bb.z, q0.w + bb.w);
+        }
+        KA_SB()
+        KA_BARRIER()                                          // every wave is past the previous unit's last LDS read
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) KA_DMA1(k, wave_u + 8 * r, col0 + (int64_t)k * Nc)
+        }
+        float4 ctx[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ctx[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float m_run = -3.0e38f, l_run = 0.f;
+        int slot = 0;
+        for (int i = 0; i < TT; ++i) {
+            // The ring in trip i: tile i - 2's slot (folded in by every wave during trip i - 1) takes tile i + 2; tile i - 1 is folded into
+            // the context; tile i is multiplied; tile i + 1 is in flight.  ONE barrier per trip.  Tile i has landed once only tile i + 1's
+            // four requests are outstanding (no stores in the stream inside a unit).
+            if (i + 1 < TT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            KA_BARRIER()                                      // tile i in LDS for every wave; tile i - 1's partial scores complete; tile i - 2 folded by all
+            const int slotp = slot == 0 ? KA_RING - 1 : slot - 1, slotn = slot >= KA_RING - 2 ? slot + 2 - KA_RING : slot + 2;
+            const bool more = i + 2 < TT;
+            const int64_t gnext = col0 + (int64_t)(i + 2) * Nc;
+            const float4 *rd = sRingA + (size_t)slot * SLOT + kg * KS_COLS + l15;
+            f32x4 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+            float4 bq[2];
+            bq[0] = rd[0];
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                KA_SB()
+                if (s + 1 < 32) bq[(s + 1) & 1] = rd[(4 * (s + 1)) * KS_COLS];
+                if ((s & 7) == 1 && more) KA_DMA1(slotn, wave_u + 8 * (s >> 3), gnext)
+                KA_SB()
+                const float4 b4 = bq[s & 1], w4 = wq[s];
+                if (s & 1) {
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, b4.x, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, b4.y, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, b4.z, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, b4.w, acc1, 0, 0, 0);
+                } else {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, b4.x, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, b4.y, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, b4.z, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, b4.w, acc0, 0, 0, 0);
+                }
+            }
+            KA_SB()
+            if (i > 0) KA_FOLD(i - 1, slotp)                  // (behind the MFMAs in program order: they are queued while this vector work runs)
+            KA_SB()
+            float part = vv.x * tanhf_acc((acc0[0] + acc1[0]) + qb.x);
+            part += vv.y * tanhf_acc((acc0[1] + acc1[1]) + qb.y);
+            part += vv.z * tanhf_acc((acc0[2] + acc1[2]) + qb.z);
+            part += vv.w * tanhf_acc((acc0[3] + acc1[3]) + qb.w);
+            part += __shfl_xor(part, 16);
+            part += __shfl_xor(part, 32);
+            if (kg == 0) sPart[((i & 1) * 8 + wave) * KS_COLS + l15] = part;
+            slot = slot == KA_RING - 1 ? 0 : slot + 1;
+        }
+        KA_BARRIER()
+        KA_FOLD(TT - 1, (slot == 0 ? KA_RING - 1 : slot - 1))
+        // the unit's 16 frames: z = ctx / l (K4 for the output MLPs + row-major), attention weights from the stored scores
+        const int64_t n = (int64_t)u * KS_COLS + cn;
+        const float inv = 1.0f / l_run;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 z = make_float4(ctx[q].x * inv, ctx[q].y * inv, ctx[q].z * inv, ctx[q].w * inv);
+            st4(a.Zk4 + ((int64_t)(4 * fg + q) * Nc + n) * 4, z);
+            if (a.z_out && n < a.N) st4(a.z_out + n * 512 + (4 * fg + q) * 4, z);
+        }
+        KA_BARRIER()                                          // the last score (written by feature group 0) is in LDS -- every thread meets here
+        if (a.align_out && n < a.N) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int t = 2 * fg + e;
+                a.align_out[n * 64 + t] = __expf(sScore[t * KS_COLS + cn] - m_run) * inv;
+            }
+        }
+    }
+#undef KA_DMA1
+#undef KA_SB
+#undef KA_BARRIER
+#undef KA_FOLD
+}
+
 // row-major [n][F] -> K4 [F/4][ld]; columns n >= N are zero-filled
 __global__ void rows_to_k4_kernel(const float *__restrict__ src, int64_t N, int F, float *__restrict__ dst, int64_t ld) {
     const int64_t n = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
@@ -516,6 +745,13 @@ hipError_t sdfa_launch_attn(const AttnArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
+bool sdfa_attn_fuses_tail(int64_t Nc, int reserve_cus) {
+    // one unit = 16 frames x all 64 time steps (no split over time: the running softmax is per frame).  Worth it from about one unit
+    // per CU: with fewer, the two-kernel form's shorter units (a quarter or an eighth of the time steps each) fill the chip better
+    const int64_t cus = std::max(1, sdfa_cu_count() - reserve_cus);
+    return (Nc / KS_COLS) >= cus - cus / 8;
+}
+
 hipError_t sdfa_launch_attn_key_score(const AttnKeyArgs &a, hipStream_t s) {
     if ((a.terms != 0 && a.terms != 1 && a.terms != 3) || a.Nc % 128 || a.Mc != 64 * a.Nc || 3 * a.Mc * 16 + 256 >= ((int64_t)1 << 32)) return hipErrorInvalidValue;
     // work units: (16 frames) x (64 >> ts_shift time steps); enough of them to give every CU two where the batch allows, never fewer
@@ -528,6 +764,14 @@ hipError_t sdfa_launch_attn_key_score(const AttnKeyArgs &a, hipStream_t s) {
     const int grid = (int)std::min<int64_t>(n_units, cus);
     const size_t lds = ks_lds_bytes(a.terms);
     hipError_t e;
+    if (a.terms == 0 && a.fuse_tail) {      // the whole layer in one pass: a unit is 16 frames x all 64 time steps
+        const size_t ldsa = ka_lds_bytes();
+        const int grid_a = (int)std::min<int64_t>(a.Nc / KS_COLS, cus);
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fused_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsa);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(attn_fused_f32_kernel, dim3(grid_a), dim3(512), ldsa, s, b);
+        return hipGetLastError();
+    }
     if (a.terms == 0) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_key_score_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

@@ -168,7 +168,14 @@ struct AttnKeyArgs {
     int terms;           // 0 = exact fp32 (v_mfma_f32_16x16x4_f32), 1 = bf16 operands, 3 = split-bf16
     int reserve_cus;
     int ts_shift;        // set by the launcher: a work unit is 16 frames x (64 >> ts_shift) time steps
+    // terms == 0 and fuse_tail: the whole attention layer in this launch (attn_fused_f32_kernel: running softmax + context while the tile
+    // is in LDS); S is not written, sdfa_launch_attn is not needed.  Outputs as AttnArgs.
+    int fuse_tail;
+    float *Zk4, *z_out, *align_out;
+    int64_t N;
 };
+// true when sdfa_launch_attn_key_score would take the one-launch form for this size (enough 16-frame units to give every CU two)
+bool sdfa_attn_fuses_tail(int64_t Nc, int reserve_cus);
 hipError_t sdfa_launch_attn_key_score(const AttnKeyArgs &a, hipStream_t s);
 
 // ---- layout helpers --------------------------------------------------------------------------

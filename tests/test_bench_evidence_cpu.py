@@ -57,7 +57,9 @@ def test_attention_stage_is_picked_by_dispatch_position(tmp_path):
     seq = [("conv123_kernel", 75, 100), ("time_lstm_kernel<2>", 84, 100), ("gemm_fat_kernel<0>", 90, 100), ("time_lstm_kernel<2>", 84, 100),
            ("gemm_k4_kernel<0>", 80, 300), ("gemm_k4_kernel<0>", 60, 100), ("attn_kernel", 0, 100), ("gemm_k4_kernel<1>", 50, 1000), ("pca_dgrad_res_kernel", 70, 100),
            # second launch group
-           ("time_lstm_kernel<1>", 82, 100), ("time_lstm_kernel<1>", 82, 100), ("gemm_k4_kernel<0>", 70, 100), ("attn_kernel", 0, 100), ("gemm_k4_kernel<1>", 50, 1000)]
+           ("time_lstm_kernel<1>", 82, 100), ("time_lstm_kernel<1>", 82, 100), ("gemm_k4_kernel<0>", 70, 100), ("attn_kernel", 0, 100), ("gemm_k4_kernel<1>", 50, 1000),
+           # third launch group (round 6): the whole layer in one launch ends the stage too
+           ("time_lstm_kernel<2>", 84, 100), ("time_lstm_kernel<2>", 84, 100), ("gemm_k4_kernel<0>", 60, 100), ("attn_fused_f32_kernel", 75, 400), ("gemm_k4_kernel<1>", 50, 1000)]
     rows, t = [], 0
     for i, (name, util, dur) in enumerate(seq):
         rows.append(f'{i},{i},256,"void (anonymous namespace)::{name}(Args)","MfmaUtil",{util},{t},{t + dur}\n')
@@ -65,9 +67,9 @@ def test_attention_stage_is_picked_by_dispatch_position(tmp_path):
     path = tmp_path / "MfmaUtil_counter_collection.csv"
     path.write_text(hdr + "".join(rows))
     util, ns, per = pmc.attention_stage(str(path))
-    assert ns == 300 + 100 + 100 + 100 + 100                                   # the MLP GEMMs behind attn_kernel are not the attention stage
-    assert abs(util - (80 * 300 + 60 * 100 + 70 * 100) / 700) < 1e-9
-    assert {e["kernel"]: e["calls"] for e in per} == {"gemm_k4_kernel<0>": 3, "attn_kernel": 2}
+    assert ns == 300 + 100 + 100 + 100 + 100 + 100 + 400                       # the MLP GEMMs behind attn_kernel / attn_fused_f32_kernel are not the attention stage
+    assert abs(util - (80 * 300 + 60 * 100 + 70 * 100 + 60 * 100 + 75 * 400) / 1200) < 1e-9
+    assert {e["kernel"]: e["calls"] for e in per} == {"gemm_k4_kernel<0>": 4, "attn_kernel": 2, "attn_fused_f32_kernel": 1}
 
 
 def test_launcher_argv_and_self_launch_relay(tmp_path, monkeypatch, capfd):

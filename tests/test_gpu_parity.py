@@ -485,11 +485,13 @@ def test_one_pass_attention_agrees_with_the_three_gemm_form(synth_sd, mode, tol_
     padded frames in the last tile, and run to run bitwise (the pipeline's waits are counted by hand: a miscount would show here as
     stale tiles)."""
     from sdfa_amd import _lib
-    eng = Engine(synth_sd["dgrad"], max_frames=4096)
+    eng = Engine(synth_sd["dgrad"], max_frames=8192)
     rs = np.random.RandomState(61)
     try:
         eng.set_precision(mode)
-        for n in (1, 72, 129, 300, 1100, 2304, 4096):
+        # (from about 3,600 frames per chunk on, exact fp32 runs the WHOLE layer in one launch -- attn_fused_f32_kernel: running softmax +
+        # context while the tile is in LDS.  attn_unfused = 2 keeps the two-kernel form there: the same recurrence, the same bits.)
+        for n in (1, 72, 129, 300, 1100, 2304, 4096, 7000, 8192, 8100):
             x = torch.from_numpy(rs.uniform(0, 1, (n, 64, 128, 3)).astype(np.float32)).cuda()
             _lib.set_option("attn_unfused", 1)
             z0, a0 = eng.encoder(x)
@@ -499,6 +501,11 @@ def test_one_pass_attention_agrees_with_the_three_gemm_form(synth_sd, mode, tol_
             z1, a1 = z1.clone(), a1.clone()
             z2, a2 = eng.encoder(x)
             assert torch.equal(z1, z2) and torch.equal(a1, a2), (mode, n)
+            if n >= 4096 and mode in ("fp32", "bf16x6"):
+                _lib.set_option("attn_unfused", 2)
+                z3, a3 = eng.encoder(x)
+                assert torch.equal(z3, z1) and torch.equal(a3, a1), (n, "one launch vs two: the same recurrence, the same bits")
+                _lib.set_option("attn_unfused", 0)
             assert bool(torch.isfinite(z1).all()) and float((a1.sum(-1) - 1).abs().max()) <= 1e-5
             dz, da = float((z0 - z1).abs().max()), float((a0 - a1).abs().max())
             assert dz <= tol_z and da <= tol_a, (mode, n, dz, da)
