@@ -276,16 +276,11 @@ __global__ __launch_bounds__(512, 2) void attn_key_score_kernel(AttnKeyArgs a) {
     const unsigned voff = (unsigned)(((int64_t)kg * Mc + l15) * 16);
     const unsigned ring_lds = (unsigned)(uintptr_t)sRing;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);  // provably wave-uniform: the request's base and M0 must be scalar registers
-#ifdef SDFA_KS_NT
-#define KS_NT " nt"
-#else
-#define KS_NT ""
-#endif
 #define KS_DMA1(slot, j, gcol)                                                                       \
     if (SDFA_KS_EXP != 2) {                                                                          \
         const char *gb = reinterpret_cast<const char *>(H4 + (int64_t)(4 * (j)) * Mc + (gcol));     \
         const unsigned la = ring_lds + (unsigned)(((slot) * 32 + (j)) * 1024);                      \
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" KS_NT ::"s"(la), "v"(voff), "s"(gb) : "memory"); \
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(la), "v"(voff), "s"(gb) : "memory"); \
     }
 #define KS_SB() __builtin_amdgcn_sched_barrier(0);
 #define KS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
