@@ -1,18 +1,23 @@
-// Bahdanau attention tail (speech_anime/layers/attentions.py:92-124,69-75) and small layout kernels.
-//
-// The dense contractions of the attention layer (query Conv1d, proj_qry, proj_key) run on the MFMA GEMM
-// (gemm.hip); this kernel does what is left per frame n:
-//     score[t] = v . tanh(qp[:, n] + kp[:, t, n] + b)          t = 0..63
+// Bahdanau attention (speech_anime/layers/attentions.py:39-75,92-124) and small layout kernels.  Per frame n, over its 64 keys t:
+//     score[t] = v . tanh(W_k x[:, t, n] + qp[:, n] + b)
 //     align    = softmax_t(score * 1.0)                         (scale_score_at_eval = 1.0)
 //     ctx      = sum_t align[t] * x[:, t, n]                    (torch.bmm(align, value))
-// One workgroup = 16 consecutive frames (Nc / 16 workgroups: 512 for an 8192-frame chunk, two per CU), lane = (frame,
-// part p = 0..3).  The kernel is a stream over H (128 KiB per frame) and KP (32 KiB per frame): every global access is a
-// 256-byte run of the K4 [feature/4][t*Nc + n] arrays per quarter wave, 8-16 independent requests in flight per lane.
-//   scores : wave w owns time steps 16w..16w+15 and ALL 128 units -- each quarter wave sums 32 of them, two __shfl_xor
-//            steps combine the quarters, so a score is complete inside its wave (no partial sums through LDS);
-//   softmax: wavefront-reduced, once: each wave keeps its 16 scores in registers, reduces (max, sum of exp) over them,
-//            and the four (max, sum) pairs per frame meet in LDS; align = exp(s - M) / sum over waves of sum_w * exp(m_w - M);
-//   context: the 64 weights of a frame go through LDS once; wave w / part p accumulates feature quads 32w+8p .. +7.
+// The query path (Conv1d over time steps 31..33, proj_qry) runs on the MFMA GEMM (gemm.hip) and gives qp.  The rest is here:
+//   attn_fused_f32_kernel      exact fp32, chunks from about 3,600 frames: the WHOLE layer in one launch that reads H once -- key
+//                              projection with the weights in registers, scores on the accumulators, running softmax + context
+//                              folded in while the tile is in an LDS-DMA ring
+//   attn_key_score_f32_kernel  the same key projection + scores for smaller chunks (time steps split over more work units; eight
+//   attn_key_score_kernel<T>   partial scores per column to HBM); <T>: bf16 (T = 1) / split-bf16 (T = 3) operands for the
+//                              mixed-precision modes, the tile split into bf16 planes in place
+//   attn_kernel<true>          softmax + context from those partial scores: the running-softmax recurrence of the one-launch form,
+//                              operation for operation (the same bits), streaming H a second time
+//   attn_kernel<false>         rounds 1-5: scores from key projections a GEMM stored (option attn_unfused = 1; an independent form the
+//                              tests compare against), two-pass softmax
+// attn_kernel: one workgroup = 16 consecutive frames (Nc / 16 workgroups: 512 for an 8192-frame chunk, two per CU), lane = (frame,
+// part p = 0..3); a stream over H (128 KiB per frame): every global access is a 256-byte run of the K4 [feature/4][t*Nc + n] arrays per
+// quarter wave.  <false> only: wave w owns time steps 16w..16w+15 and all 128 units (each quarter wave sums 32 of them, two __shfl_xor
+// steps combine the quarters), the softmax is wavefront-reduced once (per-wave (max, sum of exp) pairs meet in LDS), and the 64 weights
+// of a frame go through LDS once for the context.
 #include "common.h"
 #include "kernels.h"
 #include <algorithm>
@@ -115,15 +120,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
     }
     // ---- scores: this quarter wave sums units 32p .. 32p+31 (quads 8p .. 8p+7)
     float sc[16];
-    if constexpr (GIVEN) {
-        // eight partial scores per column (one per wave of attn_key_score_kernel), added in a fixed order
-        const float4 *__restrict__ S = reinterpret_cast<const float4 *>(a.S) + ((int64_t)(16 * wave) * a.Nc + n) * 2;
-#pragma unroll
-        for (int tt = 0; tt < 16; ++tt) {                      // the four quarters of a wave read the same words
-            const float4 p0 = S[(int64_t)tt * a.Nc * 2], p1 = S[(int64_t)tt * a.Nc * 2 + 1];
-            sc[tt] = ((p0.x + p0.y) + (p0.z + p0.w)) + ((p1.x + p1.y) + (p1.z + p1.w));
-        }
-    } else {
+    {
         float4 qb[8], vv[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
